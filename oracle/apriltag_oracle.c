@@ -1,0 +1,999 @@
+/* apriltag_oracle.c -- CPU restatement of AprilRobotics apriltag_detect() (TEST INFRASTRUCTURE).
+ * See apriltag_oracle.h for scope and parity status ("parity unpinned" beyond the reference's golden
+ * vector).  Plain C99, single-threaded, no dependencies.  Compile with -ffp-contract=off: the HIP
+ * path is compared bit-for-bit against this file, so every floating-point operation below is one
+ * IEEE-754 operation in the order written.
+ *
+ * Each function cites the step of the public AprilTag-3 algorithm it restates (SURVEY.md Appendix A
+ * numbering, "A.n") and the reference call site whose closed implementation it stands in for
+ * (paths relative to /root/reference/isaac_ros_apriltag/).
+ */
+#include "apriltag_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/apriltag_amd_families.h"
+
+/* ------------------------------------------------------------------------------------------- */
+/* parameters and families                                                                      */
+/* ------------------------------------------------------------------------------------------- */
+
+/* A.0 detector defaults; tile_size/size/max_tags defaults follow src/apriltag_node.cpp:564-567. */
+void ato_default_params(ato_params_t* p) {
+  memset(p, 0, sizeof(*p));
+  p->decimate = 1;
+  p->tile_size = 4;
+  p->min_white_black_diff = 5;
+  p->min_component_size = 25;
+  p->min_cluster_points = 24;
+  p->max_nmaxima = 10;
+  p->cos_critical_rad = 0x1.f838b8c811c17p-1; /* cos(10 deg) */
+  p->max_line_fit_mse = 10.0;
+  p->refine_edges = 1;
+  p->decode_sharpening = 0.25;
+  p->max_hamming = 2;
+  p->fx = p->fy = 1000.0;
+  p->cx = 960.0;
+  p->cy = 540.0;
+  p->tag_size = 0.22;
+}
+
+/* Accepted family strings: src/apriltag_node.cpp:47-58 (only those with an offline codebook). */
+int ato_builtin_family(const char* name, ato_family_t* out) {
+  memset(out, 0, sizeof(*out));
+  strncpy(out->name, name, sizeof(out->name) - 1);
+  if (!strcmp(name, "tag36h11")) {
+    out->d = 6; out->ncodes = APRILTAG_AMD_TAG36H11_VALIDATED; out->codes = apriltag_amd_tag36h11_codes;
+  } else if (!strcmp(name, "synth36h11")) {
+    out->d = 6; out->ncodes = APRILTAG_AMD_SYNTH36H11_NCODES; out->codes = apriltag_amd_synth36h11_codes;
+  } else if (!strcmp(name, "tag25h9")) {
+    out->d = 5; out->ncodes = APRILTAG_AMD_TAG25H9_NCODES; out->codes = apriltag_amd_tag25h9_codes;
+  } else if (!strcmp(name, "tag16h5")) {
+    out->d = 4; out->ncodes = APRILTAG_AMD_TAG16H5_NCODES; out->codes = apriltag_amd_tag16h5_codes;
+  } else {
+    return -1;
+  }
+  out->nbits = out->d * out->d;
+  out->width_at_border = out->d + 2;
+  out->total_width = out->d + 4;
+  out->reversed_border = 0;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* S1  decimation (A.1)  -- stands in for the first step inside cuAprilTagsDetect               */
+/*     (src/apriltag_node.cpp:491-493)                                                          */
+/* ------------------------------------------------------------------------------------------- */
+void ato_decimate(const uint8_t* in, int w, int h, int pitch, int f, uint8_t* out, int* sw, int* sh) {
+  int ow = 1 + (w - 1) / f, oh = 1 + (h - 1) / f;
+  for (int sy = 0; sy < oh; sy++)
+    for (int sx = 0; sx < ow; sx++) out[sy * ow + sx] = in[(size_t)(sy * f) * pitch + sx * f];
+  *sw = ow;
+  *sh = oh;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* S2  adaptive tile min/max threshold (A.2)                                                    */
+/* ------------------------------------------------------------------------------------------- */
+void ato_threshold(const uint8_t* im, int w, int h, int tile, int min_diff, uint8_t* out) {
+  int tw = w / tile, th = h / tile;
+  uint8_t* tmin = (uint8_t*)malloc((size_t)tw * th);
+  uint8_t* tmax = (uint8_t*)malloc((size_t)tw * th);
+  uint8_t* dmin = (uint8_t*)malloc((size_t)tw * th);
+  uint8_t* dmax = (uint8_t*)malloc((size_t)tw * th);
+  for (int ty = 0; ty < th; ty++)
+    for (int tx = 0; tx < tw; tx++) {
+      int mn = 255, mx = 0;
+      for (int dy = 0; dy < tile; dy++)
+        for (int dx = 0; dx < tile; dx++) {
+          int v = im[(ty * tile + dy) * w + tx * tile + dx];
+          if (v < mn) mn = v;
+          if (v > mx) mx = v;
+        }
+      tmin[ty * tw + tx] = (uint8_t)mn;
+      tmax[ty * tw + tx] = (uint8_t)mx;
+    }
+  /* 3x3 tile neighbourhood: max of max, min of min, clamped at the borders */
+  for (int ty = 0; ty < th; ty++)
+    for (int tx = 0; tx < tw; tx++) {
+      int mn = 255, mx = 0;
+      for (int dy = -1; dy <= 1; dy++) {
+        if (ty + dy < 0 || ty + dy >= th) continue;
+        for (int dx = -1; dx <= 1; dx++) {
+          if (tx + dx < 0 || tx + dx >= tw) continue;
+          int a = tmin[(ty + dy) * tw + tx + dx], b = tmax[(ty + dy) * tw + tx + dx];
+          if (a < mn) mn = a;
+          if (b > mx) mx = b;
+        }
+      }
+      dmin[ty * tw + tx] = (uint8_t)mn;
+      dmax[ty * tw + tx] = (uint8_t)mx;
+    }
+  for (int ty = 0; ty < th; ty++)
+    for (int tx = 0; tx < tw; tx++) {
+      int mn = dmin[ty * tw + tx], mx = dmax[ty * tw + tx];
+      if (mx - mn < min_diff) {
+        for (int dy = 0; dy < tile; dy++)
+          for (int dx = 0; dx < tile; dx++) out[(ty * tile + dy) * w + tx * tile + dx] = 127;
+        continue;
+      }
+      int thresh = mn + (mx - mn) / 2;
+      for (int dy = 0; dy < tile; dy++)
+        for (int dx = 0; dx < tile; dx++) {
+          int idx = (ty * tile + dy) * w + tx * tile + dx;
+          out[idx] = (im[idx] > thresh) ? 255 : 0;
+        }
+    }
+  /* pixels right of / below the last full tile use the nearest tile; no low-contrast rule there */
+  for (int y = 0; y < h; y++) {
+    int x0 = (y >= th * tile) ? 0 : tw * tile;
+    int ty = y / tile;
+    if (ty >= th) ty = th - 1;
+    for (int x = x0; x < w; x++) {
+      int tx = x / tile;
+      if (tx >= tw) tx = tw - 1;
+      int mn = dmin[ty * tw + tx], mx = dmax[ty * tw + tx];
+      int thresh = mn + (mx - mn) / 2;
+      out[y * w + x] = (im[y * w + x] > thresh) ? 255 : 0;
+    }
+  }
+  free(tmin); free(tmax); free(dmin); free(dmax);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* S3  union-find connected components (A.3)                                                    */
+/*     Links: for x in [1, w-2]: left; up (y>0); and for white pixels up-left / up-right.       */
+/*     CANONICAL: representative = smallest pixel index of the component.                       */
+/* ------------------------------------------------------------------------------------------- */
+static uint32_t uf_find(uint32_t* parent, uint32_t i) {
+  uint32_t r = i;
+  while (parent[r] != r) r = parent[r];
+  while (parent[i] != r) { uint32_t n = parent[i]; parent[i] = r; i = n; }
+  return r;
+}
+static void uf_union(uint32_t* parent, uint32_t a, uint32_t b) {
+  a = uf_find(parent, a);
+  b = uf_find(parent, b);
+  if (a == b) return;
+  if (a < b) parent[b] = a; else parent[a] = b;
+}
+
+void ato_connected_components(const uint8_t* thr, int w, int h, uint32_t* label, uint32_t* csize) {
+  size_t n = (size_t)w * h;
+  uint32_t* parent = (uint32_t*)malloc(n * sizeof(uint32_t));
+  for (size_t i = 0; i < n; i++) parent[i] = (uint32_t)i;
+  for (int y = 0; y < h; y++)
+    for (int x = 1; x < w - 1; x++) {
+      int v = thr[y * w + x];
+      if (v == 127) continue;
+      uint32_t i = (uint32_t)(y * w + x);
+      if (thr[y * w + x - 1] == v) uf_union(parent, i, i - 1);
+      if (y > 0) {
+        if (thr[(y - 1) * w + x] == v) uf_union(parent, i, i - w);
+        if (v == 255) {
+          if (thr[(y - 1) * w + x - 1] == v) uf_union(parent, i, i - w - 1);
+          if (thr[(y - 1) * w + x + 1] == v) uf_union(parent, i, i - w + 1);
+        }
+      }
+    }
+  memset(csize, 0, n * sizeof(uint32_t));
+  for (size_t i = 0; i < n; i++) {
+    if (thr[i] == 127) { label[i] = ATO_NO_LABEL; continue; }
+    uint32_t r = uf_find(parent, (uint32_t)i);
+    label[i] = r;
+    csize[r]++;
+  }
+  free(parent);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* S4  boundary points and clusters (A.4)                                                       */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct { uint64_t key; uint32_t pt; } kp_t;
+
+static int kp_cmp(const void* a, const void* b) {
+  const kp_t* x = (const kp_t*)a; const kp_t* y = (const kp_t*)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  if (x->pt != y->pt) return x->pt < y->pt ? -1 : 1;
+  return 0;
+}
+
+static inline uint32_t pack_point(int x, int y, int gx, int gy) {
+  /* x,y half-pixel units (< 2^14); gx,gy in {-255,0,255} -> code {0,1,2} */
+  return ((uint32_t)x << 18) | ((uint32_t)y << 4) | ((uint32_t)(gx / 255 + 1) << 2) | (uint32_t)(gy / 255 + 1);
+}
+static inline void unpack_point(uint32_t p, int* x, int* y, int* gx, int* gy) {
+  *x = (int)(p >> 18);
+  *y = (int)((p >> 4) & 0x3FFF);
+  *gx = ((int)((p >> 2) & 3) - 1) * 255;
+  *gy = ((int)(p & 3) - 1) * 255;
+}
+
+/* Collects every boundary point with its component-pair key, sorted by (key, packed point). */
+static kp_t* gradient_points(const uint8_t* thr, const uint32_t* label, const uint32_t* csize, int w, int h,
+                             int min_comp, size_t* nout) {
+  static const int DX[4] = {1, 0, -1, 1}, DY[4] = {0, 1, 1, 1};
+  size_t cap = 1 << 16, n = 0;
+  kp_t* pts = (kp_t*)malloc(cap * sizeof(kp_t));
+  for (int y = 1; y < h - 1; y++)
+    for (int x = 1; x < w - 1; x++) {
+      int v0 = thr[y * w + x];
+      if (v0 == 127) continue;
+      uint32_t r0 = label[y * w + x];
+      if ((int)csize[r0] < min_comp) continue;
+      for (int k = 0; k < 4; k++) {
+        int x1 = x + DX[k], y1 = y + DY[k];
+        int v1 = thr[y1 * w + x1];
+        if (v0 + v1 != 255) continue;
+        uint32_t r1 = label[y1 * w + x1];
+        if ((int)csize[r1] < min_comp) continue;   /* upstream: size > 24 */
+        uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
+        if (n == cap) { cap *= 2; pts = (kp_t*)realloc(pts, cap * sizeof(kp_t)); }
+        pts[n].key = key;
+        pts[n].pt = pack_point(2 * x + DX[k], 2 * y + DY[k], DX[k] * (v1 - v0), DY[k] * (v1 - v0));
+        n++;
+      }
+    }
+  qsort(pts, n, sizeof(kp_t), kp_cmp);
+  *nout = n;
+  return pts;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* S5  quad fitting (A.5)                                                                       */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct { double Mx, My, Mxx, Mxy, Myy, W; } lfp_t;
+
+static const float GAUSS7[7] = {0x1.6c0504p-7f, 0x1.152aaap-3f, 0x1.368b3p-1f, 1.0f,
+                                0x1.368b3p-1f, 0x1.152aaap-3f, 0x1.6c0504p-7f};
+
+static void fit_line(const lfp_t* lfps, int sz, int i0, int i1, double* lineparm, double* err, double* mse) {
+  double Mx, My, Mxx, Mxy, Myy, W;
+  int N;
+  if (i0 < i1) {
+    N = i1 - i0 + 1;
+    Mx = lfps[i1].Mx; My = lfps[i1].My; Mxx = lfps[i1].Mxx; Mxy = lfps[i1].Mxy; Myy = lfps[i1].Myy; W = lfps[i1].W;
+    if (i0 > 0) {
+      Mx -= lfps[i0 - 1].Mx; My -= lfps[i0 - 1].My; Mxx -= lfps[i0 - 1].Mxx;
+      Mxy -= lfps[i0 - 1].Mxy; Myy -= lfps[i0 - 1].Myy; W -= lfps[i0 - 1].W;
+    }
+  } else {
+    Mx = lfps[sz - 1].Mx - lfps[i0 - 1].Mx; My = lfps[sz - 1].My - lfps[i0 - 1].My;
+    Mxx = lfps[sz - 1].Mxx - lfps[i0 - 1].Mxx; Mxy = lfps[sz - 1].Mxy - lfps[i0 - 1].Mxy;
+    Myy = lfps[sz - 1].Myy - lfps[i0 - 1].Myy; W = lfps[sz - 1].W - lfps[i0 - 1].W;
+    Mx += lfps[i1].Mx; My += lfps[i1].My; Mxx += lfps[i1].Mxx; Mxy += lfps[i1].Mxy; Myy += lfps[i1].Myy; W += lfps[i1].W;
+    N = sz - i0 + i1 + 1;
+  }
+  double Ex = Mx / W, Ey = My / W;
+  double Cxx = Mxx / W - Ex * Ex, Cxy = Mxy / W - Ex * Ey, Cyy = Myy / W - Ey * Ey;
+  double disc = (Cxx - Cyy) * (Cxx - Cyy) + 4 * Cxy * Cxy;
+  float rootf = sqrtf((float)disc);
+  double eig_small = 0.5 * (Cxx + Cyy - (double)rootf);
+  if (lineparm) {
+    lineparm[0] = Ex; lineparm[1] = Ey;
+    double eig = 0.5 * (Cxx + Cyy + (double)rootf);
+    double nx1 = Cxx - eig, ny1 = Cxy, M1 = nx1 * nx1 + ny1 * ny1;
+    double nx2 = Cxy, ny2 = Cyy - eig, M2 = nx2 * nx2 + ny2 * ny2;
+    double nx, ny, M;
+    if (M1 > M2) { nx = nx1; ny = ny1; M = M1; } else { nx = nx2; ny = ny2; M = M2; }
+    double length = (double)sqrtf((float)M);
+    if (fabs(length) < 1e-12) { lineparm[2] = lineparm[3] = 0; }
+    else { lineparm[2] = nx / length; lineparm[3] = ny / length; }
+  }
+  if (err) *err = N * eig_small;
+  if (mse) *mse = eig_small;
+}
+
+static int dbl_desc(const void* a, const void* b) {
+  double x = *(const double*)a, y = *(const double*)b;
+  return (x < y) - (x > y);
+}
+
+static int quad_segment_maxima(const ato_params_t* prm, const lfp_t* lfps, int sz, int indices[4]) {
+  int ksz = sz / 12 < 20 ? sz / 12 : 20;
+  if (ksz < 2) return 0;
+  double* errs = (double*)malloc(sizeof(double) * sz);
+  double* sm = (double*)malloc(sizeof(double) * sz);
+  for (int i = 0; i < sz; i++) fit_line(lfps, sz, (i + sz - ksz) % sz, (i + ksz) % sz, NULL, &errs[i], NULL);
+  for (int iy = 0; iy < sz; iy++) {
+    double acc = 0;
+    for (int i = 0; i < 7; i++) acc += errs[(iy + i - 3 + sz) % sz] * (double)GAUSS7[i];
+    sm[iy] = acc;
+  }
+  memcpy(errs, sm, sizeof(double) * sz);
+  free(sm);
+  int* maxima = (int*)malloc(sizeof(int) * sz);
+  double* maxima_errs = (double*)malloc(sizeof(double) * sz);
+  int nmaxima = 0;
+  for (int i = 0; i < sz; i++)
+    if (errs[i] > errs[(i + 1) % sz] && errs[i] > errs[(i + sz - 1) % sz]) {
+      maxima[nmaxima] = i; maxima_errs[nmaxima] = errs[i]; nmaxima++;
+    }
+  int ok = 0;
+  if (nmaxima >= 4) {
+    if (nmaxima > prm->max_nmaxima) {
+      double* cp = (double*)malloc(sizeof(double) * nmaxima);
+      memcpy(cp, maxima_errs, sizeof(double) * nmaxima);
+      qsort(cp, nmaxima, sizeof(double), dbl_desc);
+      double thresh = cp[prm->max_nmaxima];
+      int out = 0;
+      for (int in = 0; in < nmaxima; in++) {
+        if (maxima_errs[in] <= thresh) continue;
+        maxima[out++] = maxima[in];
+      }
+      nmaxima = out;
+      free(cp);
+    }
+    int best[4] = {0, 0, 0, 0};
+    double best_error = (double)HUGE_VALF;
+    double err01, err12, err23, err30, mse01, mse12, mse23, mse30, p01[4], p12[4];
+    double max_dot = prm->cos_critical_rad;
+    for (int m0 = 0; m0 < nmaxima - 3; m0++) {
+      int i0 = maxima[m0];
+      for (int m1 = m0 + 1; m1 < nmaxima - 2; m1++) {
+        int i1 = maxima[m1];
+        fit_line(lfps, sz, i0, i1, p01, &err01, &mse01);
+        if (mse01 > prm->max_line_fit_mse) continue;
+        for (int m2 = m1 + 1; m2 < nmaxima - 1; m2++) {
+          int i2 = maxima[m2];
+          fit_line(lfps, sz, i1, i2, p12, &err12, &mse12);
+          if (mse12 > prm->max_line_fit_mse) continue;
+          double dot = p01[2] * p12[2] + p01[3] * p12[3];
+          if (fabs(dot) > max_dot) continue;
+          for (int m3 = m2 + 1; m3 < nmaxima; m3++) {
+            int i3 = maxima[m3];
+            fit_line(lfps, sz, i2, i3, NULL, &err23, &mse23);
+            if (mse23 > prm->max_line_fit_mse) continue;
+            fit_line(lfps, sz, i3, i0, NULL, &err30, &mse30);
+            if (mse30 > prm->max_line_fit_mse) continue;
+            double err = err01 + err12 + err23 + err30;
+            if (err < best_error) { best_error = err; best[0] = i0; best[1] = i1; best[2] = i2; best[3] = i3; }
+          }
+        }
+      }
+    }
+    if (best_error != (double)HUGE_VALF) {
+      for (int i = 0; i < 4; i++) indices[i] = best[i];
+      if (best_error / sz < prm->max_line_fit_mse) ok = 1;
+    }
+  }
+  free(errs); free(maxima); free(maxima_errs);
+  return ok;
+}
+
+static inline uint32_t float_sortable(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+static int u64_cmp(const void* a, const void* b) {
+  uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+  return (x > y) - (x < y);
+}
+
+/* fit one quad to the cluster pts[0..sz) (packed points); gray = working image (w x h). */
+static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, const uint32_t* pts, int sz,
+                    int tag_width, int normal_border, int reversed_border, ato_quad_t* quad) {
+  if (sz < 24) return 0;
+  int xmin = 1 << 30, xmax = -1, ymin = 1 << 30, ymax = -1;
+  long long sxg = 0, sgx = 0, sgy = 0;
+  for (int i = 0; i < sz; i++) {
+    int x, y, gx, gy;
+    unpack_point(pts[i], &x, &y, &gx, &gy);
+    if (x < xmin) xmin = x;
+    if (x > xmax) xmax = x;
+    if (y < ymin) ymin = y;
+    if (y > ymax) ymax = y;
+    sxg += (long long)x * gx + (long long)y * gy;
+    sgx += gx; sgy += gy;
+  }
+  if ((xmax - xmin) * (ymax - ymin) < tag_width) return 0;
+  double cxd = (xmin + xmax) * 0.5 + 0.05118, cyd = (ymin + ymax) * 0.5 + -0.028581;
+  /* CANONICAL: dot = sum(dx*gx + dy*gy) evaluated exactly (upstream: float accumulation in hash order) */
+  double dot = (double)sxg - cxd * (double)sgx - cyd * (double)sgy;
+  quad->reversed_border = dot < 0;
+  if (!reversed_border && quad->reversed_border) return 0;
+  if (!normal_border && !quad->reversed_border) return 0;
+
+  /* slope key: quadrant band + dy/dx after rotating into the first quadrant (float, as upstream) */
+  float cx = (float)cxd, cy = (float)cyd;
+  uint64_t* keys = (uint64_t*)malloc(sizeof(uint64_t) * sz);
+  for (int i = 0; i < sz; i++) {
+    int x, y, gx, gy;
+    unpack_point(pts[i], &x, &y, &gx, &gy);
+    float dx = (float)x - cx, dy = (float)y - cy;
+    float quadrant;
+    if (dy > 0) quadrant = (dx > 0) ? 65536.0f : 131072.0f;
+    else quadrant = (dx > 0) ? 0.0f : -65536.0f;
+    if (dy < 0) { dy = -dy; dx = -dx; }
+    if (dx < 0) { float tmp = dx; dx = dy; dy = -tmp; }
+    float slope = quadrant + dy / dx;
+    /* CANONICAL total order: (slope, y, x, gx, gy) */
+    keys[i] = ((uint64_t)float_sortable(slope) << 32) | ((uint64_t)y << 18) | ((uint64_t)x << 4) | (pts[i] & 15u);
+  }
+  qsort(keys, sz, sizeof(uint64_t), u64_cmp);
+
+  /* cumulative weighted moments (compute_lfps), sequential double accumulation */
+  lfp_t* lfps = (lfp_t*)malloc(sizeof(lfp_t) * sz);
+  lfp_t acc = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < sz; i++) {
+    int px = (int)((keys[i] >> 4) & 0x3FFF), py = (int)((keys[i] >> 18) & 0x3FFF);
+    double x = px * .5 + 0.5, y = py * .5 + 0.5;
+    int ix = (int)x, iy = (int)y;
+    double W = 1;
+    if (ix > 0 && ix + 1 < w && iy > 0 && iy + 1 < h) {
+      int grad_x = gray[iy * w + ix + 1] - gray[iy * w + ix - 1];
+      int grad_y = gray[(iy + 1) * w + ix] - gray[(iy - 1) * w + ix];
+      W = sqrt((double)(grad_x * grad_x + grad_y * grad_y)) + 1;
+    }
+    acc.Mx += W * x; acc.My += W * y; acc.Mxx += W * x * x; acc.Mxy += W * x * y; acc.Myy += W * y * y; acc.W += W;
+    lfps[i] = acc;
+  }
+  free(keys);
+
+  int res = 0, indices[4];
+  double lines[4][4];
+  if (!quad_segment_maxima(prm, lfps, sz, indices)) goto finish;
+  for (int i = 0; i < 4; i++) {
+    double mse;
+    fit_line(lfps, sz, indices[i], indices[(i + 1) & 3], lines[i], NULL, &mse);
+    if (mse > prm->max_line_fit_mse) goto finish;
+  }
+  for (int i = 0; i < 4; i++) {
+    double A00 = lines[i][3], A01 = -lines[(i + 1) & 3][3];
+    double A10 = -lines[i][2], A11 = lines[(i + 1) & 3][2];
+    double B0 = -lines[i][0] + lines[(i + 1) & 3][0];
+    double B1 = -lines[i][1] + lines[(i + 1) & 3][1];
+    double det = A00 * A11 - A10 * A01;
+    if (fabs(det) < 0.001) goto finish;
+    double W00 = A11 / det, W01 = -A01 / det;
+    double L0 = W00 * B0 + W01 * B1;
+    quad->p[i][0] = (float)(lines[i][0] + L0 * A00);
+    quad->p[i][1] = (float)(lines[i][1] + L0 * A10);
+  }
+  {
+    /* area of the two triangles (Heron) */
+    double area = 0, length[3], p;
+    for (int i = 0; i < 3; i++) {
+      int a = i, b = (i + 1) % 3;
+      double ddx = (double)quad->p[b][0] - (double)quad->p[a][0], ddy = (double)quad->p[b][1] - (double)quad->p[a][1];
+      length[i] = sqrt(ddx * ddx + ddy * ddy);
+    }
+    p = (length[0] + length[1] + length[2]) / 2;
+    area += sqrt(p * (p - length[0]) * (p - length[1]) * (p - length[2]));
+    static const int idxs[4] = {2, 3, 0, 2};
+    for (int i = 0; i < 3; i++) {
+      int a = idxs[i], b = idxs[i + 1];
+      double ddx = (double)quad->p[b][0] - (double)quad->p[a][0], ddy = (double)quad->p[b][1] - (double)quad->p[a][1];
+      length[i] = sqrt(ddx * ddx + ddy * ddy);
+    }
+    p = (length[0] + length[1] + length[2]) / 2;
+    area += sqrt(p * (p - length[0]) * (p - length[1]) * (p - length[2]));
+    if (area < 0.95 * tag_width * tag_width) goto finish;
+  }
+  for (int i = 0; i < 4; i++) {
+    int i0 = i, i1 = (i + 1) & 3, i2 = (i + 2) & 3;
+    double dx1 = (double)quad->p[i1][0] - (double)quad->p[i0][0], dy1 = (double)quad->p[i1][1] - (double)quad->p[i0][1];
+    double dx2 = (double)quad->p[i2][0] - (double)quad->p[i1][0], dy2 = (double)quad->p[i2][1] - (double)quad->p[i1][1];
+    double cos_dtheta = (dx1 * dx2 + dy1 * dy2) / sqrt((dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2));
+    if ((cos_dtheta > prm->cos_critical_rad || cos_dtheta < -prm->cos_critical_rad) || dx1 * dy2 < dy1 * dx2) goto finish;
+  }
+  res = 1;
+finish:
+  free(lfps);
+  return res;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* S6  edge refinement on the full-resolution image (A.6)                                       */
+/*     Deviation: the refitted line normal is taken from the covariance eigenvector (the fit_line */
+/*     formulation upstream's own TODO names) instead of 0.5*atan2f/cosf/sinf, so that no          */
+/*     transcendental library call sits between the CPU and HIP results.                          */
+/* ------------------------------------------------------------------------------------------- */
+static void refine_edges(const ato_params_t* prm, const uint8_t* im, int w, int h, int pitch, ato_quad_t* quad) {
+  double lines[4][4];
+  for (int edge = 0; edge < 4; edge++) {
+    int a = edge, b = (edge + 1) & 3;
+    double nx = (double)quad->p[b][1] - (double)quad->p[a][1];
+    double ny = -(double)quad->p[b][0] + (double)quad->p[a][0];
+    double mag = sqrt(nx * nx + ny * ny);
+    nx /= mag; ny /= mag;
+    if (quad->reversed_border) { nx = -nx; ny = -ny; }
+    int nsamples = (int)(mag / 8);
+    if (nsamples < 16) nsamples = 16;
+    double Mx = 0, My = 0, Mxx = 0, Mxy = 0, Myy = 0, N = 0;
+    for (int s = 0; s < nsamples; s++) {
+      double alpha = (1.0 + s) / (nsamples + 1);
+      double x0 = alpha * (double)quad->p[a][0] + (1 - alpha) * (double)quad->p[b][0];
+      double y0 = alpha * (double)quad->p[a][1] + (1 - alpha) * (double)quad->p[b][1];
+      double Mn = 0, Mcount = 0;
+      double range = prm->decimate + 1;
+      int steps = (int)(2 * range * 4) + 1;   /* n = -range + 0.25*k, exact in binary */
+      for (int k = 0; k < steps; k++) {
+        double n = -range + 0.25 * k;
+        double grange = 1;
+        int x1 = (int)(x0 + (n + grange) * nx);
+        int y1 = (int)(y0 + (n + grange) * ny);
+        if (x1 < 0 || x1 >= w || y1 < 0 || y1 >= h) continue;
+        int x2 = (int)(x0 + (n - grange) * nx);
+        int y2 = (int)(y0 + (n - grange) * ny);
+        if (x2 < 0 || x2 >= w || y2 < 0 || y2 >= h) continue;
+        int g1 = im[(size_t)y1 * pitch + x1];
+        int g2 = im[(size_t)y2 * pitch + x2];
+        if (g1 < g2) continue;
+        double weight = (double)((g2 - g1) * (g2 - g1));
+        Mn += weight * n;
+        Mcount += weight;
+      }
+      if (Mcount == 0) continue;
+      double n0 = Mn / Mcount;
+      double bestx = x0 + n0 * nx, besty = y0 + n0 * ny;
+      Mx += bestx; My += besty; Mxx += bestx * bestx; Mxy += bestx * besty; Myy += besty * besty; N++;
+    }
+    double Ex = Mx / N, Ey = My / N;
+    double Cxx = Mxx / N - Ex * Ex, Cxy = Mxy / N - Ex * Ey, Cyy = Myy / N - Ey * Ey;
+    double disc = (Cxx - Cyy) * (Cxx - Cyy) + 4 * Cxy * Cxy;
+    double eig = 0.5 * (Cxx + Cyy + (double)sqrtf((float)disc));
+    double nx1 = Cxx - eig, ny1 = Cxy, M1 = nx1 * nx1 + ny1 * ny1;
+    double nx2 = Cxy, ny2 = Cyy - eig, M2 = nx2 * nx2 + ny2 * ny2;
+    double M;
+    if (M1 > M2) { nx = nx1; ny = ny1; M = M1; } else { nx = nx2; ny = ny2; M = M2; }
+    double length = (double)sqrtf((float)M);
+    if (fabs(length) < 1e-12) { nx = 0; ny = 0; } else { nx = nx / length; ny = ny / length; }
+    lines[edge][0] = Ex; lines[edge][1] = Ey; lines[edge][2] = nx; lines[edge][3] = ny;
+  }
+  for (int i = 0; i < 4; i++) {
+    double A00 = lines[i][3], A01 = -lines[(i + 1) & 3][3];
+    double A10 = -lines[i][2], A11 = lines[(i + 1) & 3][2];
+    double B0 = -lines[i][0] + lines[(i + 1) & 3][0];
+    double B1 = -lines[i][1] + lines[(i + 1) & 3][1];
+    double det = A00 * A11 - A10 * A01;
+    if (fabs(det) > 0.001) {
+      double W00 = A11 / det, W01 = -A01 / det;
+      double L0 = W00 * B0 + W01 * B1;
+      quad->p[i][0] = (float)(lines[i][0] + L0 * A00);
+      quad->p[i][1] = (float)(lines[i][1] + L0 * A10);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* S6b homography by 8x9 Gaussian elimination (A.7)                                             */
+/* ------------------------------------------------------------------------------------------- */
+static int homography_compute2(const double c[4][4], double H[9]) {
+  double A[72];
+  for (int i = 0; i < 4; i++) {
+    double x = c[i][0], y = c[i][1], u = c[i][2], v = c[i][3];
+    double* r0 = &A[(2 * i) * 9];
+    double* r1 = &A[(2 * i + 1) * 9];
+    r0[0] = x; r0[1] = y; r0[2] = 1; r0[3] = 0; r0[4] = 0; r0[5] = 0; r0[6] = -x * u; r0[7] = -y * u; r0[8] = u;
+    r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = x; r1[4] = y; r1[5] = 1; r1[6] = -x * v; r1[7] = -y * v; r1[8] = v;
+  }
+  for (int col = 0; col < 8; col++) {
+    double max_val = 0;
+    int max_idx = -1;
+    for (int row = col; row < 8; row++) {
+      double val = fabs(A[row * 9 + col]);
+      if (val > max_val) { max_val = val; max_idx = row; }
+    }
+    if (max_val < 1e-10) return -1;
+    if (max_idx != col)
+      for (int i = col; i < 9; i++) { double t = A[col * 9 + i]; A[col * 9 + i] = A[max_idx * 9 + i]; A[max_idx * 9 + i] = t; }
+    for (int i = col + 1; i < 8; i++) {
+      double f = A[i * 9 + col] / A[col * 9 + col];
+      A[i * 9 + col] = 0;
+      for (int j = col + 1; j < 9; j++) A[i * 9 + j] -= f * A[col * 9 + j];
+    }
+  }
+  for (int col = 7; col >= 0; col--) {
+    double sum = 0;
+    for (int i = col + 1; i < 8; i++) sum += A[col * 9 + i] * A[i * 9 + 8];
+    A[col * 9 + 8] = (A[col * 9 + 8] - sum) / A[col * 9 + col];
+  }
+  for (int i = 0; i < 8; i++) H[i] = A[i * 9 + 8];
+  H[8] = 1;
+  return 0;
+}
+
+static inline void homography_project(const double H[9], double x, double y, double* ox, double* oy) {
+  double xx = H[0] * x + H[1] * y + H[2];
+  double yy = H[3] * x + H[4] * y + H[5];
+  double zz = H[6] * x + H[7] * y + H[8];
+  *ox = xx / zz;
+  *oy = yy / zz;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* S7  decode (A.8)                                                                             */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct { double A[3][3], B[3], C[3]; } graymodel_t;
+
+static void graymodel_add(graymodel_t* gm, double x, double y, double gray) {
+  gm->A[0][0] += x * x; gm->A[0][1] += x * y; gm->A[0][2] += x;
+  gm->A[1][1] += y * y; gm->A[1][2] += y; gm->A[2][2] += 1;
+  gm->B[0] += x * gray; gm->B[1] += y * gray; gm->B[2] += gray;
+}
+/* 3x3 symmetric solve via Cholesky, upper-triangle input */
+static void graymodel_solve(graymodel_t* gm) {
+  double A0 = gm->A[0][0], A1 = gm->A[0][1], A2 = gm->A[0][2], A4 = gm->A[1][1], A5 = gm->A[1][2], A8 = gm->A[2][2];
+  double L0 = sqrt(A0);
+  double L3 = A1 / L0;
+  double L6 = A2 / L0;
+  double L4 = sqrt(A4 - L3 * L3);
+  double L7 = (A5 - L3 * L6) / L4;
+  double L8 = sqrt(A8 - L6 * L6 - L7 * L7);
+  double M0 = 1 / L0;
+  double M3 = -L3 * M0 / L4;
+  double M4 = 1 / L4;
+  double M6 = (-L6 * M0 - L7 * M3) / L8;
+  double M7 = -L7 * M4 / L8;
+  double M8 = 1 / L8;
+  double t0 = M0 * gm->B[0];
+  double t1 = M3 * gm->B[0] + M4 * gm->B[1];
+  double t2 = M6 * gm->B[0] + M7 * gm->B[1] + M8 * gm->B[2];
+  gm->C[0] = M0 * t0 + M3 * t1 + M6 * t2;
+  gm->C[1] = M4 * t1 + M7 * t2;
+  gm->C[2] = M8 * t2;
+}
+static inline double graymodel_interpolate(const graymodel_t* gm, double x, double y) {
+  return gm->C[0] * x + gm->C[1] * y + gm->C[2];
+}
+
+static double value_for_pixel(const uint8_t* im, int w, int h, int pitch, double px, double py) {
+  int x1 = (int)floor(px - 0.5), x2 = (int)ceil(px - 0.5);
+  double x = px - 0.5 - x1;
+  int y1 = (int)floor(py - 0.5), y2 = (int)ceil(py - 0.5);
+  double y = py - 0.5 - y1;
+  if (x1 < 0 || x2 >= w || y1 < 0 || y2 >= h) return -1;
+  return im[(size_t)y1 * pitch + x1] * (1 - x) * (1 - y) + im[(size_t)y1 * pitch + x2] * x * (1 - y) +
+         im[(size_t)y2 * pitch + x1] * (1 - x) * y + im[(size_t)y2 * pitch + x2] * x * y;
+}
+
+/* pattern rotation used by the code lookup: new(r,c) = old(c, d-1-r) */
+static uint64_t rotate90(uint64_t w, int d) {
+  uint64_t o = 0;
+  int nb = d * d;
+  for (int r = 0; r < d; r++)
+    for (int c = 0; c < d; c++) {
+      int sr = c, sc = d - 1 - r;
+      if ((w >> (nb - 1 - (sr * d + sc))) & 1) o |= 1ULL << (nb - 1 - (r * d + c));
+    }
+  return o;
+}
+
+/* quick_decode_codeword semantics: first rotation r in 0..3 for which some code is within
+ * max_hamming bits (unique by the family's minimum distance). */
+static int decode_codeword(const ato_family_t* fam, uint64_t rcode, int max_hamming, int* id, int* hamming, int* rotation) {
+  for (int r = 0; r < 4; r++) {
+    int best = 1 << 30, bid = -1;
+    for (uint32_t i = 0; i < fam->ncodes; i++) {
+      int hd = __builtin_popcountll(rcode ^ fam->codes[i]);
+      if (hd < best) { best = hd; bid = (int)i; }
+    }
+    if (best <= max_hamming) { *id = bid; *hamming = best; *rotation = r; return 1; }
+    rcode = rotate90(rcode, (int)fam->d);
+  }
+  return 0;
+}
+
+static float quad_decode(const ato_params_t* prm, const ato_family_t* fam, const uint8_t* im, int w, int h, int pitch,
+                         const double H[9], int* id, int* hamming, int* rotation, int* found) {
+  int wb = (int)fam->width_at_border, tw = (int)fam->total_width;
+  float patterns[40] = {
+      -0.5f, 0.5f, 0, 1, 1,            /* left white column */
+      0.5f, 0.5f, 0, 1, 0,             /* left black column */
+      (float)wb + 0.5f, 0.5f, 0, 1, 1, /* right white column */
+      (float)wb - 0.5f, 0.5f, 0, 1, 0, /* right black column */
+      0.5f, -0.5f, 1, 0, 1,            /* top white row */
+      0.5f, 0.5f, 1, 0, 0,             /* top black row */
+      0.5f, (float)wb + 0.5f, 1, 0, 1, /* bottom white row */
+      0.5f, (float)wb - 0.5f, 1, 0, 0  /* bottom black row */
+  };
+  graymodel_t whitemodel, blackmodel;
+  memset(&whitemodel, 0, sizeof(whitemodel));
+  memset(&blackmodel, 0, sizeof(blackmodel));
+  *found = 0;
+  for (int pi = 0; pi < 8; pi++) {
+    const float* pat = &patterns[pi * 5];
+    int is_white = (int)pat[4];
+    for (int i = 0; i < wb; i++) {
+      double tagx01 = ((double)pat[0] + i * (double)pat[2]) / wb;
+      double tagy01 = ((double)pat[1] + i * (double)pat[3]) / wb;
+      double tagx = 2 * (tagx01 - 0.5), tagy = 2 * (tagy01 - 0.5);
+      double px, py;
+      homography_project(H, tagx, tagy, &px, &py);
+      int ix = (int)px, iy = (int)py;
+      if (ix < 0 || iy < 0 || ix >= w || iy >= h) continue;
+      int v = im[(size_t)iy * pitch + ix];
+      if (is_white) graymodel_add(&whitemodel, tagx, tagy, v);
+      else graymodel_add(&blackmodel, tagx, tagy, v);
+    }
+  }
+  graymodel_solve(&whitemodel);
+  graymodel_solve(&blackmodel);
+  if ((graymodel_interpolate(&whitemodel, 0, 0) - graymodel_interpolate(&blackmodel, 0, 0) < 0) != fam->reversed_border)
+    return -1;
+
+  double values[12 * 12];
+  memset(values, 0, sizeof(values));
+  int min_coord = (wb - tw) / 2;
+  int d = (int)fam->d;
+  for (int i = 0; i < (int)fam->nbits; i++) {
+    int bitx = 1 + i % d, bity = 1 + i / d;
+    double tagx01 = (bitx + 0.5) / wb, tagy01 = (bity + 0.5) / wb;
+    double tagx = 2 * (tagx01 - 0.5), tagy = 2 * (tagy01 - 0.5);
+    double px, py;
+    homography_project(H, tagx, tagy, &px, &py);
+    double v = value_for_pixel(im, w, h, pitch, px, py);
+    if (v == -1) continue;
+    double thresh = (graymodel_interpolate(&blackmodel, tagx, tagy) + graymodel_interpolate(&whitemodel, tagx, tagy)) / 2.0;
+    values[tw * (bity - min_coord) + bitx - min_coord] = v - thresh;
+  }
+  /* sharpen: values += decode_sharpening * Laplacian(values) */
+  {
+    static const double kernel[9] = {0, -1, 0, -1, 4, -1, 0, -1, 0};
+    double sharpened[12 * 12];
+    for (int y = 0; y < tw; y++)
+      for (int x = 0; x < tw; x++) {
+        double s = 0;
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++) {
+            if ((y + i - 1) < 0 || (y + i - 1) > tw - 1 || (x + j - 1) < 0 || (x + j - 1) > tw - 1) continue;
+            s += values[(y + i - 1) * tw + (x + j - 1)] * kernel[i * 3 + j];
+          }
+        sharpened[y * tw + x] = s;
+      }
+    for (int i = 0; i < tw * tw; i++) values[i] = values[i] + prm->decode_sharpening * sharpened[i];
+  }
+  float black_score = 0, white_score = 0, black_count = 1, white_count = 1;
+  uint64_t rcode = 0;
+  for (int i = 0; i < (int)fam->nbits; i++) {
+    int bitx = 1 + i % d, bity = 1 + i / d;
+    rcode <<= 1;
+    double v = values[(bity - min_coord) * tw + bitx - min_coord];
+    if (v > 0) { white_score = (float)((double)white_score + v); white_count++; rcode |= 1; }
+    else { black_score = (float)((double)black_score - v); black_count++; }
+  }
+  *found = decode_codeword(fam, rcode, prm->max_hamming, id, hamming, rotation);
+  float a = white_score / white_count, b = black_score / black_count;
+  return a < b ? a : b;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* S8  reconcile duplicates + ordering (A.9)                                                    */
+/* ------------------------------------------------------------------------------------------- */
+static double orient2d(const double* a, const double* b, const double* c) {
+  return (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0]);
+}
+static int on_segment(const double* a, const double* b, const double* c) {
+  double lox = a[0] < b[0] ? a[0] : b[0], hix = a[0] < b[0] ? b[0] : a[0];
+  double loy = a[1] < b[1] ? a[1] : b[1], hiy = a[1] < b[1] ? b[1] : a[1];
+  return c[0] >= lox && c[0] <= hix && c[1] >= loy && c[1] <= hiy;
+}
+static int segments_intersect(const double* p1, const double* p2, const double* q1, const double* q2) {
+  double d1 = orient2d(q1, q2, p1), d2 = orient2d(q1, q2, p2);
+  double d3 = orient2d(p1, p2, q1), d4 = orient2d(p1, p2, q2);
+  if (((d1 > 0 && d2 < 0) || (d1 < 0 && d2 > 0)) && ((d3 > 0 && d4 < 0) || (d3 < 0 && d4 > 0))) return 1;
+  if (d1 == 0 && on_segment(q1, q2, p1)) return 1;
+  if (d2 == 0 && on_segment(q1, q2, p2)) return 1;
+  if (d3 == 0 && on_segment(p1, p2, q1)) return 1;
+  if (d4 == 0 && on_segment(p1, p2, q2)) return 1;
+  return 0;
+}
+static int point_in_quad(const double poly[4][2], const double* q) {
+  int inside = 0;
+  for (int i = 0, j = 3; i < 4; j = i++) {
+    if (((poly[i][1] > q[1]) != (poly[j][1] > q[1])) &&
+        (q[0] < (poly[j][0] - poly[i][0]) * (q[1] - poly[i][1]) / (poly[j][1] - poly[i][1]) + poly[i][0]))
+      inside = !inside;
+  }
+  return inside;
+}
+static int quads_overlap(const double a[4][2], const double b[4][2]) {
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++)
+      if (segments_intersect(a[i], a[(i + 1) & 3], b[j], b[(j + 1) & 3])) return 1;
+  if (point_in_quad(a, b[0])) return 1;
+  if (point_in_quad(b, a[0])) return 1;
+  return 0;
+}
+/* CANONICAL preference order: family, id, lower hamming, higher margin, then corner coordinates */
+static int det_cmp(const void* pa, const void* pb) {
+  const ato_detection_t* a = (const ato_detection_t*)pa;
+  const ato_detection_t* b = (const ato_detection_t*)pb;
+  if (a->family != b->family) return a->family < b->family ? -1 : 1;
+  if (a->id != b->id) return a->id < b->id ? -1 : 1;
+  if (a->hamming != b->hamming) return a->hamming < b->hamming ? -1 : 1;
+  if (a->decision_margin != b->decision_margin) return a->decision_margin > b->decision_margin ? -1 : 1;
+  for (int i = 0; i < 4; i++)
+    for (int k = 0; k < 2; k++)
+      if (a->p[i][k] != b->p[i][k]) return a->p[i][k] < b->p[i][k] ? -1 : 1;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* S9  planar pose from the homography (A.10, "reference homography solve")                     */
+/* ------------------------------------------------------------------------------------------- */
+static void mat33_inv_transpose(const double* M, double* O) {
+  double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+  double c10 = M[2] * M[7] - M[1] * M[8], c11 = M[0] * M[8] - M[2] * M[6], c12 = M[1] * M[6] - M[0] * M[7];
+  double c20 = M[1] * M[5] - M[2] * M[4], c21 = M[2] * M[3] - M[0] * M[5], c22 = M[0] * M[4] - M[1] * M[3];
+  double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+  /* inverse = adj/det = cof^T/det, so inverse-transpose = cof/det */
+  O[0] = c00 / det; O[1] = c01 / det; O[2] = c02 / det;
+  O[3] = c10 / det; O[4] = c11 / det; O[5] = c12 / det;
+  O[6] = c20 / det; O[7] = c21 / det; O[8] = c22 / det;
+}
+
+void ato_pose_from_homography(const double H[9], double fx_in, double fy, double cx, double cy, double tag_size,
+                              double R[9], double t[3]) {
+  double fx = -fx_in; /* upstream calls homography_to_pose(H, -fx, fy, cx, cy) */
+  double R20 = H[6], R21 = H[7], TZ = H[8];
+  double R00 = (H[0] - cx * R20) / fx, R01 = (H[1] - cx * R21) / fx, TX = (H[2] - cx * TZ) / fx;
+  double R10 = (H[3] - cy * R20) / fy, R11 = (H[4] - cy * R21) / fy, TY = (H[5] - cy * TZ) / fy;
+  double length1 = (double)sqrtf((float)(R00 * R00 + R10 * R10 + R20 * R20));
+  double length2 = (double)sqrtf((float)(R01 * R01 + R11 * R11 + R21 * R21));
+  double s = 1.0 / (double)sqrtf((float)(length1 * length2));
+  if (TZ > 0) s *= -1;
+  R20 *= s; R21 *= s; TZ *= s; R00 *= s; R01 *= s; TX *= s; R10 *= s; R11 *= s; TY *= s;
+  double R02 = R10 * R21 - R20 * R11, R12 = R20 * R01 - R00 * R21, R22 = R00 * R11 - R10 * R01;
+  /* polar decomposition (upstream: R = U*V' from the SVD); here the orthogonal polar factor by a
+   * fixed number of Newton steps X <- (X + X^-T)/2, which converges to the same matrix. */
+  double X[9] = {R00, R01, R02, R10, R11, R12, R20, R21, R22};
+  for (int it = 0; it < 12; it++) {
+    double Y[9];
+    mat33_inv_transpose(X, Y);
+    for (int i = 0; i < 9; i++) X[i] = 0.5 * (X[i] + Y[i]);
+  }
+  double scale = tag_size / 2.0;
+  TX *= scale; TY *= scale; TZ *= scale;
+  /* fix = diag(1,-1,-1): camera looks along +z, y down */
+  R[0] = X[0]; R[1] = X[1]; R[2] = X[2];
+  R[3] = -X[3]; R[4] = -X[4]; R[5] = -X[5];
+  R[6] = -X[6]; R[7] = -X[7]; R[8] = -X[8];
+  t[0] = TX; t[1] = -TY; t[2] = -TZ;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* full pipeline -- the CPU stand-in for one cuAprilTagsDetect call                             */
+/* (src/apriltag_node.cpp:491-493)                                                              */
+/* ------------------------------------------------------------------------------------------- */
+static int quad_key_cmp(const void* a, const void* b) {
+  const ato_quad_t* x = (const ato_quad_t*)a; const ato_quad_t* y = (const ato_quad_t*)b;
+  return (x->key > y->key) - (x->key < y->key);
+}
+
+int ato_detect(const ato_params_t* prm, const ato_family_t* fams, int nfam, const uint8_t* image, int width,
+               int height, int pitch, ato_detection_t* out, int max_det, ato_dump_t* dump) {
+  if (nfam < 1 || nfam > ATO_MAX_FAMILIES || prm->decimate < 1 || prm->tile_size < 1) return -1;
+  int f = prm->decimate;
+  int w = 1 + (width - 1) / f, h = 1 + (height - 1) / f;
+  if (w / prm->tile_size < 1 || h / prm->tile_size < 1 || 2 * w + 1 >= (1 << 14) || 2 * h + 1 >= (1 << 14)) return -2;
+  size_t n = (size_t)w * h;
+  uint8_t* gray = (uint8_t*)malloc(n);
+  uint8_t* thr = (uint8_t*)malloc(n);
+  uint32_t* label = (uint32_t*)malloc(n * 4);
+  uint32_t* csize = (uint32_t*)malloc(n * 4);
+  int sw, sh;
+  ato_decimate(image, width, height, pitch, f, gray, &sw, &sh);
+  ato_threshold(gray, w, h, prm->tile_size, prm->min_white_black_diff, thr);
+  ato_connected_components(thr, w, h, label, csize);
+
+  size_t npts;
+  kp_t* kp = gradient_points(thr, label, csize, w, h, prm->min_component_size, &npts);
+
+  /* family-derived quad parameters */
+  int min_tag_width = 1000000, normal_border = 0, reversed_border = 0;
+  for (int i = 0; i < nfam; i++) {
+    if ((int)fams[i].width_at_border < min_tag_width) min_tag_width = (int)fams[i].width_at_border;
+    normal_border |= !fams[i].reversed_border;
+    reversed_border |= fams[i].reversed_border;
+  }
+  min_tag_width = (int)((float)min_tag_width / (float)f);
+  if (min_tag_width < 3) min_tag_width = 3;
+
+  /* clusters -> quads */
+  uint32_t maxpts = (uint32_t)(3 * (2 * w + 2 * h));
+  size_t qcap = 64, nq = 0;
+  ato_quad_t* quads = (ato_quad_t*)malloc(qcap * sizeof(ato_quad_t));
+  uint32_t* ptsbuf = (uint32_t*)malloc((npts ? npts : 1) * 4);
+  size_t ccap = 64, nc = 0, npk = 0;
+  ato_cluster_t* clusters = (ato_cluster_t*)malloc(ccap * sizeof(ato_cluster_t));
+  for (size_t i = 0; i < npts;) {
+    size_t j = i;
+    while (j < npts && kp[j].key == kp[i].key) j++;
+    size_t cnt = j - i;
+    if (cnt >= (size_t)prm->min_cluster_points && cnt <= maxpts) {
+      if (nc == ccap) { ccap *= 2; clusters = (ato_cluster_t*)realloc(clusters, ccap * sizeof(ato_cluster_t)); }
+      clusters[nc].key = kp[i].key; clusters[nc].start = (uint32_t)npk; clusters[nc].count = (uint32_t)cnt; nc++;
+      for (size_t k = i; k < j; k++) ptsbuf[npk++] = kp[k].pt;
+      ato_quad_t q;
+      memset(&q, 0, sizeof(q));
+      q.key = kp[i].key;
+      if (fit_quad(prm, gray, w, h, &ptsbuf[npk - cnt], (int)cnt, min_tag_width, normal_border, reversed_border, &q)) {
+        if (f > 1)
+          for (int c = 0; c < 4; c++) {
+            q.p[c][0] = (float)(((double)q.p[c][0] - 0.5) * (double)(float)f + 0.5);
+            q.p[c][1] = (float)(((double)q.p[c][1] - 0.5) * (double)(float)f + 0.5);
+          }
+        if (nq == qcap) { qcap *= 2; quads = (ato_quad_t*)realloc(quads, qcap * sizeof(ato_quad_t)); }
+        quads[nq++] = q;
+      }
+    }
+    i = j;
+  }
+  free(kp);
+  qsort(quads, nq, sizeof(ato_quad_t), quad_key_cmp);
+
+  /* decode */
+  size_t dcap = 64, nd = 0;
+  ato_detection_t* dets = (ato_detection_t*)malloc(dcap * sizeof(ato_detection_t));
+  for (size_t qi = 0; qi < nq; qi++) {
+    ato_quad_t q = quads[qi];
+    if (prm->refine_edges) refine_edges(prm, image, width, height, pitch, &q);
+    double corr[4][4], H[9];
+    for (int i = 0; i < 4; i++) {
+      corr[i][0] = (i == 0 || i == 3) ? -1 : 1;
+      corr[i][1] = (i == 0 || i == 1) ? -1 : 1;
+      corr[i][2] = (double)q.p[i][0];
+      corr[i][3] = (double)q.p[i][1];
+    }
+    if (homography_compute2(corr, H) != 0) continue;
+    for (int fi = 0; fi < nfam; fi++) {
+      if (fams[fi].reversed_border != q.reversed_border) continue;
+      int id = 0, hamming = 0, rotation = 0, found = 0;
+      float margin = quad_decode(prm, &fams[fi], image, width, height, pitch, H, &id, &hamming, &rotation, &found);
+      if (!(margin >= 0 && found)) continue;
+      if (nd == dcap) { dcap *= 2; dets = (ato_detection_t*)realloc(dets, dcap * sizeof(ato_detection_t)); }
+      ato_detection_t* det = &dets[nd++];
+      memset(det, 0, sizeof(*det));
+      det->family = fi; det->id = id; det->hamming = hamming; det->decision_margin = margin;
+      /* H' = H * Rz(rotation * 90 deg), with exact {0,+-1} entries */
+      static const double CS[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};
+      double c = CS[rotation][0], s = CS[rotation][1];
+      for (int r = 0; r < 3; r++) {
+        det->H[r * 3 + 0] = H[r * 3 + 0] * c + H[r * 3 + 1] * s;
+        det->H[r * 3 + 1] = H[r * 3 + 0] * -s + H[r * 3 + 1] * c;
+        det->H[r * 3 + 2] = H[r * 3 + 2];
+      }
+      homography_project(det->H, 0, 0, &det->c[0], &det->c[1]);
+      for (int i = 0; i < 4; i++) {
+        double tcx = (i == 1 || i == 2) ? 1 : -1, tcy = (i < 2) ? 1 : -1;
+        homography_project(det->H, tcx, tcy, &det->p[i][0], &det->p[i][1]);
+      }
+    }
+  }
+  /* reconcile + order */
+  qsort(dets, nd, sizeof(ato_detection_t), det_cmp);
+  size_t nk = 0;
+  for (size_t i = 0; i < nd; i++) {
+    int dead = 0;
+    for (size_t j = 0; j < nk && !dead; j++)
+      if (dets[j].family == dets[i].family && dets[j].id == dets[i].id && quads_overlap(dets[j].p, dets[i].p)) dead = 1;
+    if (!dead) dets[nk++] = dets[i];
+  }
+  nd = nk;
+  for (size_t i = 0; i < nd; i++)
+    ato_pose_from_homography(dets[i].H, prm->fx, prm->fy, prm->cx, prm->cy, prm->tag_size, dets[i].R, dets[i].t);
+
+  int nout = (int)(nd < (size_t)max_det ? nd : (size_t)max_det);
+  for (int i = 0; i < nout; i++) out[i] = dets[i];
+
+  if (dump) {
+    dump->w = w; dump->h = h; dump->gray = gray; dump->thr = thr; dump->label = label; dump->csize = csize;
+    dump->nclusters = (uint32_t)nc; dump->clusters = clusters; dump->npoints = (uint32_t)npk; dump->points = ptsbuf;
+    dump->nquads = (uint32_t)nq; dump->quads = quads; dump->ndet = (uint32_t)nd; dump->dets = dets;
+  } else {
+    free(gray); free(thr); free(label); free(csize); free(clusters); free(ptsbuf); free(quads); free(dets);
+  }
+  return nout;
+}
+
+void ato_dump_free(ato_dump_t* d) {
+  free(d->gray); free(d->thr); free(d->label); free(d->csize); free(d->clusters); free(d->points); free(d->quads);
+  free(d->dets);
+  memset(d, 0, sizeof(*d));
+}

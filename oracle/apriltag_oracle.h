@@ -1,0 +1,118 @@
+/* apriltag_oracle.h -- CPU restatement of the AprilRobotics apriltag_detect() pipeline.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (isaac_ros_apriltag_amd/) links, imports
+ * or calls this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * PARITY STATUS: "parity unpinned" beyond the reference's own golden numbers.  The detector
+ * arithmetic of the reference lives in closed binaries (libcuapriltags.a, called at
+ * isaac_ros_apriltag/src/apriltag_node.cpp:450-452,491-493; NVIDIA VPI, called at :228-231,:290-301)
+ * and AprilRobotics' apriltag is not vendored/installed.  This file restates
+ * the published AprilTag-3 algorithm (Olson 2011; Wang & Olson 2016; AprilRobotics/apriltag 3.x,
+ * BSD-2) from its public description; it is pinned against the reference's golden vector
+ * (isaac_ros_apriltag/test/isaac_ros_apriltag_pol_test.py:113-175) and against the analytic ground
+ * truth of the in-repo renderer.  Where the public algorithm accumulates in a data-dependent order
+ * (hash iteration), this restatement fixes a canonical order; those places are marked CANONICAL.
+ */
+#ifndef APRILTAG_ORACLE_H_
+#define APRILTAG_ORACLE_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ATO_MAX_FAMILIES 4
+#define ATO_NO_LABEL 0xFFFFFFFFu
+
+typedef struct {
+  char name[32];
+  uint32_t nbits;            /* data bits = d*d */
+  uint32_t d;                /* data cells per side */
+  uint32_t width_at_border;  /* cells border-to-border (d + 2 for the classic families) */
+  uint32_t total_width;      /* incl. white quiet ring (d + 4) */
+  int32_t reversed_border;   /* 0 for the classic families */
+  uint32_t ncodes;
+  const uint64_t* codes;     /* row-major, MSB = top-left data cell, 1 = white */
+} ato_family_t;
+
+typedef struct {
+  int32_t decimate;              /* quad_decimate, integer >= 1 */
+  int32_t tile_size;             /* 4 (apriltag_node.cpp:566 default) */
+  int32_t min_white_black_diff;  /* 5 */
+  int32_t min_component_size;    /* 25 */
+  int32_t min_cluster_points;    /* 24 */
+  int32_t max_nmaxima;           /* 10 */
+  double cos_critical_rad;       /* cos(10 deg) */
+  double max_line_fit_mse;       /* 10 */
+  int32_t refine_edges;          /* 1 */
+  double decode_sharpening;      /* 0.25 */
+  int32_t max_hamming;           /* 2 */
+  double fx, fy, cx, cy;         /* intrinsics K[0],K[4],K[2],K[5] (apriltag_node.cpp:442-446) */
+  double tag_size;               /* metres, black-border edge (apriltag_node.cpp:565) */
+} ato_params_t;
+
+typedef struct {
+  int32_t family;   /* index into the family list */
+  int32_t id;
+  int32_t hamming;
+  float decision_margin;
+  double H[9];      /* row-major homography tag[-1,1]^2 -> image */
+  double c[2];      /* centre = H(0,0) */
+  double p[4][2];   /* AprilRobotics order: H(-1,1), H(1,1), H(1,-1), H(-1,-1) */
+  double R[9];      /* row-major rotation, tag frame in camera optical frame */
+  double t[3];      /* metres */
+} ato_detection_t;
+
+typedef struct {
+  float p[4][2];
+  int32_t reversed_border;
+  uint64_t key;     /* component-pair key of the cluster the quad came from */
+} ato_quad_t;
+
+typedef struct {
+  uint64_t key;     /* (min(rep0,rep1) << 32) | max(rep0,rep1) */
+  uint32_t start;   /* offset into points[] */
+  uint32_t count;
+} ato_cluster_t;
+
+/* Stage dump of one frame (all arrays malloc'ed by ato_detect_dump, freed by ato_dump_free). */
+typedef struct {
+  int32_t w, h;                 /* working-image size */
+  uint8_t* gray;                /* decimated gray image, w*h */
+  uint8_t* thr;                 /* threshold image, w*h */
+  uint32_t* label;              /* w*h, canonical representative (min pixel index) or ATO_NO_LABEL */
+  uint32_t* csize;              /* w*h, component size stored at the representative's index */
+  uint32_t nclusters;
+  ato_cluster_t* clusters;      /* kept clusters (min_cluster_points <= count <= 3*(2w+2h)), sorted by key */
+  uint32_t npoints;
+  uint32_t* points;             /* packed (x<<18)|(y<<4)|(gxc<<2)|gyc, per cluster sorted ascending */
+  uint32_t nquads;
+  ato_quad_t* quads;            /* after fit (working-image coords scaled back to full-res), sorted by key */
+  uint32_t ndet;
+  ato_detection_t* dets;        /* final detections (after reconcile + sort) */
+} ato_dump_t;
+
+void ato_default_params(ato_params_t* p);
+/* Built-in family tables (include/apriltag_amd_families.h). Returns 0 on success. */
+int ato_builtin_family(const char* name, ato_family_t* out);
+
+/* stage entry points (each follows the cited public algorithm step) */
+void ato_decimate(const uint8_t* in, int w, int h, int pitch, int f, uint8_t* out, int* sw, int* sh);
+void ato_threshold(const uint8_t* im, int w, int h, int tile, int min_diff, uint8_t* out);
+void ato_connected_components(const uint8_t* thr, int w, int h, uint32_t* label, uint32_t* csize);
+
+/* Full pipeline. image is mono8 pitch-linear. Returns number of detections written (<= max_det),
+ * or a negative error code. dump may be NULL. */
+int ato_detect(const ato_params_t* prm, const ato_family_t* fams, int nfam,
+               const uint8_t* image, int width, int height, int pitch,
+               ato_detection_t* out, int max_det, ato_dump_t* dump);
+void ato_dump_free(ato_dump_t* d);
+
+/* Pose from a detection homography ("reference homography solve", AprilRobotics
+ * estimate_pose_for_tag_homography). */
+void ato_pose_from_homography(const double H[9], double fx, double fy, double cx, double cy,
+                              double tag_size, double R[9], double t[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
