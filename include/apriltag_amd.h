@@ -1,0 +1,216 @@
+/* apriltag_amd.h -- C ABI of the MI355X-native AprilTag detector (libapriltag_amd.so).
+ *
+ * Drop-in boundary for the detector calls the reference node makes into NVIDIA's closed
+ * cuAprilTags library (paths relative to /root/reference/isaac_ros_apriltag/):
+ *
+ *   amdCreateAprilTagsDetector   replaces nvCreateAprilTagsDetector   src/apriltag_node.cpp:450-452
+ *   amdAprilTagsDetect           replaces cuAprilTagsDetect           src/apriltag_node.cpp:491-493
+ *   amdAprilTagsDestroy          replaces cuAprilTagsDestroy          src/apriltag_node.cpp:556
+ *   amdAprilTagsImageInput_t     replaces cuAprilTagsImageInput_t     src/apriltag_node.cpp:481-486
+ *   amdAprilTagsID_t             replaces cuAprilTagsID_t             src/apriltag_node.cpp:412-419,509-516
+ *   amdAprilTagsCameraIntrinsics_t replaces cuAprilTagsCameraIntrinsics_t  src/apriltag_node.cpp:447
+ *   amdAprilTagsFamily           replaces cuAprilTagsFamily           src/apriltag_node.cpp:401-407
+ *
+ * Differences that are part of the contract (north_star of BASELINE.json):
+ *   - the image is mono8 (1 byte/pixel, pitch-linear, DEVICE memory); colour input is converted
+ *     first with amdAprilTagsConvertToMono8 (stands in for vpiSubmitConvertImageFormat,
+ *     src/apriltag_node.cpp:275-282; accepted encodings = the table at :76-82);
+ *   - a batched entry point (amdAprilTagsDetectBatch) processes independent frames in one
+ *     submission; a HIP stream replaces the CUDA stream;
+ *   - more than one tag family can be enabled (amdCreateAprilTagsDetectorEx).
+ * Ownership and threading follow the reference's use: the caller owns the input buffers and the
+ * output arrays (host memory); the library owns everything behind the handle; one thread per handle;
+ * every Detect call is host-synchronous (results valid on return).  All functions return 0 on
+ * success and a non-zero amdAprilTagsStatus otherwise (the node drops the frame on a non-zero
+ * detect status and throws on a non-zero create status, src/apriltag_node.cpp:453-457,494-497).
+ *
+ * Plain C, no C++ or torch types.  hipStream_t is passed as void* so that this header needs no HIP
+ * include; pass NULL for the detector's own stream.
+ */
+#ifndef APRILTAG_AMD_H_
+#define APRILTAG_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct amdAprilTagsDetector_st* amdAprilTagsHandle;
+typedef void* amdAprilTagsStream; /* hipStream_t */
+
+typedef enum {
+  AMDAT_SUCCESS = 0,
+  AMDAT_INVALID_ARGUMENT = 1,
+  AMDAT_UNSUPPORTED = 2,      /* tile size / family / encoding not supported */
+  AMDAT_HIP_ERROR = 3,
+  AMDAT_SIZE_MISMATCH = 4,    /* image size differs from the size given at creation */
+  AMDAT_OUT_OF_MEMORY = 5,
+  AMDAT_BATCH_TOO_LARGE = 6
+} amdAprilTagsStatus;
+
+/* Per-frame status bits reported by amdAprilTagsGetFrameFlags (capacity overflows are reported,
+ * never undefined behaviour). */
+#define AMDAT_FLAG_POINTS_OVERFLOW 0x1u    /* boundary points dropped */
+#define AMDAT_FLAG_HASH_OVERFLOW 0x2u      /* cluster table full */
+#define AMDAT_FLAG_CLUSTERS_OVERFLOW 0x4u  /* cluster list full */
+#define AMDAT_FLAG_QUADS_OVERFLOW 0x8u     /* quad list full */
+#define AMDAT_FLAG_DETS_OVERFLOW 0x10u     /* detection list full */
+
+typedef enum {
+  AMDAT_TAG36H11 = 0,   /* ids 0..26 built in (see include/apriltag_amd_families.h) */
+  AMDAT_TAG25H9 = 1,
+  AMDAT_TAG16H5 = 2,
+  AMDAT_SYNTH36H11 = 3, /* stand-in 36-bit family, NOT the published tag36h11 table */
+  AMDAT_CUSTOM0 = 4,    /* slots filled by amdAprilTagsRegisterFamily */
+  AMDAT_CUSTOM1 = 5,
+  AMDAT_ENUM_SIZE = 6
+} amdAprilTagsFamily;
+
+typedef struct {
+  float fx, fy, cx, cy;
+} amdAprilTagsCameraIntrinsics_t;
+
+typedef struct {
+  uint32_t width;
+  uint32_t height;
+  const uint8_t* dev_ptr; /* mono8, device memory */
+  size_t pitch;           /* bytes per row */
+} amdAprilTagsImageInput_t;
+
+typedef struct {
+  float x, y;
+} amdFloat2;
+
+/* One detection.  The leading fields have the meaning the reference reads from cuAprilTagsID_t:
+ * corners in the library's native order (= message order, src/apriltag_node.cpp:512-517; for an
+ * upright tag: top-left, top-right, bottom-right, bottom-left), orientation COLUMN-major 3x3
+ * (src/apriltag_node.cpp:416-419), translation in metres. */
+typedef struct {
+  uint16_t id;
+  amdFloat2 corners[4];
+  uint16_t hamming_error;
+  float orientation[9];
+  float translation[3];
+  /* extensions */
+  uint16_t family;        /* amdAprilTagsFamily */
+  uint16_t reserved;
+  float decision_margin;
+  amdFloat2 center;       /* H(0,0); the reference recomputes it from the diagonals (:519-530) */
+} amdAprilTagsID_t;
+
+/* Full-precision record (parity tests, pose consumers): AprilRobotics conventions. */
+typedef struct {
+  int32_t family; /* index into the detector's family list */
+  int32_t id;
+  int32_t hamming;
+  float decision_margin;
+  double H[9];    /* row-major homography, tag [-1,1]^2 -> pixels */
+  double c[2];    /* centre */
+  double p[4][2]; /* H(-1,1), H(1,1), H(1,-1), H(-1,-1) */
+  double R[9];    /* row-major rotation, tag frame in the camera optical frame */
+  double t[3];    /* metres */
+} amdAprilTagsDetectionEx_t;
+
+typedef struct {
+  uint32_t width, height;      /* input image size (fixed for the handle, as in the reference) */
+  uint32_t tile_size;          /* 4 (src/apriltag_node.cpp:566); other values: AMDAT_UNSUPPORTED */
+  uint32_t decimate;           /* quad_decimate, integer >= 1 (1 = cuAprilTags behaviour) */
+  uint32_t num_families;       /* 1..4 */
+  amdAprilTagsFamily families[4];
+  amdAprilTagsCameraIntrinsics_t intrinsics;
+  float tag_size;              /* metres (src/apriltag_node.cpp:565) */
+  uint32_t max_batch;          /* frames per submission the handle is sized for (>= 1) */
+  uint32_t refine_edges;       /* 1 */
+  uint32_t max_hamming;        /* 2 */
+  float decode_sharpening;     /* 0.25 */
+  /* capacities per frame; 0 = defaults derived from the image size */
+  uint32_t max_points;         /* boundary points */
+  uint32_t hash_slots;         /* power of two */
+  uint32_t max_clusters;
+  uint32_t max_quads;
+  uint32_t max_detections;
+  int32_t device;              /* HIP device ordinal, -1 = current */
+} amdAprilTagsConfig_t;
+
+void amdAprilTagsDefaultConfig(amdAprilTagsConfig_t* cfg, uint32_t width, uint32_t height);
+
+/* nvCreateAprilTagsDetector-shaped constructor (one family, batch 1, decimate 1). */
+int amdCreateAprilTagsDetector(amdAprilTagsHandle* handle, uint32_t img_width, uint32_t img_height,
+                               uint32_t tile_size, amdAprilTagsFamily tag_family,
+                               const amdAprilTagsCameraIntrinsics_t* cam, float tag_dim);
+int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsConfig_t* cfg);
+int amdAprilTagsDestroy(amdAprilTagsHandle handle);
+
+/* cuAprilTagsDetect-shaped call: one frame, blocking. */
+int amdAprilTagsDetect(amdAprilTagsHandle handle, const amdAprilTagsImageInput_t* img_input,
+                       amdAprilTagsID_t* tags_out, uint32_t* num_tags, uint32_t max_tags,
+                       amdAprilTagsStream stream);
+
+/* Batched call: n independent frames (n <= max_batch).  tags_out holds n*max_tags records,
+ * num_tags n counts.  per_frame_intrinsics may be NULL (handle intrinsics used for all frames). */
+int amdAprilTagsDetectBatch(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
+                            const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics,
+                            amdAprilTagsID_t* tags_out, uint32_t* num_tags, uint32_t max_tags,
+                            amdAprilTagsStream stream);
+/* Same, full-precision records. */
+int amdAprilTagsDetectBatchEx(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
+                              const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics,
+                              amdAprilTagsDetectionEx_t* dets_out, uint32_t* num_dets, uint32_t max_dets,
+                              amdAprilTagsStream stream);
+
+/* Status bits of the frames of the last submission (n values). */
+int amdAprilTagsGetFrameFlags(amdAprilTagsHandle handle, uint32_t* flags, uint32_t n);
+
+/* Colour -> mono8 on the device.  encoding: "mono8","rgb8","bgr8","rgba8","bgra8"
+ * (src/apriltag_node.cpp:76-82). */
+int amdAprilTagsConvertToMono8(const void* src_dev, size_t src_pitch, const char* encoding, uint32_t width,
+                               uint32_t height, uint8_t* dst_dev, size_t dst_pitch, amdAprilTagsStream stream);
+
+/* Registers a tag family as data (row-major codes, MSB = top-left data cell) in a custom slot. */
+int amdAprilTagsRegisterFamily(amdAprilTagsFamily slot, const char* name, uint32_t data_bits_per_side,
+                               const uint64_t* codes, uint32_t ncodes);
+/* Family metadata: returns 0 and fills the outputs if the family is known. */
+int amdAprilTagsFamilyInfo(amdAprilTagsFamily family, const char** name, uint32_t* data_bits_per_side,
+                           uint32_t* ncodes, const uint64_t** codes);
+/* Family lookup by the reference's parameter string (src/apriltag_node.cpp:47-58); -1 if unknown
+ * or without an offline codebook. */
+int amdAprilTagsFamilyFromName(const char* name);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+#define AMDAT_NUM_STAGES 12
+/* Stage names, index-aligned with amdAprilTagsGetStageMs. */
+const char* amdAprilTagsStageName(uint32_t stage);
+/* enable != 0: bracket every stage of subsequent submissions with HIP events on the submission
+ * stream. */
+int amdAprilTagsSetProfiling(amdAprilTagsHandle handle, int enable);
+/* Milliseconds per stage of the last submission (AMDAT_NUM_STAGES floats). */
+int amdAprilTagsGetStageMs(amdAprilTagsHandle handle, float* ms);
+/* Runs only the threshold pass (S1+S2) on n frames; used by the roofline measurement. */
+int amdAprilTagsThresholdOnly(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
+                              amdAprilTagsStream stream);
+
+/* ---- stage inspection (parity tests) ------------------------------------------------------ */
+typedef enum {
+  AMDAT_DBG_GRAY = 0,      /* u8  w*h working gray image */
+  AMDAT_DBG_THRESH = 1,    /* u8  w*h */
+  AMDAT_DBG_LABEL = 2,     /* u32 w*h canonical representative or 0xFFFFFFFF */
+  AMDAT_DBG_CSIZE = 3,     /* u32 w*h, valid at representatives */
+  AMDAT_DBG_CLUSTERS = 4,  /* {u64 key; u32 start; u32 count} x nclusters */
+  AMDAT_DBG_POINTS = 5,    /* u32 packed points, grouped by cluster */
+  AMDAT_DBG_QUADS = 6,     /* {float p[4][2]; i32 reversed_border; u32 pad; u64 key} x nquads */
+  AMDAT_DBG_COUNTS = 7     /* u32[8]: npoints_raw, nclusters, npoints_kept, nquads, ndets, flags, w, h */
+} amdAprilTagsDebugBuffer;
+/* Copies an intermediate buffer of frame `frame` of the last submission to host memory.
+ * Returns the number of bytes the buffer holds through *bytes (copy truncated to capacity). */
+int amdAprilTagsDebugCopy(amdAprilTagsHandle handle, uint32_t frame, amdAprilTagsDebugBuffer what,
+                          void* host_dst, size_t capacity, size_t* bytes);
+/* Device-arithmetic self check: op 0 = sqrt(f64), 1 = a/b (f64), 2 = sqrtf(f32 bits in low word),
+ * 3 = a/b (f32).  n pairs in, n results out (host pointers). */
+int amdAprilTagsDebugMath(int op, uint32_t n, const double* a, const double* b, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APRILTAG_AMD_H_ */

@@ -1,0 +1,77 @@
+"""Builds the native pieces of the package in-tree (the .so files travel to the GPU box with the repo).
+
+  libapriltag_amd.so    HIP kernels + C ABI (hipcc, gfx950 only)         <- csrc/detector.hip
+  libapriltag_synth.so  deterministic frame renderer (host C)            <- csrc/synth_render.c
+  libapriltag_node.so   ROS-free C++ mirror of the reference node shell  <- csrc/node_shell.cpp (if present)
+"""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_AMD = os.path.join(_HERE, "libapriltag_amd.so")
+LIB_SYNTH = os.path.join(_HERE, "libapriltag_synth.so")
+LIB_NODE = os.path.join(_HERE, "libapriltag_node.so")
+
+
+def _hipcc():
+    for c in ("/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _sources(*exts):
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    out = []
+    for d in (_CSRC, inc):
+        for f in sorted(os.listdir(d)):
+            if f.endswith(exts):
+                out.append(os.path.join(d, f))
+    return out
+
+
+def build_amd(force=False):
+    srcs = _sources(".hip", ".h")
+    if force or _newer(LIB_AMD, srcs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-fno-fast-math", "-Wall", "-Wno-unused-value", "-Wno-unused-function",
+               os.path.join(_CSRC, "detector.hip"), "-o", LIB_AMD]
+        subprocess.check_call(cmd)
+    return LIB_AMD
+
+
+def build_synth(force=False):
+    src = os.path.join(_CSRC, "synth_render.c")
+    if force or _newer(LIB_SYNTH, [src] + _sources(".h")):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-std=gnu99", "-ffp-contract=off", "-shared", "-o", LIB_SYNTH,
+                               src, "-lm"])
+    return LIB_SYNTH
+
+
+def build_node(force=False):
+    src = os.path.join(_CSRC, "node_shell.cpp")
+    if not os.path.exists(src):
+        return None
+    if force or _newer(LIB_NODE, [src] + _sources(".h", ".hpp")):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", LIB_NODE, src, "-ldl"])
+    return LIB_NODE
+
+
+def build_all(force=False):
+    build_synth(force)
+    build_amd(force)
+    build_node(force)
+
+
+if __name__ == "__main__":
+    build_all(force=True)
+    print("built", LIB_AMD, LIB_SYNTH)

@@ -1,0 +1,129 @@
+// common.h -- shared device-side types and helpers of the MI355X AprilTag detector.
+// gfx950 only: wave = 64 lanes, __ballot is 64-bit.  Compiled with -ffp-contract=off; every
+// floating-point statement below is meant to be exactly one IEEE operation per operator.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define AT_NO_LABEL 0xFFFFFFFFu
+#define AT_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define AT_INVALID_SLOT 0xFFFFFFFFu
+#define AT_MAX_FAMILIES 4
+
+// Per-frame descriptor (device copy of amdAprilTagsImageInput_t + intrinsics), one per batch slot.
+struct FrameDesc {
+  const uint8_t* img;  // mono8, full resolution
+  uint32_t pitch;
+  uint32_t pad;
+  double fx, fy, cx, cy;
+};
+
+// Per-frame counters (one struct per batch slot), zeroed at the start of every submission.
+struct FrameCounters {
+  uint32_t npoints_raw;   // staged boundary points
+  uint32_t nclusters;     // kept clusters
+  uint32_t npoints_kept;  // points in kept clusters (allocation cursor)
+  uint32_t nquads;
+  uint32_t ndets;         // raw detections before reconcile
+  uint32_t flags;         // AMDAT_FLAG_*
+  uint32_t nout;          // detections after reconcile
+  uint32_t pad;
+};
+
+struct ClusterRec {
+  uint64_t key;
+  uint32_t start;
+  uint32_t count;
+};
+
+struct QuadRec {
+  float p[4][2];
+  int32_t reversed_border;
+  uint32_t pad;
+  uint64_t key;
+};
+
+// Same layout as amdAprilTagsDetectionEx_t.
+struct DetRec {
+  int32_t family, id, hamming;
+  float decision_margin;
+  double H[9];
+  double c[2];
+  double p[4][2];
+  double R[9];
+  double t[3];
+};
+
+struct FamilyDev {
+  uint32_t nbits, d, width_at_border, total_width;
+  int32_t reversed_border;
+  uint32_t ncodes;
+  const uint64_t* codes;  // device pointer
+};
+
+// Geometry + algorithm parameters shared by all kernels of a handle.
+struct DetParams {
+  int W0, H0;        // input size
+  int W, H;          // working (decimated) size
+  int WS;            // pitch of the working u8 images (multiple of 16)
+  int decimate;
+  int tw, th;        // full 4x4 tiles
+  int min_white_black_diff;
+  int min_component_size;
+  int min_cluster_points;
+  int max_cluster_points;
+  int max_nmaxima;
+  int min_tag_width;
+  int normal_border, reversed_border;
+  int refine_edges;
+  int max_hamming;
+  int nfam;
+  double cos_critical_rad;
+  double max_line_fit_mse;
+  double decode_sharpening;
+  double tag_size;
+  // capacities per frame
+  uint32_t pcap, hcap, hshift, ccap, qcap, dcap;
+  FamilyDev fam[AT_MAX_FAMILIES];
+};
+
+__device__ __forceinline__ uint32_t pack_point(int x, int y, int gx, int gy) {
+  return ((uint32_t)x << 18) | ((uint32_t)y << 4) | ((uint32_t)(gx / 255 + 1) << 2) | (uint32_t)(gy / 255 + 1);
+}
+
+__device__ __forceinline__ uint32_t float_sortable(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// wave-level inclusive scan (wave64)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  int lane = lane_id();
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t n = __shfl_up(v, off, 64);
+    if (lane >= off) v += n;
+  }
+  return v;
+}
+
+// Exclusive scan of one uint32 per thread over a 256-thread block; returns exclusive prefix and the
+// block total through *total.  scratch: 4 uint32 in LDS.
+__device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32_t* scratch, uint32_t* total) {
+  uint32_t inc = wave_incl_scan(v);
+  int w = threadIdx.x >> 6;
+  if (lane_id() == 63) scratch[w] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint32_t s = scratch[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}

@@ -1,0 +1,666 @@
+// detector.hip -- host side of libapriltag_amd.so: the C ABI declared in include/apriltag_amd.h,
+// buffer management, and the launch sequence of one batched submission.
+//
+// Replaces the closed cuAprilTags calls of the reference node
+// (src/apriltag_node.cpp:450-452 create, :491-493 detect, :556 destroy).  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/apriltag_amd.h"
+#include "../../include/apriltag_amd_families.h"
+#include "common.h"
+#include "kernels_cc.h"
+#include "kernels_cluster.h"
+#include "kernels_decode.h"
+#include "kernels_quad.h"
+#include "kernels_threshold.h"
+
+static_assert(sizeof(DetRec) == sizeof(amdAprilTagsDetectionEx_t), "DetRec must match the public record");
+static_assert(sizeof(QuadRec) == 48, "QuadRec layout");
+static_assert(sizeof(ClusterRec) == 16, "ClusterRec layout");
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      fprintf(stderr, "[apriltag_amd] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return AMDAT_HIP_ERROR;                                                                      \
+    }                                                                                              \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// family registry
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct FamilyHost {
+  const char* name = nullptr;
+  uint32_t d = 0;
+  uint32_t ncodes = 0;
+  const uint64_t* codes = nullptr;
+  std::vector<uint64_t> owned;
+  char name_buf[32] = {0};
+};
+FamilyHost g_families[AMDAT_ENUM_SIZE];
+std::once_flag g_fam_once;
+std::mutex g_fam_mutex;
+
+void init_families() {
+  g_families[AMDAT_TAG36H11].name = "tag36h11";
+  g_families[AMDAT_TAG36H11].d = 6;
+  g_families[AMDAT_TAG36H11].ncodes = APRILTAG_AMD_TAG36H11_VALIDATED;
+  g_families[AMDAT_TAG36H11].codes = apriltag_amd_tag36h11_codes;
+  g_families[AMDAT_TAG25H9].name = "tag25h9";
+  g_families[AMDAT_TAG25H9].d = 5;
+  g_families[AMDAT_TAG25H9].ncodes = APRILTAG_AMD_TAG25H9_NCODES;
+  g_families[AMDAT_TAG25H9].codes = apriltag_amd_tag25h9_codes;
+  g_families[AMDAT_TAG16H5].name = "tag16h5";
+  g_families[AMDAT_TAG16H5].d = 4;
+  g_families[AMDAT_TAG16H5].ncodes = APRILTAG_AMD_TAG16H5_NCODES;
+  g_families[AMDAT_TAG16H5].codes = apriltag_amd_tag16h5_codes;
+  g_families[AMDAT_SYNTH36H11].name = "synth36h11";
+  g_families[AMDAT_SYNTH36H11].d = 6;
+  g_families[AMDAT_SYNTH36H11].ncodes = APRILTAG_AMD_SYNTH36H11_NCODES;
+  g_families[AMDAT_SYNTH36H11].codes = apriltag_amd_synth36h11_codes;
+}
+
+const char* kStageNames[AMDAT_NUM_STAGES] = {"upload_clear", "threshold", "cc_local",  "cc_border",
+                                             "cc_flatten",   "points",    "cluster_select", "scatter",
+                                             "fit_quads",    "decode",    "reconcile", "download"};
+
+uint32_t next_pow2(uint32_t v) {
+  uint32_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+}  // namespace
+
+struct amdAprilTagsDetector_st {
+  amdAprilTagsConfig_t cfg;
+  DetParams P;
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  // device buffers
+  uint8_t* d_gray = nullptr;
+  uint8_t* d_thr = nullptr;
+  uint32_t* d_label = nullptr;
+  uint32_t* d_csize = nullptr;
+  unsigned long long* d_hkeys = nullptr;
+  uint32_t* d_hcnt = nullptr;
+  uint32_t* d_hoff = nullptr;
+  uint2* d_stage = nullptr;
+  uint32_t* d_pts = nullptr;
+  ClusterRec* d_clusters = nullptr;
+  unsigned long long* d_keys = nullptr;
+  double* d_lf = nullptr;
+  double* d_errs_a = nullptr;
+  double* d_errs_b = nullptr;
+  QuadRec* d_quads = nullptr;
+  DetRec* d_dets = nullptr;
+  DetRec* d_out = nullptr;
+  uint16_t* d_order = nullptr;
+  FrameCounters* d_counters = nullptr;
+  FrameDesc* d_frames = nullptr;
+  uint64_t* d_codes[AT_MAX_FAMILIES] = {nullptr, nullptr, nullptr, nullptr};
+  // pinned host buffers
+  FrameDesc* h_frames = nullptr;
+  FrameCounters* h_counters = nullptr;
+  DetRec* h_out = nullptr;
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev[AMDAT_NUM_STAGES + 1] = {};
+  float stage_ms[AMDAT_NUM_STAGES] = {};
+  uint32_t last_n = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// small kernels that live with the host code
+// ------------------------------------------------------------------------------------------------
+__global__ void k_debug_math(int op, uint32_t n, const double* a, const double* b, double* out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (op == 0) out[i] = __dsqrt_rn(a[i]);
+  else if (op == 1) out[i] = a[i] / b[i];
+  else if (op == 2) out[i] = (double)__fsqrt_rn((float)a[i]);
+  else out[i] = (double)__fdiv_rn((float)a[i], (float)b[i]);
+}
+
+// colour -> mono8 with the fixed-point BT.601 weights cv_bridge/OpenCV use for the reference's mono8
+// test input (test/isaac_ros_apriltag_mono8_test.py): Y = (4899 R + 9617 G + 1868 B + 8192) >> 14
+template <int NCH, int RIDX, int BIDX>
+__global__ __launch_bounds__(256) void k_to_mono8(const uint8_t* __restrict__ src, size_t spitch, uint8_t* __restrict__ dst,
+                                                  size_t dpitch, uint32_t w, uint32_t h) {
+  const uint32_t x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const uint32_t y = blockIdx.y;
+  if (x4 >= w || y >= h) return;
+  const uint8_t* s = src + (size_t)y * spitch + (size_t)x4 * NCH;
+  uint8_t* d = dst + (size_t)y * dpitch + x4;
+  for (uint32_t k = 0; k < 4 && x4 + k < w; k++) {
+    const uint32_t R = s[k * NCH + RIDX], G = s[k * NCH + 1], B = s[k * NCH + BIDX];
+    d[k] = (uint8_t)((4899u * R + 9617u * G + 1868u * B + 8192u) >> 14);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+void amdAprilTagsDefaultConfig(amdAprilTagsConfig_t* cfg, uint32_t width, uint32_t height) {
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->width = width;
+  cfg->height = height;
+  cfg->tile_size = 4;
+  cfg->decimate = 1;
+  cfg->num_families = 1;
+  cfg->families[0] = AMDAT_TAG36H11;
+  cfg->intrinsics = {1000.0f, 1000.0f, width / 2.0f, height / 2.0f};
+  cfg->tag_size = 0.22f;
+  cfg->max_batch = 1;
+  cfg->refine_edges = 1;
+  cfg->max_hamming = 2;
+  cfg->decode_sharpening = 0.25f;
+  cfg->device = -1;
+}
+
+int amdAprilTagsRegisterFamily(amdAprilTagsFamily slot, const char* name, uint32_t d, const uint64_t* codes, uint32_t ncodes) {
+  std::call_once(g_fam_once, init_families);
+  if (slot != AMDAT_CUSTOM0 && slot != AMDAT_CUSTOM1) return AMDAT_INVALID_ARGUMENT;
+  if (!name || !codes || ncodes == 0 || d < 3 || d > 7) return AMDAT_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(g_fam_mutex);
+  FamilyHost& f = g_families[slot];
+  f.owned.assign(codes, codes + ncodes);
+  strncpy(f.name_buf, name, sizeof(f.name_buf) - 1);
+  f.name = f.name_buf;
+  f.d = d;
+  f.ncodes = ncodes;
+  f.codes = f.owned.data();
+  return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsFamilyInfo(amdAprilTagsFamily family, const char** name, uint32_t* d, uint32_t* ncodes, const uint64_t** codes) {
+  std::call_once(g_fam_once, init_families);
+  if ((int)family < 0 || family >= AMDAT_ENUM_SIZE || g_families[family].codes == nullptr) return AMDAT_UNSUPPORTED;
+  if (name) *name = g_families[family].name;
+  if (d) *d = g_families[family].d;
+  if (ncodes) *ncodes = g_families[family].ncodes;
+  if (codes) *codes = g_families[family].codes;
+  return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsFamilyFromName(const char* name) {
+  std::call_once(g_fam_once, init_families);
+  if (!name) return -1;
+  for (int i = 0; i < AMDAT_ENUM_SIZE; i++)
+    if (g_families[i].codes && g_families[i].name && !strcmp(g_families[i].name, name)) return i;
+  return -1;
+}
+
+const char* amdAprilTagsStageName(uint32_t stage) { return stage < AMDAT_NUM_STAGES ? kStageNames[stage] : ""; }
+
+static void free_all(amdAprilTagsDetector_st* D) {
+  hipFree(D->d_gray); hipFree(D->d_thr); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_hkeys);
+  hipFree(D->d_hcnt); hipFree(D->d_hoff); hipFree(D->d_stage); hipFree(D->d_pts); hipFree(D->d_clusters);
+  hipFree(D->d_keys); hipFree(D->d_lf); hipFree(D->d_errs_a); hipFree(D->d_errs_b); hipFree(D->d_quads);
+  hipFree(D->d_dets); hipFree(D->d_out); hipFree(D->d_order); hipFree(D->d_counters); hipFree(D->d_frames);
+  for (int i = 0; i < AT_MAX_FAMILIES; i++) hipFree(D->d_codes[i]);
+  if (D->h_frames) hipHostFree(D->h_frames);
+  if (D->h_counters) hipHostFree(D->h_counters);
+  if (D->h_out) hipHostFree(D->h_out);
+  for (auto& e : D->ev) if (e) hipEventDestroy(e);
+  if (D->own_stream) hipStreamDestroy(D->own_stream);
+}
+
+int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsConfig_t* cfg_in) {
+  std::call_once(g_fam_once, init_families);
+  if (!handle || !cfg_in) return AMDAT_INVALID_ARGUMENT;
+  *handle = nullptr;
+  amdAprilTagsConfig_t cfg = *cfg_in;
+  if (cfg.width == 0 || cfg.height == 0 || cfg.max_batch == 0 || cfg.decimate == 0) return AMDAT_INVALID_ARGUMENT;
+  if (cfg.tile_size != 4) return AMDAT_UNSUPPORTED;
+  if (cfg.num_families < 1 || cfg.num_families > AT_MAX_FAMILIES) return AMDAT_INVALID_ARGUMENT;
+  for (uint32_t i = 0; i < cfg.num_families; i++) {
+    if ((int)cfg.families[i] < 0 || cfg.families[i] >= AMDAT_ENUM_SIZE || !g_families[cfg.families[i]].codes)
+      return AMDAT_UNSUPPORTED;
+  }
+  const int W = 1 + ((int)cfg.width - 1) / (int)cfg.decimate, H = 1 + ((int)cfg.height - 1) / (int)cfg.decimate;
+  if (W / 4 < 1 || H / 4 < 1 || 2 * W + 1 >= (1 << 14) || 2 * H + 1 >= (1 << 14)) return AMDAT_UNSUPPORTED;
+
+  auto* D = new (std::nothrow) amdAprilTagsDetector_st();
+  if (!D) return AMDAT_OUT_OF_MEMORY;
+  D->cfg = cfg;
+  if (cfg.device >= 0) {
+    if (hipSetDevice(cfg.device) != hipSuccess) { delete D; return AMDAT_HIP_ERROR; }
+  }
+  if (hipGetDevice(&D->device) != hipSuccess) { delete D; return AMDAT_HIP_ERROR; }
+
+  DetParams& P = D->P;
+  memset(&P, 0, sizeof(P));
+  P.W0 = (int)cfg.width; P.H0 = (int)cfg.height; P.W = W; P.H = H;
+  P.WS = (W + 15) & ~15;
+  P.decimate = (int)cfg.decimate;
+  P.tw = W / 4; P.th = H / 4;
+  P.min_white_black_diff = 5;
+  P.min_component_size = 25;
+  P.min_cluster_points = 24;
+  P.max_cluster_points = 3 * (2 * W + 2 * H);
+  P.max_nmaxima = 10;
+  P.refine_edges = cfg.refine_edges ? 1 : 0;
+  P.max_hamming = (int)cfg.max_hamming;
+  P.nfam = (int)cfg.num_families;
+  P.cos_critical_rad = 0x1.f838b8c811c17p-1;
+  P.max_line_fit_mse = 10.0;
+  P.decode_sharpening = (double)cfg.decode_sharpening;
+  P.tag_size = (double)cfg.tag_size;
+  int min_tag_width = 1000000;
+  for (int i = 0; i < P.nfam; i++) {
+    const FamilyHost& f = g_families[cfg.families[i]];
+    P.fam[i].d = f.d; P.fam[i].nbits = f.d * f.d; P.fam[i].width_at_border = f.d + 2; P.fam[i].total_width = f.d + 4;
+    P.fam[i].reversed_border = 0; P.fam[i].ncodes = f.ncodes;
+    if ((int)P.fam[i].width_at_border < min_tag_width) min_tag_width = (int)P.fam[i].width_at_border;
+    P.normal_border |= 1;
+  }
+  min_tag_width = (int)((float)min_tag_width / (float)P.decimate);
+  if (min_tag_width < 3) min_tag_width = 3;
+  P.min_tag_width = min_tag_width;
+  const uint32_t npx = (uint32_t)W * (uint32_t)H;
+  P.pcap = cfg.max_points ? cfg.max_points : 2u * npx;
+  P.hcap = cfg.hash_slots ? next_pow2(cfg.hash_slots) : next_pow2(npx / 8 > 4096 ? npx / 8 : 4096);
+  if (P.hcap < 256) P.hcap = 256;
+  { uint32_t lg = 0; while ((1u << lg) < P.hcap) lg++; P.hshift = 64 - lg; }
+  P.ccap = cfg.max_clusters ? cfg.max_clusters : (P.hcap < 65536 ? P.hcap : 65536);
+  P.qcap = cfg.max_quads ? cfg.max_quads : 8192;
+  P.dcap = cfg.max_detections ? cfg.max_detections : 1024;
+  if (P.dcap > 65535) P.dcap = 65535;
+
+  const size_t B = cfg.max_batch;
+  bool ok = true;
+  auto alloc = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes ? bytes : 16) != hipSuccess) ok = false; };
+  if (P.decimate > 1) alloc((void**)&D->d_gray, B * (size_t)H * P.WS);
+  alloc((void**)&D->d_thr, B * (size_t)H * P.WS);
+  alloc((void**)&D->d_label, B * (size_t)npx * 4);
+  alloc((void**)&D->d_csize, B * (size_t)npx * 4);
+  alloc((void**)&D->d_hkeys, B * (size_t)P.hcap * 8);
+  alloc((void**)&D->d_hcnt, B * (size_t)P.hcap * 4);
+  alloc((void**)&D->d_hoff, B * (size_t)P.hcap * 4);
+  alloc((void**)&D->d_stage, B * (size_t)P.pcap * 8);
+  alloc((void**)&D->d_pts, B * (size_t)P.pcap * 4);
+  alloc((void**)&D->d_clusters, B * (size_t)P.ccap * sizeof(ClusterRec));
+  alloc((void**)&D->d_keys, B * (size_t)P.pcap * 8);
+  alloc((void**)&D->d_lf, B * (size_t)P.pcap * 48);
+  alloc((void**)&D->d_errs_a, B * (size_t)P.pcap * 8);
+  alloc((void**)&D->d_errs_b, B * (size_t)P.pcap * 8);
+  alloc((void**)&D->d_quads, B * (size_t)P.qcap * sizeof(QuadRec));
+  alloc((void**)&D->d_dets, B * (size_t)P.dcap * sizeof(DetRec));
+  alloc((void**)&D->d_out, B * (size_t)P.dcap * sizeof(DetRec));
+  alloc((void**)&D->d_order, B * (size_t)P.dcap * 2);
+  alloc((void**)&D->d_counters, B * sizeof(FrameCounters));
+  alloc((void**)&D->d_frames, B * sizeof(FrameDesc));
+  for (int i = 0; ok && i < P.nfam; i++) {
+    const FamilyHost& f = g_families[cfg.families[i]];
+    alloc((void**)&D->d_codes[i], (size_t)f.ncodes * 8);
+    if (ok && hipMemcpy(D->d_codes[i], f.codes, (size_t)f.ncodes * 8, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+    P.fam[i].codes = D->d_codes[i];
+  }
+  if (ok && hipHostMalloc((void**)&D->h_frames, B * sizeof(FrameDesc)) != hipSuccess) ok = false;
+  if (ok && hipHostMalloc((void**)&D->h_counters, B * sizeof(FrameCounters)) != hipSuccess) ok = false;
+  if (ok && hipHostMalloc((void**)&D->h_out, B * (size_t)P.dcap * sizeof(DetRec)) != hipSuccess) ok = false;
+  if (ok && hipStreamCreateWithFlags(&D->own_stream, hipStreamNonBlocking) != hipSuccess) ok = false;
+  for (auto& e : D->ev) if (ok && hipEventCreate(&e) != hipSuccess) ok = false;
+  if (ok && D->d_thr) {
+    // the padding columns of the working images are read by vector loads; define them once
+    if (hipMemset(D->d_thr, 127, B * (size_t)H * P.WS) != hipSuccess) ok = false;
+    if (ok && D->d_gray && hipMemset(D->d_gray, 0, B * (size_t)H * P.WS) != hipSuccess) ok = false;
+  }
+  if (!ok) {
+    free_all(D);
+    delete D;
+    return AMDAT_OUT_OF_MEMORY;
+  }
+  *handle = D;
+  return AMDAT_SUCCESS;
+}
+
+int amdCreateAprilTagsDetector(amdAprilTagsHandle* handle, uint32_t img_width, uint32_t img_height, uint32_t tile_size,
+                               amdAprilTagsFamily tag_family, const amdAprilTagsCameraIntrinsics_t* cam, float tag_dim) {
+  if (!cam) return AMDAT_INVALID_ARGUMENT;
+  amdAprilTagsConfig_t cfg;
+  amdAprilTagsDefaultConfig(&cfg, img_width, img_height);
+  cfg.tile_size = tile_size;
+  cfg.families[0] = tag_family;
+  cfg.intrinsics = *cam;
+  cfg.tag_size = tag_dim;
+  return amdCreateAprilTagsDetectorEx(handle, &cfg);
+}
+
+int amdAprilTagsDestroy(amdAprilTagsHandle handle) {
+  if (!handle) return AMDAT_INVALID_ARGUMENT;
+  hipSetDevice(handle->device);
+  hipDeviceSynchronize();
+  free_all(handle);
+  delete handle;
+  return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsSetProfiling(amdAprilTagsHandle handle, int enable) {
+  if (!handle) return AMDAT_INVALID_ARGUMENT;
+  handle->profiling = enable != 0;
+  return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsGetStageMs(amdAprilTagsHandle handle, float* ms) {
+  if (!handle || !ms) return AMDAT_INVALID_ARGUMENT;
+  memcpy(ms, handle->stage_ms, sizeof(handle->stage_ms));
+  return AMDAT_SUCCESS;
+}
+
+static int check_images(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images) {
+  if (n == 0 || !images) return AMDAT_INVALID_ARGUMENT;
+  if (n > D->cfg.max_batch) return AMDAT_BATCH_TOO_LARGE;
+  for (uint32_t i = 0; i < n; i++) {
+    if (!images[i].dev_ptr) return AMDAT_INVALID_ARGUMENT;
+    if (images[i].width != D->cfg.width || images[i].height != D->cfg.height) return AMDAT_SIZE_MISMATCH;
+    if (images[i].pitch < images[i].width) return AMDAT_INVALID_ARGUMENT;
+  }
+  return AMDAT_SUCCESS;
+}
+
+static void fill_frames(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images,
+                        const amdAprilTagsCameraIntrinsics_t* intr) {
+  for (uint32_t i = 0; i < n; i++) {
+    const amdAprilTagsCameraIntrinsics_t& k = intr ? intr[i] : D->cfg.intrinsics;
+    D->h_frames[i].img = images[i].dev_ptr;
+    D->h_frames[i].pitch = (uint32_t)images[i].pitch;
+    D->h_frames[i].pad = 0;
+    D->h_frames[i].fx = (double)k.fx; D->h_frames[i].fy = (double)k.fy;
+    D->h_frames[i].cx = (double)k.cx; D->h_frames[i].cy = (double)k.cy;
+  }
+}
+
+static void launch_threshold(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s) {
+  const DetParams& P = D->P;
+  dim3 grid((unsigned)(((P.W + 3) / 4 + 127) / 128), (unsigned)(((P.H + 3) / 4 + 7) / 8), n);
+  const bool leftover = (P.W % 4) || (P.H % 4);
+  const int nleft = (P.W - P.tw * 4) * (P.th * 4) + (P.H - P.th * 4) * P.W;
+  dim3 lgrid((unsigned)((nleft + 255) / 256), 1, n);
+  switch (P.decimate) {
+    case 1:
+      hipLaunchKernelGGL(k_threshold<1>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
+      if (leftover) hipLaunchKernelGGL(k_threshold_leftover<1>, lgrid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
+      break;
+    case 2:
+      hipLaunchKernelGGL(k_threshold<2>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
+      if (leftover) hipLaunchKernelGGL(k_threshold_leftover<2>, lgrid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
+      break;
+    case 3:
+      hipLaunchKernelGGL(k_threshold<3>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
+      if (leftover) hipLaunchKernelGGL(k_threshold_leftover<3>, lgrid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
+      break;
+    default:
+      hipLaunchKernelGGL(k_threshold<4>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
+      if (leftover) hipLaunchKernelGGL(k_threshold_leftover<4>, lgrid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
+      break;
+  }
+}
+
+// One batched submission; results land in h_out / h_counters with `ostride` records per frame.
+static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images,
+                     const amdAprilTagsCameraIntrinsics_t* intr, uint32_t ostride, hipStream_t s) {
+  const DetParams& P = D->P;
+  HIP_TRY(hipSetDevice(D->device));
+  fill_frames(D, n, images, intr);
+  D->last_n = n;
+  const bool prof = D->profiling;
+  int evi = 0;
+  auto mark = [&]() { if (prof) hipEventRecord(D->ev[evi++], s); };
+
+  mark();
+  HIP_TRY(hipMemcpyAsync(D->d_frames, D->h_frames, n * sizeof(FrameDesc), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(D->d_counters, 0, n * sizeof(FrameCounters), s));
+  HIP_TRY(hipMemsetAsync(D->d_hkeys, 0xFF, (size_t)n * P.hcap * 8, s));
+  HIP_TRY(hipMemsetAsync(D->d_hcnt, 0, (size_t)n * P.hcap * 4, s));
+  mark();
+  launch_threshold(D, n, s);
+  mark();
+  hipLaunchKernelGGL(k_cc_local, dim3((P.W + CC_T - 1) / CC_T, (P.H + CC_T - 1) / CC_T, n), dim3(256), 0, s, D->d_thr,
+                     D->d_label, D->d_csize, P);
+  mark();
+  {
+    const int nrows = (P.H - 1) / CC_T, ncols = (P.W - 1) / CC_T;
+    const long total = (long)nrows * P.W + 2L * ncols * P.H;
+    if (total > 0)
+      hipLaunchKernelGGL(k_cc_border, dim3((unsigned)((total + 255) / 256), 1, n), dim3(256), 0, s, D->d_thr, D->d_label, P);
+  }
+  mark();
+  hipLaunchKernelGGL(k_cc_flatten, dim3((unsigned)(((size_t)P.W * P.H + 255) / 256), 1, n), dim3(256), 0, s, D->d_label,
+                     D->d_csize, P);
+  mark();
+  hipLaunchKernelGGL(k_points, dim3((P.W + PT_TW - 1) / PT_TW, (P.H + PT_TH - 1) / PT_TH, n), dim3(256), 0, s, D->d_thr,
+                     D->d_label, D->d_csize, D->d_hkeys, D->d_hcnt, D->d_stage, D->d_counters, P);
+  mark();
+  hipLaunchKernelGGL(k_cluster_select, dim3(P.hcap / 256, 1, n), dim3(256), 0, s, D->d_hkeys, D->d_hcnt, D->d_hoff,
+                     D->d_clusters, D->d_counters, P);
+  mark();
+  {
+    unsigned gx = (P.pcap + 255) / 256;
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(k_scatter, dim3(gx, 1, n), dim3(256), 0, s, D->d_stage, D->d_hcnt, D->d_hoff, D->d_pts, D->d_counters, P);
+  }
+  mark();
+  {
+    unsigned gx = 4096 / n;
+    if (gx < 32) gx = 32;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_fit_quads, dim3(gx, n), dim3(256), 0, s, D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_keys,
+                       D->d_lf, D->d_errs_a, D->d_errs_b, D->d_quads, D->d_counters, P);
+  }
+  mark();
+  hipLaunchKernelGGL(k_decode, dim3(8, n), dim3(64), 0, s, D->d_frames, D->d_quads, D->d_dets, D->d_counters, P);
+  mark();
+  hipLaunchKernelGGL(k_reconcile, dim3(n), dim3(64), 0, s, D->d_frames, D->d_dets, D->d_out, D->d_counters, D->d_order, P);
+  mark();
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(D->h_counters, D->d_counters, n * sizeof(FrameCounters), hipMemcpyDeviceToHost, s));
+  if (ostride > P.dcap) ostride = P.dcap;
+  HIP_TRY(hipMemcpy2DAsync(D->h_out, (size_t)ostride * sizeof(DetRec), D->d_out, (size_t)P.dcap * sizeof(DetRec),
+                           (size_t)ostride * sizeof(DetRec), n, hipMemcpyDeviceToHost, s));
+  mark();
+  HIP_TRY(hipStreamSynchronize(s));
+  if (prof) {
+    for (int i = 0; i < AMDAT_NUM_STAGES; i++) {
+      float ms = 0;
+      hipEventElapsedTime(&ms, D->ev[i], D->ev[i + 1]);
+      D->stage_ms[i] = ms;
+    }
+  }
+  return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsDetectBatchEx(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
+                              const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics, amdAprilTagsDetectionEx_t* dets_out,
+                              uint32_t* num_dets, uint32_t max_dets, amdAprilTagsStream stream) {
+  if (!handle || !dets_out || !num_dets || max_dets == 0) return AMDAT_INVALID_ARGUMENT;
+  int rc = check_images(handle, n, images);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : handle->own_stream;
+  uint32_t ostride = max_dets < handle->P.dcap ? max_dets : handle->P.dcap;
+  rc = run_batch(handle, n, images, per_frame_intrinsics, ostride, s);
+  if (rc) return rc;
+  for (uint32_t f = 0; f < n; f++) {
+    uint32_t k = handle->h_counters[f].nout;
+    if (k > ostride) k = ostride;
+    num_dets[f] = k;
+    memcpy(dets_out + (size_t)f * max_dets, handle->h_out + (size_t)f * ostride, (size_t)k * sizeof(DetRec));
+  }
+  return AMDAT_SUCCESS;
+}
+
+static void to_public(const DetRec& d, uint16_t family_enum, amdAprilTagsID_t* o) {
+  memset(o, 0, sizeof(*o));
+  o->id = (uint16_t)d.id;
+  // library-native corner order = message order = AprilRobotics p[3-i]
+  for (int i = 0; i < 4; i++) { o->corners[i].x = (float)d.p[3 - i][0]; o->corners[i].y = (float)d.p[3 - i][1]; }
+  o->hamming_error = (uint16_t)d.hamming;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) o->orientation[c * 3 + r] = (float)d.R[r * 3 + c];  // column-major
+  for (int i = 0; i < 3; i++) o->translation[i] = (float)d.t[i];
+  o->family = family_enum;
+  o->decision_margin = d.decision_margin;
+  o->center.x = (float)d.c[0];
+  o->center.y = (float)d.c[1];
+}
+
+int amdAprilTagsDetectBatch(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
+                            const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics, amdAprilTagsID_t* tags_out,
+                            uint32_t* num_tags, uint32_t max_tags, amdAprilTagsStream stream) {
+  if (!handle || !tags_out || !num_tags || max_tags == 0) return AMDAT_INVALID_ARGUMENT;
+  int rc = check_images(handle, n, images);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : handle->own_stream;
+  uint32_t ostride = max_tags < handle->P.dcap ? max_tags : handle->P.dcap;
+  rc = run_batch(handle, n, images, per_frame_intrinsics, ostride, s);
+  if (rc) return rc;
+  for (uint32_t f = 0; f < n; f++) {
+    uint32_t k = handle->h_counters[f].nout;
+    if (k > ostride) k = ostride;
+    num_tags[f] = k;
+    for (uint32_t i = 0; i < k; i++) {
+      const DetRec& d = handle->h_out[(size_t)f * ostride + i];
+      to_public(d, (uint16_t)handle->cfg.families[d.family], &tags_out[(size_t)f * max_tags + i]);
+    }
+  }
+  return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsDetect(amdAprilTagsHandle handle, const amdAprilTagsImageInput_t* img_input, amdAprilTagsID_t* tags_out,
+                       uint32_t* num_tags, uint32_t max_tags, amdAprilTagsStream stream) {
+  return amdAprilTagsDetectBatch(handle, 1, img_input, nullptr, tags_out, num_tags, max_tags, stream);
+}
+
+int amdAprilTagsGetFrameFlags(amdAprilTagsHandle handle, uint32_t* flags, uint32_t n) {
+  if (!handle || !flags || n > handle->last_n) return AMDAT_INVALID_ARGUMENT;
+  for (uint32_t i = 0; i < n; i++) flags[i] = handle->h_counters[i].flags;
+  return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsThresholdOnly(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
+                              amdAprilTagsStream stream) {
+  if (!handle) return AMDAT_INVALID_ARGUMENT;
+  int rc = check_images(handle, n, images);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : handle->own_stream;
+  HIP_TRY(hipSetDevice(handle->device));
+  fill_frames(handle, n, images, nullptr);
+  handle->last_n = n;
+  HIP_TRY(hipMemcpyAsync(handle->d_frames, handle->h_frames, n * sizeof(FrameDesc), hipMemcpyHostToDevice, s));
+  if (handle->profiling) hipEventRecord(handle->ev[1], s);
+  launch_threshold(handle, n, s);
+  if (handle->profiling) hipEventRecord(handle->ev[2], s);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));
+  if (handle->profiling) {
+    memset(handle->stage_ms, 0, sizeof(handle->stage_ms));
+    hipEventElapsedTime(&handle->stage_ms[1], handle->ev[1], handle->ev[2]);
+  }
+  return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsConvertToMono8(const void* src_dev, size_t src_pitch, const char* encoding, uint32_t width, uint32_t height,
+                               uint8_t* dst_dev, size_t dst_pitch, amdAprilTagsStream stream) {
+  if (!src_dev || !dst_dev || !encoding || width == 0 || height == 0) return AMDAT_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  const uint8_t* src = (const uint8_t*)src_dev;
+  dim3 grid((width + 1023) / 1024, height), block(256);
+  if (!strcmp(encoding, "mono8")) {
+    HIP_TRY(hipMemcpy2DAsync(dst_dev, dst_pitch, src_dev, src_pitch, width, height, hipMemcpyDeviceToDevice, s));
+  } else if (!strcmp(encoding, "rgb8")) {
+    hipLaunchKernelGGL((k_to_mono8<3, 0, 2>), grid, block, 0, s, src, src_pitch, dst_dev, dst_pitch, width, height);
+  } else if (!strcmp(encoding, "bgr8")) {
+    hipLaunchKernelGGL((k_to_mono8<3, 2, 0>), grid, block, 0, s, src, src_pitch, dst_dev, dst_pitch, width, height);
+  } else if (!strcmp(encoding, "rgba8")) {
+    hipLaunchKernelGGL((k_to_mono8<4, 0, 2>), grid, block, 0, s, src, src_pitch, dst_dev, dst_pitch, width, height);
+  } else if (!strcmp(encoding, "bgra8")) {
+    hipLaunchKernelGGL((k_to_mono8<4, 2, 0>), grid, block, 0, s, src, src_pitch, dst_dev, dst_pitch, width, height);
+  } else {
+    return AMDAT_UNSUPPORTED;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));
+  return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsDebugCopy(amdAprilTagsHandle handle, uint32_t frame, amdAprilTagsDebugBuffer what, void* host_dst,
+                          size_t capacity, size_t* bytes) {
+  if (!handle || !bytes || frame >= handle->last_n) return AMDAT_INVALID_ARGUMENT;
+  const DetParams& P = handle->P;
+  HIP_TRY(hipSetDevice(handle->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const FrameCounters& fc = handle->h_counters[frame];
+  const size_t npx = (size_t)P.W * P.H;
+  const void* src = nullptr;
+  size_t sz = 0;
+  std::vector<uint8_t> tmp;
+  switch (what) {
+    case AMDAT_DBG_GRAY:
+    case AMDAT_DBG_THRESH: {
+      // de-pitch rows on the host
+      const uint8_t* base = nullptr;
+      size_t pitch = P.WS;
+      if (what == AMDAT_DBG_THRESH) base = handle->d_thr + (size_t)frame * P.H * P.WS;
+      else if (P.decimate > 1) base = handle->d_gray + (size_t)frame * P.H * P.WS;
+      else { base = handle->h_frames[frame].img; pitch = handle->h_frames[frame].pitch; }
+      tmp.resize(npx);
+      HIP_TRY(hipMemcpy2D(tmp.data(), P.W, base, pitch, P.W, P.H, hipMemcpyDeviceToHost));
+      *bytes = npx;
+      if (host_dst) memcpy(host_dst, tmp.data(), npx < capacity ? npx : capacity);
+      return AMDAT_SUCCESS;
+    }
+    case AMDAT_DBG_LABEL: src = handle->d_label + (size_t)frame * npx; sz = npx * 4; break;
+    case AMDAT_DBG_CSIZE: src = handle->d_csize + (size_t)frame * npx; sz = npx * 4; break;
+    case AMDAT_DBG_CLUSTERS:
+      src = handle->d_clusters + (size_t)frame * P.ccap;
+      sz = (size_t)(fc.nclusters < P.ccap ? fc.nclusters : P.ccap) * sizeof(ClusterRec);
+      break;
+    case AMDAT_DBG_POINTS:
+      src = handle->d_pts + (size_t)frame * P.pcap;
+      sz = (size_t)(fc.npoints_kept < P.pcap ? fc.npoints_kept : P.pcap) * 4;
+      break;
+    case AMDAT_DBG_QUADS:
+      src = handle->d_quads + (size_t)frame * P.qcap;
+      sz = (size_t)(fc.nquads < P.qcap ? fc.nquads : P.qcap) * sizeof(QuadRec);
+      break;
+    case AMDAT_DBG_COUNTS: {
+      uint32_t c[8] = {fc.npoints_raw, fc.nclusters, fc.npoints_kept, fc.nquads, fc.ndets, fc.flags, (uint32_t)P.W, (uint32_t)P.H};
+      *bytes = sizeof(c);
+      if (host_dst) memcpy(host_dst, c, sizeof(c) < capacity ? sizeof(c) : capacity);
+      return AMDAT_SUCCESS;
+    }
+    default: return AMDAT_INVALID_ARGUMENT;
+  }
+  *bytes = sz;
+  if (host_dst && sz) HIP_TRY(hipMemcpy(host_dst, src, sz < capacity ? sz : capacity, hipMemcpyDeviceToHost));
+  return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsDebugMath(int op, uint32_t n, const double* a, const double* b, double* out) {
+  if (!a || !b || !out || n == 0) return AMDAT_INVALID_ARGUMENT;
+  double *da = nullptr, *db = nullptr, *dout = nullptr;
+  HIP_TRY(hipMalloc((void**)&da, n * 8));
+  HIP_TRY(hipMalloc((void**)&db, n * 8));
+  HIP_TRY(hipMalloc((void**)&dout, n * 8));
+  HIP_TRY(hipMemcpy(da, a, n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, b, n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, 0, op, n, da, db, dout);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost));
+  hipFree(da); hipFree(db); hipFree(dout);
+  return AMDAT_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,236 @@
+// kernels_cc.h -- S3 union-find connected components for the closed
+// cuAprilTagsDetect call (reference src/apriltag_node.cpp:491-493).
+//
+// Link set (the partition is all that matters downstream): for a source pixel (x,y), x in [1,W-2],
+// value v != 127:  left (x-1,y);  up (x,y-1);  and for v == 255 also up-left / up-right.
+// Representative = smallest pixel index of the component (y*W + x).
+//
+//   k_cc_local   one 64x64 tile per 256-thread block, entirely in LDS: wave-ballot run labelling
+//                of each 64-pixel row (no atomics), lock-free atomicMin union of rows, flatten,
+//                per-run size counting; writes global labels (index of the tile-local root) and
+//                the local size at root pixels.
+//   k_cc_border  unions across tile borders with global atomicMin (only first-overlap pixels).
+//   k_cc_flatten path compression to the final representative + size accumulation at it.
+#pragma once
+#include "common.h"
+
+#define CC_T 64  // tile edge
+
+__device__ __forceinline__ uint32_t lds_find(volatile uint32_t* L, uint32_t i) {
+  uint32_t p;
+  while ((p = L[i]) != i) i = p;
+  return i;
+}
+__device__ __forceinline__ void lds_union(uint32_t* L, uint32_t a, uint32_t b) {
+  for (;;) {
+    a = lds_find(L, a);
+    b = lds_find(L, b);
+    if (a == b) return;
+    if (a < b) { uint32_t t = a; a = b; b = t; }
+    uint32_t old = atomicMin(&L[a], b);
+    if (old == a) return;
+    a = old;
+  }
+}
+
+__device__ __forceinline__ uint32_t glb_load(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t glb_find(const uint32_t* L, uint32_t i) {
+  uint32_t p;
+  while ((p = glb_load(&L[i])) != i) i = p;
+  return i;
+}
+__device__ __forceinline__ void glb_union(uint32_t* L, uint32_t a, uint32_t b) {
+  for (;;) {
+    a = glb_find(L, a);
+    b = glb_find(L, b);
+    if (a == b) return;
+    if (a < b) { uint32_t t = a; a = b; b = t; }
+    uint32_t old = atomicMin(&L[a], b);
+    if (old == a) return;
+    a = old;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ thr_all, uint32_t* __restrict__ label_all,
+                                                  uint32_t* __restrict__ csize_all, DetParams P) {
+  __shared__ __attribute__((aligned(16))) uint8_t st[CC_T * CC_T];
+  __shared__ uint32_t sl[CC_T * CC_T];
+  const int frame = blockIdx.z;
+  const int X0 = blockIdx.x * CC_T, Y0 = blockIdx.y * CC_T;
+  const int W = P.W, H = P.H;
+  const uint8_t* thr = thr_all + (size_t)frame * H * P.WS;
+  const int tid = threadIdx.x;
+
+  {  // load the tile: 16 bytes per thread, out-of-image pixels become 127
+    const int row = tid >> 2, seg = tid & 3;
+    const int gy = Y0 + row, gx = X0 + seg * 16;
+    uint32_t w[4] = {0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu};
+    if (gy < H && gx < W) {
+      uint4 v = *reinterpret_cast<const uint4*>(thr + (size_t)gy * P.WS + gx);
+      w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+      if (gx + 16 > W) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int b = 0; b < 4; b++)
+            if (gx + 4 * j + b >= W) w[j] = (w[j] & ~(0xFFu << (8 * b))) | (0x7Fu << (8 * b));
+      }
+    }
+    *reinterpret_cast<uint4*>(st + row * CC_T + seg * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  __syncthreads();
+
+  const int lane = tid & 63, wv = tid >> 6;
+  const int gx = X0 + lane;
+  const bool src_ok = gx >= 1 && gx <= W - 2;  // this column may be a link source
+
+  // ---- 1. run labelling per row (wave ballot, no atomics) -------------------------------------
+  for (int k = 0; k < 16; k++) {
+    const int r = wv * 16 + k;
+    const uint32_t v = st[r * CC_T + lane];
+    const bool link = lane > 0 && v != 127 && src_ok && st[r * CC_T + lane - 1] == v;
+    const unsigned long long L = __ballot(link);
+    const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    const unsigned long long m = ~L & below;  // run starts at or below this lane (lane 0 always set)
+    const int s = 63 - __clzll((long long)m);
+    sl[r * CC_T + lane] = (v == 127) ? AT_NO_LABEL : (uint32_t)(r * CC_T + s);
+  }
+  __syncthreads();
+
+  // ---- 2. unions with the row above (only the first pixel of every overlap) -------------------
+  for (int k = 0; k < 16; k++) {
+    const int r = wv * 16 + k;
+    if (r == 0) continue;
+    const uint32_t v = st[r * CC_T + lane];
+    if (v == 127 || !src_ok) continue;
+    const uint32_t me = (uint32_t)(r * CC_T + lane);
+    const uint32_t vu = st[(r - 1) * CC_T + lane];
+    const uint32_t vl = lane > 0 ? st[r * CC_T + lane - 1] : 127;
+    const uint32_t vul = lane > 0 ? st[(r - 1) * CC_T + lane - 1] : 127;
+    const bool left_src = gx - 1 >= 1;  // (x-1) is itself a valid link source
+    if (vu == v && !(lane > 0 && left_src && vl == v && vul == v)) lds_union(sl, me, me - CC_T);
+    if (v == 255) {
+      if (lane > 0 && vul == 255 && vu != 255 && !(left_src && vl == 255)) lds_union(sl, me, me - CC_T - 1);
+      if (lane < 63) {
+        const uint32_t vur = st[(r - 1) * CC_T + lane + 1];
+        const uint32_t vr = st[r * CC_T + lane + 1];
+        const bool right_src = gx + 1 <= W - 2;
+        if (vur == 255 && !(right_src && (vu == 255 || vr == 255))) lds_union(sl, me, me - CC_T + 1);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. flatten into registers, then count pixels per root (one LDS atomic per run) ----------
+  uint32_t root[16];
+  for (int k = 0; k < 16; k++) {
+    const int r = wv * 16 + k;
+    const uint32_t l = sl[r * CC_T + lane];
+    root[k] = (l == AT_NO_LABEL) ? AT_NO_LABEL : lds_find(sl, (uint32_t)(r * CC_T + lane));
+  }
+  __syncthreads();
+  for (int k = 0; k < 16; k++) sl[(wv * 16 + k) * CC_T + lane] = 0;
+  __syncthreads();
+  for (int k = 0; k < 16; k++) {
+    const int r = wv * 16 + k;
+    const uint32_t v = st[r * CC_T + lane];
+    const bool link = lane > 0 && v != 127 && src_ok && st[r * CC_T + lane - 1] == v;
+    const unsigned long long S = ~__ballot(link);  // run starts
+    if (!link && v != 127) {
+      const unsigned long long higher = (lane == 63) ? 0ull : (S & ~((2ull << lane) - 1ull));
+      const int e = higher ? __ffsll((long long)higher) - 1 : 64;
+      atomicAdd(&sl[root[k]], (uint32_t)(e - lane));
+    }
+  }
+  __syncthreads();
+
+  // ---- 4. write global labels (index of the local root) and local sizes at the roots -----------
+  uint32_t* label = label_all + (size_t)frame * W * H;
+  uint32_t* csize = csize_all + (size_t)frame * W * H;
+  if (gx < W) {
+    for (int k = 0; k < 16; k++) {
+      const int r = wv * 16 + k;
+      const int gy = Y0 + r;
+      if (gy >= H) break;
+      const uint32_t me = (uint32_t)(r * CC_T + lane);
+      const size_t gi = (size_t)gy * W + gx;
+      if (root[k] == AT_NO_LABEL) { label[gi] = AT_NO_LABEL; csize[gi] = 0; continue; }
+      const uint32_t rr = root[k] / CC_T, rc = root[k] % CC_T;
+      label[gi] = (uint32_t)((Y0 + rr) * W + X0 + rc);
+      csize[gi] = (root[k] == me) ? sl[me] : 0;
+    }
+  }
+}
+
+// Links of pixel (gx,gy) selected by `which` (bit0 left, bit1 up, bit2 up-left, bit3 up-right),
+// evaluated on the global threshold image with the same first-overlap rules as the tile kernel.
+__device__ __forceinline__ void cc_global_links(const uint8_t* thr, uint32_t* label, int W, int H, int WS, int gx, int gy,
+                                                int which) {
+  if (gx < 1 || gx > W - 2 || gy >= H) return;
+  const uint32_t v = thr[(size_t)gy * WS + gx];
+  if (v == 127) return;
+  const uint32_t me = (uint32_t)(gy * W + gx);
+  const uint32_t vl = thr[(size_t)gy * WS + gx - 1];
+  if ((which & 1) && vl == v) glb_union(label, me, me - 1);
+  if (gy == 0) return;
+  const uint32_t vu = thr[(size_t)(gy - 1) * WS + gx];
+  const uint32_t vul = thr[(size_t)(gy - 1) * WS + gx - 1];
+  const bool left_src = gx - 1 >= 1;
+  if ((which & 2) && vu == v && !(left_src && vl == v && vul == v)) glb_union(label, me, me - W);
+  if (v == 255) {
+    if ((which & 4) && vul == 255 && vu != 255 && !(left_src && vl == 255)) glb_union(label, me, me - W - 1);
+    if (which & 8) {
+      const uint32_t vur = thr[(size_t)(gy - 1) * WS + gx + 1];
+      const uint32_t vr = thr[(size_t)gy * WS + gx + 1];
+      const bool right_src = gx + 1 <= W - 2;
+      if (vur == 255 && !(right_src && (vu == 255 || vr == 255))) glb_union(label, me, me - W + 1);
+    }
+  }
+}
+
+// grid.x covers [border rows: nrows*W pixels][left columns: ncols*H][right columns: ncols*H]
+__global__ __launch_bounds__(256) void k_cc_border(const uint8_t* __restrict__ thr_all, uint32_t* __restrict__ label_all,
+                                                   DetParams P) {
+  const int frame = blockIdx.z;
+  const int W = P.W, H = P.H;
+  const uint8_t* thr = thr_all + (size_t)frame * H * P.WS;
+  uint32_t* label = label_all + (size_t)frame * W * H;
+  const int nrows = (H - 1) / CC_T;  // tile-top rows at y = 64, 128, ...
+  const int ncols = (W - 1) / CC_T;  // tile-left columns at x = 64, 128, ...
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nrows * W) {
+    const int gy = (i / W + 1) * CC_T, gx = i % W;
+    cc_global_links(thr, label, W, H, P.WS, gx, gy, 2 | 4 | 8);
+    return;
+  }
+  i -= nrows * W;
+  if (i < ncols * H) {  // first column of a tile: left link always, up-left unless on a tile-top row
+    const int gx = (i / H + 1) * CC_T, gy = i % H;
+    cc_global_links(thr, label, W, H, P.WS, gx, gy, (gy % CC_T) ? (1 | 4) : 1);
+    return;
+  }
+  i -= ncols * H;
+  if (i < ncols * H) {  // last column of a tile: up-right crosses into the next tile
+    const int gx = (i / H + 1) * CC_T - 1, gy = i % H;
+    if (gy % CC_T) cc_global_links(thr, label, W, H, P.WS, gx, gy, 8);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cc_flatten(uint32_t* __restrict__ label_all, uint32_t* __restrict__ csize_all,
+                                                    DetParams P) {
+  const int frame = blockIdx.z;
+  const size_t n = (size_t)P.W * P.H;
+  uint32_t* label = label_all + (size_t)frame * n;
+  uint32_t* csize = csize_all + (size_t)frame * n;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t l = label[i];
+  if (l == AT_NO_LABEL) return;
+  uint32_t r = l, p;
+  while ((p = glb_load(&label[r])) != r) r = p;
+  if (r != l) label[i] = r;
+  const uint32_t c = csize[i];
+  if (c != 0 && r != (uint32_t)i) atomicAdd(&csize[r], c);
+}

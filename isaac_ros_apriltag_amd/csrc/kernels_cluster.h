@@ -1,0 +1,196 @@
+// kernels_cluster.h -- S4 boundary-point extraction and clustering by component pair
+// (inside cuAprilTagsDetect, reference src/apriltag_node.cpp:491-493).
+//
+//   k_points          every pixel of a 64x16 tile looks at its 4 forward neighbours (LDS halo tile of
+//                     {value, label-if-component>=25}); points are compacted with a block scan and one
+//                     atomic per block, and counted per component pair in a per-frame open-addressing
+//                     hash table (64-bit CAS on the key, 32-bit add on the count).
+//   k_cluster_select  keeps pairs with min_cluster_points <= count <= 3*(2W+2H), allocates their point
+//                     ranges with one atomic per wave (ballot/scan), emits the cluster list.
+//   k_scatter         moves the staged points into their cluster's range (order inside a cluster is
+//                     fixed later by the slope sort, so the atomics' arrival order never shows).
+#pragma once
+#include "common.h"
+
+#define PT_TW 64
+#define PT_TH 16
+#define PT_LW (PT_TW + 2)
+#define PT_LH (PT_TH + 1)
+
+__device__ __forceinline__ uint32_t hash_slot(uint64_t key, uint32_t shift) {
+  return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> shift);
+}
+
+// returns slot or AT_INVALID_SLOT when the table is full
+__device__ __forceinline__ uint32_t hash_insert(unsigned long long* hkeys, uint32_t hcap, uint32_t hshift, uint64_t key) {
+  uint32_t h = hash_slot(key, hshift);
+  for (uint32_t probe = 0; probe < hcap; probe++) {
+    unsigned long long cur = __hip_atomic_load(&hkeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == key) return h;
+    if (cur == AT_EMPTY_KEY) {
+      unsigned long long old = atomicCAS(&hkeys[h], AT_EMPTY_KEY, (unsigned long long)key);
+      if (old == AT_EMPTY_KEY || old == key) return h;
+    }
+    h = (h + 1) & (hcap - 1);
+  }
+  return AT_INVALID_SLOT;
+}
+
+__global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_all, const uint32_t* __restrict__ label_all,
+                                                const uint32_t* __restrict__ csize_all, unsigned long long* __restrict__ hkeys_all,
+                                                uint32_t* __restrict__ hcnt_all, uint2* __restrict__ stage_all,
+                                                FrameCounters* __restrict__ counters, DetParams P) {
+  __shared__ uint8_t sv[PT_LH * PT_LW];
+  __shared__ uint32_t slab[PT_LH * PT_LW];
+  __shared__ uint32_t sscan[4];
+  __shared__ uint32_t sbase;
+  const int frame = blockIdx.z;
+  const int W = P.W, H = P.H;
+  const size_t npx = (size_t)W * H;
+  const uint8_t* thr = thr_all + (size_t)frame * H * P.WS;
+  const uint32_t* label = label_all + (size_t)frame * npx;
+  const uint32_t* csize = csize_all + (size_t)frame * npx;
+  const int X0 = blockIdx.x * PT_TW, Y0 = blockIdx.y * PT_TH;
+  const int tid = threadIdx.x;
+
+  for (int i = tid; i < PT_LH * PT_LW; i += 256) {
+    const int ly = i / PT_LW, lx = i % PT_LW;
+    const int gx = X0 + lx - 1, gy = Y0 + ly;
+    uint32_t v = 127, lab = AT_NO_LABEL;
+    if (gx >= 0 && gx < W && gy < H) {
+      v = thr[(size_t)gy * P.WS + gx];
+      if (v != 127) {
+        const uint32_t r = label[(size_t)gy * W + gx];
+        if ((int)csize[r] >= P.min_component_size) lab = r;
+      }
+    }
+    sv[i] = (uint8_t)v;
+    slab[i] = lab;
+  }
+  __syncthreads();
+
+  const int lx = tid & 63;
+  const int gx = X0 + lx;
+  const int DX[4] = {1, 0, -1, 1}, DY[4] = {0, 1, 1, 1};
+  // pass 1: count
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int ly = (tid >> 6) + 4 * k;
+    const int gy = Y0 + ly;
+    if (gx < 1 || gx > W - 2 || gy < 1 || gy > H - 2) continue;
+    const int c = ly * PT_LW + lx + 1;
+    const uint32_t r0 = slab[c];
+    if (r0 == AT_NO_LABEL) continue;
+    const int v0 = sv[c];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const int n = c + DY[d] * PT_LW + DX[d];
+      if (slab[n] != AT_NO_LABEL && v0 + (int)sv[n] == 255) cnt++;
+    }
+  }
+  uint32_t total;
+  uint32_t off = block_excl_scan256(cnt, sscan, &total);
+  if (tid == 0) sbase = total ? atomicAdd(&counters[frame].npoints_raw, total) : 0;
+  __syncthreads();
+  if (total == 0) return;
+  const uint32_t base = sbase;
+  if (base + total > P.pcap) {
+    if (tid == 0) atomicOr(&counters[frame].flags, 0x1u);
+    if (base >= P.pcap) return;
+  }
+  // pass 2: emit
+  unsigned long long* hkeys = hkeys_all + (size_t)frame * P.hcap;
+  uint32_t* hcnt = hcnt_all + (size_t)frame * P.hcap;
+  uint2* stage = stage_all + (size_t)frame * P.pcap;
+  uint64_t last_key = AT_EMPTY_KEY;
+  uint32_t last_slot = AT_INVALID_SLOT;
+  uint32_t pos = base + off;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int ly = (tid >> 6) + 4 * k;
+    const int gy = Y0 + ly;
+    if (gx < 1 || gx > W - 2 || gy < 1 || gy > H - 2) continue;
+    const int c = ly * PT_LW + lx + 1;
+    const uint32_t r0 = slab[c];
+    if (r0 == AT_NO_LABEL) continue;
+    const int v0 = sv[c];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const int n = c + DY[d] * PT_LW + DX[d];
+      const uint32_t r1 = slab[n];
+      const int v1 = sv[n];
+      if (r1 == AT_NO_LABEL || v0 + v1 != 255) continue;
+      const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
+      if (key != last_key) {
+        last_key = key;
+        last_slot = hash_insert(hkeys, P.hcap, P.hshift, key);
+        if (last_slot == AT_INVALID_SLOT) atomicOr(&counters[frame].flags, 0x2u);
+      }
+      if (pos < P.pcap) {
+        if (last_slot != AT_INVALID_SLOT) atomicAdd(&hcnt[last_slot], 1u);
+        stage[pos] = make_uint2(last_slot, pack_point(2 * gx + DX[d], 2 * gy + DY[d], DX[d] * (v1 - v0), DY[d] * (v1 - v0)));
+      }
+      pos++;
+    }
+  }
+}
+
+// one thread per hash slot
+__global__ __launch_bounds__(256) void k_cluster_select(const unsigned long long* __restrict__ hkeys_all,
+                                                        const uint32_t* __restrict__ hcnt_all, uint32_t* __restrict__ hoff_all,
+                                                        ClusterRec* __restrict__ clusters_all,
+                                                        FrameCounters* __restrict__ counters, DetParams P) {
+  const int frame = blockIdx.z;
+  const uint32_t slot = blockIdx.x * 256 + threadIdx.x;  // hcap is a multiple of 256
+  const size_t hi = (size_t)frame * P.hcap + slot;
+  const unsigned long long key = hkeys_all[hi];
+  const uint32_t c = hcnt_all[hi];
+  const bool keep = key != AT_EMPTY_KEY && (int)c >= P.min_cluster_points && (int)c <= P.max_cluster_points;
+  const unsigned long long mask = __ballot(keep);
+  uint32_t off = AT_INVALID_SLOT;
+  if (mask) {  // wave-uniform
+    const uint32_t inc = wave_incl_scan(keep ? c : 0u);
+    const int lane = lane_id();
+    const uint32_t wave_total = __shfl(inc, 63, 64);
+    const uint32_t nkeep = (uint32_t)__popcll(mask);
+    uint32_t pbase = 0, cbase = 0;
+    if (lane == 0) {
+      pbase = atomicAdd(&counters[frame].npoints_kept, wave_total);
+      cbase = atomicAdd(&counters[frame].nclusters, nkeep);
+    }
+    pbase = __shfl(pbase, 0, 64);
+    cbase = __shfl(cbase, 0, 64);
+    if (keep) {
+      const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      const uint32_t ci = cbase + rank;
+      if (ci < P.ccap) {
+        off = pbase + inc - c;
+        ClusterRec rec;
+        rec.key = key; rec.start = off; rec.count = c;
+        clusters_all[(size_t)frame * P.ccap + ci] = rec;
+      } else {
+        atomicOr(&counters[frame].flags, 0x4u);
+      }
+    }
+  }
+  hoff_all[hi] = off;
+}
+
+// one thread per staged point
+__global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ stage_all, uint32_t* __restrict__ hcnt_all,
+                                                 const uint32_t* __restrict__ hoff_all, uint32_t* __restrict__ pts_all,
+                                                 const FrameCounters* __restrict__ counters, DetParams P) {
+  const int frame = blockIdx.z;
+  uint32_t n = counters[frame].npoints_raw;
+  if (n > P.pcap) n = P.pcap;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint2 rec = stage_all[(size_t)frame * P.pcap + i];
+    if (rec.x == AT_INVALID_SLOT) continue;
+    const size_t hi = (size_t)frame * P.hcap + rec.x;
+    const uint32_t off = hoff_all[hi];
+    if (off == AT_INVALID_SLOT) continue;
+    const uint32_t k = atomicSub(&hcnt_all[hi], 1u) - 1u;
+    pts_all[(size_t)frame * P.pcap + off + k] = rec.y;
+  }
+}

@@ -1,0 +1,244 @@
+// kernels_threshold.h -- S1 (point-sample decimation) fused into S2 (adaptive 4x4-tile min/max
+// threshold with 3x3 tile dilation/erosion).  Stands in for the first stages inside the closed
+// cuAprilTagsDetect call (reference src/apriltag_node.cpp:491-493); semantics per SURVEY.md A.1/A.2.
+//
+// HBM-bound streaming kernel, 2 B/pixel algorithmic (1 read + 1 written):
+//   * a 256-thread block owns a 512 x 32 pixel region (128 x 8 tiles); every thread owns a
+//     16 x 4 pixel unit = 4 tiles and keeps its 64 pixels in registers (4 x 16-byte loads);
+//   * per-tile min/max go to LDS (u8, 10 x 132 incl. a one-tile halo ring), the 3x3 dilation reads
+//     two aligned dwords per halo row, the thresholded unit leaves as 4 x 16-byte stores;
+//   * the halo ring (2 tile rows + 2 tile columns) is recomputed from the image (L2 hits).
+#pragma once
+#include "common.h"
+
+#define TH_LDS_STRIDE 132  // bytes per LDS tile row (33 dwords)
+
+// one working-image pixel through the decimating gather (slow path: halos, edges, unaligned input)
+template <int DEC>
+__device__ __forceinline__ uint32_t th_px(const uint8_t* img, uint32_t pitch, int W0, int H0, int x, int y) {
+  int sx = x * DEC, sy = y * DEC;
+  if (sx >= W0 || sy >= H0) return 0;
+  return img[(size_t)sy * pitch + sx];
+}
+
+// loads 16 consecutive working pixels of row y starting at x0 (multiple of 16) into 4 dwords
+template <int DEC>
+__device__ __forceinline__ void th_load16(const uint8_t* img, uint32_t pitch, int W0, int H0, bool aligned,
+                                          int x0, int y, uint32_t out[4]) {
+  int sy = y * DEC;
+  if (sy >= H0 || x0 * DEC >= W0) { out[0] = out[1] = out[2] = out[3] = 0; return; }
+  const uint8_t* row = img + (size_t)sy * pitch;
+  if (DEC == 1) {
+    if (aligned && x0 + 16 <= W0) {
+      uint4 v = *reinterpret_cast<const uint4*>(row + x0);
+      out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+      return;
+    }
+  } else if (DEC == 2) {
+    if (aligned && 2 * x0 + 32 <= W0) {
+      uint4 a = *reinterpret_cast<const uint4*>(row + 2 * x0);
+      uint4 b = *reinterpret_cast<const uint4*>(row + 2 * x0 + 16);
+      // keep the even bytes of each dword pair
+      out[0] = (a.x & 0xFF) | ((a.x >> 8) & 0xFF00) | ((a.y & 0xFF) << 16) | ((a.y << 8) & 0xFF000000u);
+      out[1] = (a.z & 0xFF) | ((a.z >> 8) & 0xFF00) | ((a.w & 0xFF) << 16) | ((a.w << 8) & 0xFF000000u);
+      out[2] = (b.x & 0xFF) | ((b.x >> 8) & 0xFF00) | ((b.y & 0xFF) << 16) | ((b.y << 8) & 0xFF000000u);
+      out[3] = (b.z & 0xFF) | ((b.z >> 8) & 0xFF00) | ((b.w & 0xFF) << 16) | ((b.w << 8) & 0xFF000000u);
+      return;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      int sx = (x0 + 4 * j + b) * DEC;
+      uint32_t v = (sx < W0) ? row[sx] : 0;
+      w |= v << (8 * b);
+    }
+    out[j] = w;
+  }
+}
+
+__device__ __forceinline__ void th_minmax_word(uint32_t w, uint32_t& mn, uint32_t& mx) {
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    uint32_t v = (w >> (8 * b)) & 0xFF;
+    mn = min(mn, v);
+    mx = max(mx, v);
+  }
+}
+
+template <int DEC>
+__global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__ frames, uint8_t* __restrict__ gray_all,
+                                                   uint8_t* __restrict__ thr_all, DetParams P) {
+  __shared__ __attribute__((aligned(16))) uint8_t smin[10 * TH_LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint8_t smax[10 * TH_LDS_STRIDE];
+
+  const int frame = blockIdx.z;
+  const FrameDesc fd = frames[frame];
+  const bool aligned = ((((uintptr_t)fd.img) | (uintptr_t)fd.pitch) & 15) == 0;
+  const int tid = threadIdx.x;
+  const int tx32 = tid & 31, ty8 = tid >> 5;
+  const int TX0 = blockIdx.x * 128, TY0 = blockIdx.y * 8;  // first tile of the block
+  uint8_t* thr = thr_all + (size_t)frame * P.H * P.WS;
+  uint8_t* gray = (DEC > 1) ? gray_all + (size_t)frame * P.H * P.WS : nullptr;
+
+  // ---- own unit: 16 x 4 pixels --------------------------------------------------------------
+  const int ux = (TX0 + 4 * tx32) * 4, uy = (TY0 + ty8) * 4;
+  uint32_t u[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) th_load16<DEC>(fd.img, fd.pitch, P.W0, P.H0, aligned, ux, uy + r, u[r]);
+  if (DEC > 1) {
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      if (uy + r < P.H && ux < P.WS)
+        *reinterpret_cast<uint4*>(gray + (size_t)(uy + r) * P.WS + ux) = make_uint4(u[r][0], u[r][1], u[r][2], u[r][3]);
+  }
+  {
+    const int tY = TY0 + ty8;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int tX = TX0 + 4 * tx32 + j;
+      uint32_t mn = 255, mx = 0;
+      if (tX < P.tw && tY < P.th) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) th_minmax_word(u[r][j], mn, mx);
+      }
+      smin[(ty8 + 1) * TH_LDS_STRIDE + 4 * tx32 + j + 1] = (uint8_t)mn;
+      smax[(ty8 + 1) * TH_LDS_STRIDE + 4 * tx32 + j + 1] = (uint8_t)mx;
+    }
+  }
+  // ---- halo ring ----------------------------------------------------------------------------
+  if (tid < 64) {  // tile rows TY0-1 and TY0+8, 32 units each
+    const int side = tid >> 5, c = tid & 31;
+    const int tY = side ? TY0 + 8 : TY0 - 1;
+    const int lrow = side ? 9 : 0;
+    uint32_t h[4][4];
+    const bool rowok = tY >= 0 && tY < P.th;
+    if (rowok) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) th_load16<DEC>(fd.img, fd.pitch, P.W0, P.H0, aligned, (TX0 + 4 * c) * 4, tY * 4 + r, h[r]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int tX = TX0 + 4 * c + j;
+      uint32_t mn = 255, mx = 0;
+      if (rowok && tX < P.tw) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) th_minmax_word(h[r][j], mn, mx);
+      }
+      smin[lrow * TH_LDS_STRIDE + 4 * c + j + 1] = (uint8_t)mn;
+      smax[lrow * TH_LDS_STRIDE + 4 * c + j + 1] = (uint8_t)mx;
+    }
+  } else if (tid < 84) {  // tile columns TX0-1 and TX0+128, tile rows TY0-1 .. TY0+8
+    const int k = tid - 64;
+    const int side = k / 10, lrow = k % 10;
+    const int tX = side ? TX0 + 128 : TX0 - 1;
+    const int tY = TY0 - 1 + lrow;
+    uint32_t mn = 255, mx = 0;
+    if (tX >= 0 && tX < P.tw && tY >= 0 && tY < P.th) {
+      for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+          uint32_t v = th_px<DEC>(fd.img, fd.pitch, P.W0, P.H0, tX * 4 + c, tY * 4 + r);
+          mn = min(mn, v);
+          mx = max(mx, v);
+        }
+    }
+    const int lcol = side ? 129 : 0;
+    smin[lrow * TH_LDS_STRIDE + lcol] = (uint8_t)mn;
+    smax[lrow * TH_LDS_STRIDE + lcol] = (uint8_t)mx;
+  }
+  __syncthreads();
+
+  // ---- 3x3 dilation / erosion over tiles, then binarize --------------------------------------
+  // LDS columns 4*tx32 .. 4*tx32+5 hold tiles (first-1) .. (first+4): two aligned dwords per row.
+  uint32_t cmin[6], cmax[6];
+#pragma unroll
+  for (int c = 0; c < 6; c++) { cmin[c] = 255; cmax[c] = 0; }
+#pragma unroll
+  for (int dr = 0; dr < 3; dr++) {
+    const uint32_t* rmin = reinterpret_cast<const uint32_t*>(smin + (ty8 + dr) * TH_LDS_STRIDE + 4 * tx32);
+    const uint32_t* rmax = reinterpret_cast<const uint32_t*>(smax + (ty8 + dr) * TH_LDS_STRIDE + 4 * tx32);
+    uint32_t a0 = rmin[0], a1 = rmin[1], b0 = rmax[0], b1 = rmax[1];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      cmin[c] = min(cmin[c], (a0 >> (8 * c)) & 0xFF);
+      cmax[c] = max(cmax[c], (b0 >> (8 * c)) & 0xFF);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      cmin[4 + c] = min(cmin[4 + c], (a1 >> (8 * c)) & 0xFF);
+      cmax[4 + c] = max(cmax[4 + c], (b1 >> (8 * c)) & 0xFF);
+    }
+  }
+  const int tY = TY0 + ty8;
+  if (tY >= P.th) return;
+  uint32_t o[4][4];
+  bool valid[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int tX = TX0 + 4 * tx32 + j;
+    valid[j] = tX < P.tw;
+    const uint32_t mn = min(min(cmin[j], cmin[j + 1]), cmin[j + 2]);
+    const uint32_t mx = max(max(cmax[j], cmax[j + 1]), cmax[j + 2]);
+    if ((int)(mx - mn) < P.min_white_black_diff) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) o[r][j] = 0x7F7F7F7Fu;
+    } else {
+      const uint32_t thresh = mn + (mx - mn) / 2;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t w = u[r][j];
+        uint32_t ow = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) ow |= (((w >> (8 * b)) & 0xFF) > thresh ? 0xFFu : 0u) << (8 * b);
+        o[r][j] = ow;
+      }
+    }
+  }
+  if (valid[3]) {
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      *reinterpret_cast<uint4*>(thr + (size_t)(uy + r) * P.WS + ux) = make_uint4(o[r][0], o[r][1], o[r][2], o[r][3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (valid[j]) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) *reinterpret_cast<uint32_t*>(thr + (size_t)(uy + r) * P.WS + ux + 4 * j) = o[r][j];
+      }
+  }
+}
+
+// Pixels right of / below the last full tile (only when W or H is not a multiple of 4): threshold
+// against the nearest tile's dilated min/max, recomputed from its 12x12 neighbourhood.  No
+// low-contrast rule there.
+template <int DEC>
+__global__ __launch_bounds__(256) void k_threshold_leftover(const FrameDesc* __restrict__ frames, uint8_t* __restrict__ gray_all,
+                                                            uint8_t* __restrict__ thr_all, DetParams P) {
+  const int frame = blockIdx.z;
+  const FrameDesc fd = frames[frame];
+  const int nright = P.W - P.tw * 4;  // columns per row in the right strip
+  const int nbot = P.H - P.th * 4;    // rows in the bottom strip
+  const int right_cnt = nright * (P.th * 4);
+  const int total = right_cnt + nbot * P.W;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int x, y;
+  if (i < right_cnt) { y = i / nright; x = P.tw * 4 + i % nright; }
+  else { int k = i - right_cnt; y = P.th * 4 + k / P.W; x = k % P.W; }
+  int tX = min(x / 4, P.tw - 1), tY = min(y / 4, P.th - 1);
+  uint32_t mn = 255, mx = 0;
+  for (int ty = max(tY - 1, 0); ty <= min(tY + 1, P.th - 1); ty++)
+    for (int tx = max(tX - 1, 0); tx <= min(tX + 1, P.tw - 1); tx++)
+      for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+          uint32_t v = th_px<DEC>(fd.img, fd.pitch, P.W0, P.H0, tx * 4 + c, ty * 4 + r);
+          mn = min(mn, v);
+          mx = max(mx, v);
+        }
+  uint32_t thresh = mn + (mx - mn) / 2;
+  uint32_t v = th_px<DEC>(fd.img, fd.pitch, P.W0, P.H0, x, y);
+  thr_all[(size_t)frame * P.H * P.WS + (size_t)y * P.WS + x] = v > thresh ? 255 : 0;
+  if (DEC > 1) gray_all[(size_t)frame * P.H * P.WS + (size_t)y * P.WS + x] = (uint8_t)v;
+}

@@ -1,0 +1,149 @@
+"""Python host-side view of the detector handle (thin; all work happens behind the C ABI).
+
+Mirrors the call shape the reference node uses on cuAprilTags (reference
+isaac_ros_apriltag/src/apriltag_node.cpp:450-452 create, :491-493 detect, :556 destroy): create once
+per (width, height, family, intrinsics, size); detect is host-synchronous; destroy in close().
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+def _as_images(frames, width, height):
+    """frames: torch uint8 CUDA tensor [n,H,W] / [H,W], or a list of such 2-D tensors, or a list of
+    (dev_ptr, pitch) pairs.  Returns (ctypes array, keepalive)."""
+    items = []
+    if hasattr(frames, "data_ptr"):
+        t = frames
+        if t.dim() == 2:
+            t = t.unsqueeze(0)
+        assert t.dim() == 3 and t.stride(2) == 1, "expected [n,H,W] mono8 with unit pixel stride"
+        for i in range(t.shape[0]):
+            items.append((t[i].data_ptr(), t.stride(1)))
+    else:
+        for f in frames:
+            if hasattr(f, "data_ptr"):
+                assert f.dim() == 2 and f.stride(1) == 1
+                items.append((f.data_ptr(), f.stride(0)))
+            else:
+                items.append((int(f[0]), int(f[1])))
+    arr = (capi.ImageInput * len(items))()
+    for i, (ptr, pitch) in enumerate(items):
+        arr[i].width, arr[i].height, arr[i].dev_ptr, arr[i].pitch = width, height, ptr, pitch
+    return arr, frames
+
+
+class AprilTagDetector:
+    def __init__(self, width, height, families=("tag36h11",), decimate=1, intrinsics=None, tag_size=0.22, max_batch=1,
+                 tile_size=4, device=-1, refine_edges=True, **caps):
+        L = capi.lib()
+        cfg = capi.Config()
+        L.amdAprilTagsDefaultConfig(C.byref(cfg), width, height)
+        cfg.tile_size = tile_size
+        cfg.decimate = decimate
+        cfg.num_families = len(families)
+        for i, f in enumerate(families):
+            e = f if isinstance(f, int) else L.amdAprilTagsFamilyFromName(f.encode())
+            if e < 0:
+                raise capi.AprilTagsError("family lookup %r" % (f,), 2)
+            cfg.families[i] = e
+        if intrinsics is not None:
+            cfg.intrinsics = capi.Intrinsics(*[float(v) for v in intrinsics])
+        cfg.tag_size = tag_size
+        cfg.max_batch = max_batch
+        cfg.refine_edges = 1 if refine_edges else 0
+        cfg.device = device
+        for k, v in caps.items():
+            if not hasattr(cfg, k):
+                raise AttributeError(k)
+            setattr(cfg, k, v)
+        self.families = [f if isinstance(f, str) else capi.family_info(f)["name"] for f in families]
+        self.width, self.height, self.decimate, self.max_batch = width, height, decimate, max_batch
+        self._h = C.c_void_p()
+        capi._check("amdCreateAprilTagsDetectorEx", L.amdCreateAprilTagsDetectorEx(C.byref(self._h), C.byref(cfg)))
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.amdAprilTagsDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- detection --------------------------------------------------------------------------------
+    def detect_batch_ex(self, frames, max_dets=64, intrinsics=None, stream=None):
+        imgs, keep = _as_images(frames, self.width, self.height)
+        n = len(imgs)
+        out = (capi.DetectionEx * (n * max_dets))()
+        cnt = (C.c_uint32 * n)()
+        intr = None
+        if intrinsics is not None:
+            intr = (capi.Intrinsics * n)(*[capi.Intrinsics(*[float(v) for v in k]) for k in intrinsics])
+        capi._check("amdAprilTagsDetectBatchEx",
+                    self._L.amdAprilTagsDetectBatchEx(self._h, n, imgs, intr, out, cnt, max_dets, stream))
+        res = []
+        for f in range(n):
+            dets = []
+            for i in range(cnt[f]):
+                d = out[f * max_dets + i]
+                dets.append({"family": self.families[d.family], "id": int(d.id), "hamming": int(d.hamming),
+                             "decision_margin": float(d.decision_margin),
+                             "H": np.array(list(d.H)).reshape(3, 3), "center": np.array(list(d.c)),
+                             "p": np.array([[d.p[k][0], d.p[k][1]] for k in range(4)]),
+                             "R": np.array(list(d.R)).reshape(3, 3), "t": np.array(list(d.t))})
+            res.append(dets)
+        return res
+
+    def detect_batch_raw(self, frames, max_tags=64, intrinsics=None, stream=None):
+        """Returns (TagID ctypes array of n*max_tags, counts) -- the cuAprilTagsID_t-shaped records."""
+        imgs, keep = _as_images(frames, self.width, self.height)
+        n = len(imgs)
+        out = (capi.TagID * (n * max_tags))()
+        cnt = (C.c_uint32 * n)()
+        intr = None
+        if intrinsics is not None:
+            intr = (capi.Intrinsics * n)(*[capi.Intrinsics(*[float(v) for v in k]) for k in intrinsics])
+        capi._check("amdAprilTagsDetectBatch",
+                    self._L.amdAprilTagsDetectBatch(self._h, n, imgs, intr, out, cnt, max_tags, stream))
+        return out, [int(c) for c in cnt]
+
+    def threshold_only(self, frames, stream=None):
+        imgs, keep = _as_images(frames, self.width, self.height)
+        capi._check("amdAprilTagsThresholdOnly", self._L.amdAprilTagsThresholdOnly(self._h, len(imgs), imgs, stream))
+
+    # ---- measurement / inspection ---------------------------------------------------------------------
+    def set_profiling(self, enable=True):
+        capi._check("amdAprilTagsSetProfiling", self._L.amdAprilTagsSetProfiling(self._h, 1 if enable else 0))
+
+    def stage_ms(self):
+        ms = (C.c_float * capi.NUM_STAGES)()
+        capi._check("amdAprilTagsGetStageMs", self._L.amdAprilTagsGetStageMs(self._h, ms))
+        return dict(zip(capi.stage_names(), [float(v) for v in ms]))
+
+    def frame_flags(self, n):
+        fl = (C.c_uint32 * n)()
+        capi._check("amdAprilTagsGetFrameFlags", self._L.amdAprilTagsGetFrameFlags(self._h, fl, n))
+        return [int(v) for v in fl]
+
+    def debug(self, frame, what):
+        nbytes = C.c_size_t()
+        capi._check("amdAprilTagsDebugCopy", self._L.amdAprilTagsDebugCopy(self._h, frame, what, None, 0, C.byref(nbytes)))
+        buf = np.empty(max(nbytes.value, 1), dtype=np.uint8)
+        capi._check("amdAprilTagsDebugCopy",
+                    self._L.amdAprilTagsDebugCopy(self._h, frame, what, buf.ctypes.data, buf.size, C.byref(nbytes)))
+        buf = buf[:nbytes.value]
+        if what in (capi.DBG_GRAY, capi.DBG_THRESH):
+            return buf
+        if what in (capi.DBG_LABEL, capi.DBG_CSIZE, capi.DBG_POINTS, capi.DBG_COUNTS):
+            return buf.view(np.uint32)
+        if what == capi.DBG_CLUSTERS:
+            return buf.view(np.dtype([("key", "<u8"), ("start", "<u4"), ("count", "<u4")]))
+        if what == capi.DBG_QUADS:
+            return buf.view(np.dtype([("p", "<f4", (4, 2)), ("reversed_border", "<i4"), ("pad", "<u4"), ("key", "<u8")]))
+        return buf

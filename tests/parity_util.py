@@ -1,0 +1,82 @@
+"""Shared helpers: run the HIP path and the CPU oracle on the same frame and compare every stage."""
+import numpy as np
+
+from isaac_ros_apriltag_amd import capi
+from oracle import pyoracle as po
+
+
+def oracle_params(K, decimate=1, tag_size=0.22):
+    # the C ABI carries float intrinsics (like cuAprilTagsCameraIntrinsics_t); give the oracle the same values
+    f32 = lambda v: float(np.float32(v))
+    return po.default_params(fx=f32(K[0, 0]), fy=f32(K[1, 1]), cx=f32(K[0, 2]), cy=f32(K[1, 2]), decimate=decimate,
+                             tag_size=f32(tag_size))
+
+
+def compare_stages(det, frame_idx, img, families, K, decimate=1, tag_size=0.22, verbose=False):
+    """Returns a list of mismatch strings (empty = bit-exact parity on every stage)."""
+    errs = []
+    odets, dump = po.detect(img, families=families, params=oracle_params(K, decimate, tag_size), want_dump=True)
+    w, h = dump["w"], dump["h"]
+    gray = det.debug(frame_idx, capi.DBG_GRAY).reshape(h, w)
+    if not np.array_equal(gray, dump["gray"]):
+        errs.append("gray: %d pixels differ" % int((gray != dump["gray"]).sum()))
+    thr = det.debug(frame_idx, capi.DBG_THRESH).reshape(h, w)
+    if not np.array_equal(thr, dump["thr"]):
+        errs.append("thresh: %d pixels differ" % int((thr != dump["thr"]).sum()))
+    label = det.debug(frame_idx, capi.DBG_LABEL).reshape(h, w)
+    if not np.array_equal(label, dump["label"]):
+        errs.append("label: %d pixels differ" % int((label != dump["label"]).sum()))
+    csize = det.debug(frame_idx, capi.DBG_CSIZE).reshape(h, w)
+    roots = dump["label"] == np.arange(w * h, dtype=np.uint32).reshape(h, w)
+    if not np.array_equal(csize[roots], dump["csize"][roots]):
+        errs.append("csize: %d roots differ" % int((csize[roots] != dump["csize"][roots]).sum()))
+    counts = det.debug(frame_idx, capi.DBG_COUNTS)
+    if counts[5] != 0:
+        errs.append("frame flags 0x%x" % counts[5])
+    cl = det.debug(frame_idx, capi.DBG_CLUSTERS)
+    pts = det.debug(frame_idx, capi.DBG_POINTS)
+    order = np.argsort(cl["key"], kind="stable")
+    okeys = np.array([c[0] for c in dump["clusters"]], dtype=np.uint64)
+    ocnt = np.array([c[2] for c in dump["clusters"]], dtype=np.uint32)
+    if len(order) != len(okeys) or not np.array_equal(cl["key"][order], okeys) or not np.array_equal(cl["count"][order], ocnt):
+        errs.append("clusters: gpu %d vs oracle %d (keys/counts differ)" % (len(order), len(okeys)))
+    else:
+        bad = 0
+        for gi, (key, start, count) in zip(order, dump["clusters"]):
+            g = np.sort(pts[cl["start"][gi]:cl["start"][gi] + count])
+            if not np.array_equal(g, dump["points"][start:start + count]):
+                bad += 1
+        if bad:
+            errs.append("points: %d clusters differ" % bad)
+    q = det.debug(frame_idx, capi.DBG_QUADS)
+    qo = np.argsort(q["key"], kind="stable")
+    oq = dump["quads"]
+    if len(qo) != len(oq):
+        errs.append("quads: gpu %d vs oracle %d" % (len(qo), len(oq)))
+    else:
+        for gi, o in zip(qo, oq):
+            if int(q["key"][gi]) != o["key"] or not np.array_equal(q["p"][gi], o["p"]):
+                errs.append("quad key %x differs: %s vs %s" % (o["key"], q["p"][gi].tolist(), o["p"].tolist()))
+                break
+    if verbose:
+        print("   stages: clusters %d points %d quads %d dets(oracle) %d" % (len(okeys), len(dump["points"]), len(oq), len(odets)))
+    return errs, odets
+
+
+def compare_detections(gdets, odets, exact=True):
+    errs = []
+    if len(gdets) != len(odets):
+        return ["detections: gpu %d vs oracle %d" % (len(gdets), len(odets))]
+    for g, o in zip(gdets, odets):
+        for k in ("family", "id", "hamming"):
+            if g[k] != o[k]:
+                errs.append("det %s: %r vs %r" % (k, g[k], o[k]))
+        if np.float32(g["decision_margin"]) != np.float32(o["decision_margin"]):
+            errs.append("det margin %r vs %r" % (g["decision_margin"], o["decision_margin"]))
+        for k in ("H", "center", "p", "R", "t"):
+            if exact:
+                if not np.array_equal(g[k], o[k]):
+                    errs.append("det id %d field %s differs by %.3e" % (o["id"], k, np.abs(g[k] - o[k]).max()))
+            elif not np.allclose(g[k], o[k], rtol=0, atol=1e-9):
+                errs.append("det id %d field %s differs by %.3e" % (o["id"], k, np.abs(g[k] - o[k]).max()))
+    return errs
