@@ -96,6 +96,11 @@ __device__ __forceinline__ uint32_t float_sortable(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// Correctly rounded float sqrt: HIP's __fsqrt_rn lowers to the native (approximate) instruction on
+// gfx950 (measured: not bit-exact against IEEE).  sqrt in double followed by one rounding to float
+// is exact because 53 >= 2*24 + 2 (double rounding is innocuous for sqrt at that width).
+__device__ __forceinline__ float at_sqrtf_rn(float x) { return (float)__dsqrt_rn((double)x); }
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // wave-level inclusive scan (wave64)

@@ -127,7 +127,7 @@ __global__ void k_debug_math(int op, uint32_t n, const double* a, const double* 
   if (i >= n) return;
   if (op == 0) out[i] = __dsqrt_rn(a[i]);
   else if (op == 1) out[i] = a[i] / b[i];
-  else if (op == 2) out[i] = (double)__fsqrt_rn((float)a[i]);
+  else if (op == 2) out[i] = (double)at_sqrtf_rn((float)a[i]);
   else out[i] = (double)__fdiv_rn((float)a[i], (float)b[i]);
 }
 

@@ -60,12 +60,12 @@ __device__ void refine_edges_dev(const DetParams& P, const uint8_t* im, int w, i
     const double Ex = Mx / N, Ey = My / N;
     const double Cxx = Mxx / N - Ex * Ex, Cxy = Mxy / N - Ex * Ey, Cyy = Myy / N - Ey * Ey;
     const double disc = (Cxx - Cyy) * (Cxx - Cyy) + 4 * Cxy * Cxy;
-    const double eig = 0.5 * (Cxx + Cyy + (double)__fsqrt_rn((float)disc));
+    const double eig = 0.5 * (Cxx + Cyy + (double)at_sqrtf_rn((float)disc));
     const double nx1 = Cxx - eig, ny1 = Cxy, M1 = nx1 * nx1 + ny1 * ny1;
     const double nx2 = Cxy, ny2 = Cyy - eig, M2 = nx2 * nx2 + ny2 * ny2;
     double M;
     if (M1 > M2) { nx = nx1; ny = ny1; M = M1; } else { nx = nx2; ny = ny2; M = M2; }
-    const double length = (double)__fsqrt_rn((float)M);
+    const double length = (double)at_sqrtf_rn((float)M);
     if (fabs(length) < 1e-12) { nx = 0; ny = 0; } else { nx = nx / length; ny = ny / length; }
     lines[edge][0] = Ex; lines[edge][1] = Ey; lines[edge][2] = nx; lines[edge][3] = ny;
   }
@@ -357,9 +357,9 @@ __device__ void pose_from_homography_dev(const double* H, double fx_in, double f
   double R20 = H[6], R21 = H[7], TZ = H[8];
   double R00 = (H[0] - cx * R20) / fx, R01 = (H[1] - cx * R21) / fx, TX = (H[2] - cx * TZ) / fx;
   double R10 = (H[3] - cy * R20) / fy, R11 = (H[4] - cy * R21) / fy, TY = (H[5] - cy * TZ) / fy;
-  const double length1 = (double)__fsqrt_rn((float)(R00 * R00 + R10 * R10 + R20 * R20));
-  const double length2 = (double)__fsqrt_rn((float)(R01 * R01 + R11 * R11 + R21 * R21));
-  double s = 1.0 / (double)__fsqrt_rn((float)(length1 * length2));
+  const double length1 = (double)at_sqrtf_rn((float)(R00 * R00 + R10 * R10 + R20 * R20));
+  const double length2 = (double)at_sqrtf_rn((float)(R01 * R01 + R11 * R11 + R21 * R21));
+  double s = 1.0 / (double)at_sqrtf_rn((float)(length1 * length2));
   if (TZ > 0) s *= -1;
   R20 *= s; R21 *= s; TZ *= s; R00 *= s; R01 *= s; TX *= s; R10 *= s; R11 *= s; TY *= s;
   const double R02 = R10 * R21 - R20 * R11, R12 = R20 * R01 - R00 * R21, R22 = R00 * R11 - R10 * R01;

@@ -62,7 +62,7 @@ __device__ __forceinline__ void fit_line_dev(const double* lf, int sz, int i0, i
   const double Ex = Mx / W, Ey = My / W;
   const double Cxx = Mxx / W - Ex * Ex, Cxy = Mxy / W - Ex * Ey, Cyy = Myy / W - Ey * Ey;
   const double disc = (Cxx - Cyy) * (Cxx - Cyy) + 4 * Cxy * Cxy;
-  const float rootf = __fsqrt_rn((float)disc);
+  const float rootf = at_sqrtf_rn((float)disc);
   const double eig_small = 0.5 * (Cxx + Cyy - (double)rootf);
   if (lineparm) {
     lineparm[0] = Ex; lineparm[1] = Ey;
@@ -71,7 +71,7 @@ __device__ __forceinline__ void fit_line_dev(const double* lf, int sz, int i0, i
     const double nx2 = Cxy, ny2 = Cyy - eig, M2 = nx2 * nx2 + ny2 * ny2;
     double nx, ny, M;
     if (M1 > M2) { nx = nx1; ny = ny1; M = M1; } else { nx = nx2; ny = ny2; M = M2; }
-    const double length = (double)__fsqrt_rn((float)M);
+    const double length = (double)at_sqrtf_rn((float)M);
     if (fabs(length) < 1e-12) { lineparm[2] = 0; lineparm[3] = 0; }
     else { lineparm[2] = nx / length; lineparm[3] = ny / length; }
   }

@@ -44,7 +44,22 @@ def run_scene(name, img, K, families=("tag36h11",), decimate=1):
     det.set_profiling(True)
     det.detect_batch_ex(t, max_dets=256)
     print("      stage ms:", {k: round(v, 3) for k, v in det.stage_ms().items()})
+    # batched throughput: 16 copies of the frame
     det.close()
+    B = 16
+    detb = AprilTagDetector(w, h, families=families, decimate=decimate, intrinsics=(K[0, 0], K[1, 1], K[0, 2], K[1, 2]),
+                            max_batch=B)
+    tb = t.unsqueeze(0).repeat(B, 1, 1).contiguous()
+    detb.detect_batch_ex(tb, max_dets=64)
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(3):
+        rb = detb.detect_batch_ex(tb, max_dets=64)
+    dt = (time.time() - t0) / 3
+    same = all(len(r) == len(g) for r in rb)
+    detb.set_profiling(True); detb.detect_batch_ex(tb, max_dets=64)
+    print("      batch %d: %.2f ms/batch = %.0f fps (all frames same count: %s)" % (B, dt * 1e3, B / dt, same))
+    print("      batch stage ms:", {k: round(v, 3) for k, v in detb.stage_ms().items()})
+    detb.close()
     return not errs
 
 
