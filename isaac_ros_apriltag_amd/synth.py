@@ -107,7 +107,7 @@ def render(width, height, tags, background=150, sigma=0.0, seed=0, ss=4, black=2
     arr = (_Tag * max(len(tags), 1))()
     for i, tg in enumerate(tags):
         codes, d = family_codes(tg["family"])
-        arr[i].code = codes[tg["id"]]
+        arr[i].code = tg["code"] if "code" in tg else codes[tg["id"]]
         arr[i].d = d
         for k, v in enumerate(np.asarray(tg["H"], dtype=np.float64).reshape(-1)):
             arr[i].H[k] = float(v)
@@ -187,22 +187,22 @@ def scene_c5(seed=1234, sigma=2.0):
 
 def scene_c3(seed=77, sigma=2.0):
     """Config 3: 3840x2160, 10x10 board of the stand-in family synth36h11 ids 0-99, side 160 px,
-    gap 40 px, mild tilt 10 deg."""
-    width, height, size = 3840, 2160, 0.16
-    K = default_K(width, height)
-    pitch_px = 200.0
-    z = 1.0
-    # board plane: tags on a regular grid in a plane tilted 10 deg about the vertical axis
+    gap 40 px, board tilted 10 deg about the vertical axis (long lens, f = 4000 px, so that the whole
+    board stays in view)."""
+    width, height = 3840, 2160
+    K = np.array([[4000.0, 0, width / 2.0], [0, 4000.0, height / 2.0], [0, 0, 1]])
+    z = 4.0
+    scale_m = z / K[0, 0]          # metres per pixel at depth z
+    pitch_m, size = 200.0 * scale_m, 160.0 * scale_m
     Rb = rot_xyz(0, math.radians(10.0), 0)
-    scale_m = z / K[0, 0]  # metres per pixel at depth z
     tags, truth = [], []
     for r in range(10):
         for c in range(10):
-            off = np.array([(c - 4.5) * pitch_px * scale_m, (r - 4.5) * pitch_px * scale_m, 0.0])
+            off = np.array([(c - 4.5) * pitch_m, (r - 4.5) * pitch_m, 0.0])
             t = np.array([0.0, 0.0, z]) + Rb @ off
-            H = homography_from_pose(Rb, t, K, size * 160.0 / 160.0 * (160.0 * scale_m) / size)
+            H = homography_from_pose(Rb, t, K, size)
             tid = r * 10 + c
             tags.append({"family": "synth36h11", "id": tid, "H": H})
             truth.append(truth_from_H("synth36h11", tid, H, Rb, t))
     img = render(width, height, tags, background=150, sigma=sigma, seed=seed)
-    return img, K, truth
+    return img, K, truth, size

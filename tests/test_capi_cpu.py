@@ -1,0 +1,88 @@
+"""CPU checks of the drop-in boundary: libapriltag_amd.so loads, exports every symbol that
+include/apriltag_amd.h declares, struct layouts match the header, and argument validation returns
+the documented status codes before any HIP call (no compute without a GPU)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from isaac_ros_apriltag_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "apriltag_amd.h")
+
+
+def _need_lib():
+    if not os.path.exists(capi.LIB_PATH):
+        from isaac_ros_apriltag_amd import build
+        build.build_amd()
+
+
+def test_exports_every_declared_symbol():
+    _need_lib()
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(amd[A-Za-z0-9_]+)\s*\(", text))
+    assert names, "no declarations parsed"
+    L = capi.lib()
+    for n in sorted(names):
+        assert hasattr(L, n), n
+    assert names == set(capi.EXPORTS)
+
+
+def test_struct_layouts_match_header():
+    src = r'''
+#include <stdio.h>
+#include "apriltag_amd.h"
+int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(amdAprilTagsID_t), sizeof(amdAprilTagsDetectionEx_t),
+  sizeof(amdAprilTagsConfig_t), sizeof(amdAprilTagsImageInput_t), sizeof(amdAprilTagsCameraIntrinsics_t), sizeof(amdFloat2)); return 0; }
+'''
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(td, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    assert sizes == [C.sizeof(capi.TagID), C.sizeof(capi.DetectionEx), C.sizeof(capi.Config), C.sizeof(capi.ImageInput),
+                     C.sizeof(capi.Intrinsics), C.sizeof(capi.Float2)]
+
+
+def test_family_names_of_the_reference():
+    """Accepted family strings of the reference (apriltag_node.cpp:47-58); only those with an offline
+    codebook resolve."""
+    _need_lib()
+    L = capi.lib()
+    for name in ("tag36h11", "tag25h9", "tag16h5"):
+        assert L.amdAprilTagsFamilyFromName(name.encode()) >= 0
+    for name in ("tag36h10", "circle21h7", "circle49h12", "custom48h12", "standard41h12", "standard52h13", "NOTHING"):
+        assert L.amdAprilTagsFamilyFromName(name.encode()) == -1
+    info = capi.family_info("tag36h11")
+    assert info["d"] == 6 and info["codes"][0] == 0xd5d628584
+
+
+def test_create_argument_validation():
+    _need_lib()
+    L = capi.lib()
+    h = C.c_void_p()
+    cam = capi.Intrinsics(1000, 1000, 960, 540)
+    # unsupported tile size / family -> AMDAT_UNSUPPORTED (the node throws on non-zero, apriltag_node.cpp:453-457)
+    assert L.amdCreateAprilTagsDetector(C.byref(h), 1920, 1080, 8, 0, C.byref(cam), 0.22) == 2
+    assert L.amdCreateAprilTagsDetector(C.byref(h), 1920, 1080, 4, 5, C.byref(cam), 0.22) == 2
+    assert L.amdCreateAprilTagsDetector(C.byref(h), 0, 1080, 4, 0, C.byref(cam), 0.22) == 1
+    assert L.amdCreateAprilTagsDetector(C.byref(h), 1920, 1080, 4, 0, None, 0.22) == 1
+    assert L.amdAprilTagsDestroy(None) == 1
+    assert not h
+
+
+def test_register_custom_family():
+    _need_lib()
+    L = capi.lib()
+    codes = (C.c_uint64 * 3)(0x231b, 0x2ea5, 0x346a)
+    assert L.amdAprilTagsRegisterFamily(4, b"mini16", 4, codes, 3) == 0
+    assert L.amdAprilTagsFamilyFromName(b"mini16") == 4
+    assert capi.family_info("mini16")["codes"] == [0x231b, 0x2ea5, 0x346a]
+    assert L.amdAprilTagsRegisterFamily(0, b"x", 4, codes, 3) == 1   # built-in slots are read-only
+    assert L.amdAprilTagsStageName(1) == b"threshold"

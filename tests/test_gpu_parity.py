@@ -1,0 +1,225 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI, against
+the CPU oracle on the same seeded frames -- bit-exact on every integer stage (threshold, labels,
+component sizes, clusters, points), bit-exact floats for quads, and bit-exact ids / corners /
+homographies / poses for the detections -- plus the committed golden vectors and size-independent
+properties at the full BASELINE.json sizes."""
+import ctypes as C
+import glob
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from isaac_ros_apriltag_amd import capi, synth  # noqa: E402
+from isaac_ros_apriltag_amd.detector import AprilTagDetector  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+import parity_util as pu  # noqa: E402
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.json")))
+
+
+def _k4(K):
+    return (K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+
+
+def _run(img, K, families=("tag36h11",), decimate=1, **kw):
+    h, w = img.shape
+    det = AprilTagDetector(w, h, families=families, decimate=decimate, intrinsics=_k4(K), max_batch=1, **kw)
+    g = det.detect_batch_ex(torch.from_numpy(np.ascontiguousarray(img)).cuda(), max_dets=256)[0]
+    return det, g
+
+
+def test_device_arithmetic_is_ieee(built):
+    rng = np.random.default_rng(0)
+    a = np.abs(rng.standard_normal(200000)) * 10 ** rng.uniform(-8, 10, 200000)
+    b = rng.standard_normal(200000) * 10 ** rng.uniform(-4, 4, 200000)
+    assert np.array_equal(capi.debug_math(0, a, b), np.sqrt(a))
+    assert np.array_equal(capi.debug_math(1, a, b), a / b)
+    af, bf = a.astype(np.float32), b.astype(np.float32)
+    assert np.array_equal(capi.debug_math(2, a, b), np.sqrt(af).astype(np.float64))
+    assert np.array_equal(capi.debug_math(3, a, b), (af / bf).astype(np.float64))
+
+
+@pytest.mark.parametrize("name,scene,families,decimate", [
+    ("c1", lambda: synth.scene_c1(), ("tag36h11",), 1),
+    ("c1_dec2", lambda: synth.scene_c1(), ("tag36h11",), 2),
+    ("c1_dec3", lambda: synth.scene_c1(), ("tag36h11",), 3),
+    ("pol", lambda: synth.scene_pol_golden(), ("tag36h11",), 1),
+    ("c2_clean", lambda: synth.scene_c2(sigma=0), ("tag36h11",), 1),
+    ("c2", lambda: synth.scene_c2(), ("tag36h11",), 1),
+    ("c2_dec2", lambda: synth.scene_c2(seed=1301), ("tag36h11",), 2),
+    ("c5", lambda: synth.scene_c5(), ("tag36h11", "tag25h9"), 1),
+])
+def test_stage_and_detection_parity(built, name, scene, families, decimate):
+    r = scene()
+    img, K = r[0], r[1]
+    det, g = _run(img, K, families, decimate)
+    errs, odets = pu.compare_stages(det, 0, img, families, K, decimate)
+    errs += pu.compare_detections(g, odets, exact=True)
+    det.close()
+    assert not errs, errs[:5]
+    assert len(g) == len(odets)
+
+
+def test_c3_4k_board_decimate2(built):
+    img, K, truth, size = synth.scene_c3()
+    h, w = img.shape
+    det = AprilTagDetector(w, h, families=("synth36h11",), decimate=2, intrinsics=_k4(K), tag_size=size, max_batch=1)
+    g = det.detect_batch_ex(torch.from_numpy(img).cuda(), max_dets=256)[0]
+    errs, odets = pu.compare_stages(det, 0, img, ("synth36h11",), K, 2, tag_size=size)
+    errs += pu.compare_detections(g, odets)
+    det.close()
+    assert not errs, errs[:5]
+    assert sorted(d["id"] for d in g) == list(range(100))
+
+
+@pytest.mark.parametrize("shape,pitch", [((480, 644), 644), ((477, 635), 640), ((203, 301), 301), ((64, 64), 64), ((33, 70), 83)])
+def test_integer_stages_on_noise_ragged_sizes(built, shape, pitch):
+    """Uniform random bytes (every tile high-contrast, salt-and-pepper components), odd sizes, odd pitch
+    (exercises the unaligned loader and the leftover strips)."""
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    buf = rng.integers(0, 256, size=(shape[0], pitch), dtype=np.uint8)
+    img = buf[:, :shape[1]]
+    K = synth.default_K(shape[1], shape[0])
+    det = AprilTagDetector(shape[1], shape[0], intrinsics=_k4(K), max_batch=1)
+    t = torch.from_numpy(buf).cuda()
+    g = det.detect_batch_ex([(t.data_ptr(), pitch)], max_dets=64)[0]
+    errs, odets = pu.compare_stages(det, 0, np.ascontiguousarray(img), ("tag36h11",), K, 1)
+    errs += pu.compare_detections(g, odets)
+    det.close()
+    assert not errs, errs[:5]
+
+
+def test_three_valued_blocks_cc(built):
+    """Piecewise-constant image with low-contrast regions: exercises value-127 exclusion and large runs."""
+    rng = np.random.default_rng(11)
+    base = rng.choice(np.array([20, 128, 130, 240], dtype=np.uint8), size=(40, 60))
+    img = np.kron(base, np.ones((8, 8), dtype=np.uint8))
+    K = synth.default_K(img.shape[1], img.shape[0])
+    det, g = _run(img, K)
+    errs, odets = pu.compare_stages(det, 0, img, ("tag36h11",), K, 1)
+    det.close()
+    assert not errs, errs[:5]
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-5] for p in GOLD])
+def test_against_committed_golden_vectors(built, path):
+    rec = json.load(open(path))
+    r = getattr(synth, rec["scene"])(**rec["kwargs"])
+    img, K = r[0], r[1]
+    assert zlib.crc32(img.tobytes()) == rec["image_crc32"]
+    det, g = _run(img, K, tuple(rec["families"]), rec["decimate"])
+    h, w = (1 + (img.shape[0] - 1) // rec["decimate"]), (1 + (img.shape[1] - 1) // rec["decimate"])
+    assert zlib.crc32(det.debug(0, capi.DBG_THRESH).tobytes()) == rec["thr_crc32"]
+    assert zlib.crc32(det.debug(0, capi.DBG_LABEL).tobytes()) == rec["label_crc32"]
+    q = det.debug(0, capi.DBG_QUADS)
+    qo = np.argsort(q["key"], kind="stable")
+    assert [q["p"][i].astype("<f4").tobytes().hex() for i in qo] == rec["quads_hex"]
+    det.close()
+    assert len(g) == len(rec["detections"])
+    for d, gd in zip(g, rec["detections"]):
+        assert (d["family"], d["id"], d["hamming"]) == (gd["family"], gd["id"], gd["hamming"])
+        assert np.float32(d["decision_margin"]).tobytes().hex() == gd["decision_margin_hex"]
+        assert np.asarray(d["p"], dtype="<f8").tobytes().hex() == gd["p_hex"]
+        assert np.asarray(d["center"], dtype="<f8").tobytes().hex() == gd["center_hex"]
+        assert np.asarray(d["R"], dtype="<f8").tobytes().hex() == gd["R_hex"]
+        assert np.asarray(d["t"], dtype="<f8").tobytes().hex() == gd["t_hex"]
+
+
+def test_reference_pol_golden_through_c_abi(built):
+    """The reference's pol_test assertions (tolerances 2 px / 0.01 / 0.01) on the cuAprilTagsID_t-shaped
+    records of amdAprilTagsDetect: id, family, corner order, column-major orientation, translation."""
+    img, K, _ = synth.scene_pol_golden()
+    det = AprilTagDetector(1920, 1080, intrinsics=_k4(K), tag_size=0.22, max_batch=1)
+    tags, cnt = det.detect_batch_raw(torch.from_numpy(img).cuda(), max_tags=64)
+    det.close()
+    assert cnt[0] >= 1
+    for i in range(cnt[0]):
+        t = tags[i]
+        assert t.id == 0 and t.family == 0
+        gold = [(1044.0, 665.0), (808.0, 665.0), (808.0, 429.0), (1044.0, 429.0)]
+        for c, g in zip(t.corners, gold):
+            assert abs(c.x - g[0]) <= 2 and abs(c.y - g[1]) <= 2
+        assert abs(t.center.x - 926.0) <= 2 and abs(t.center.y - 547.0) <= 2
+        for v, g in zip(t.translation, (0.255342, 0.098358, 0.403961)):
+            assert abs(v - g) <= 0.01
+        R = np.array(list(t.orientation)).reshape(3, 3).T   # column-major -> row-major
+        assert np.abs(R - np.diag([-1.0, -1.0, 1.0])).max() <= 0.02   # quaternion (0,0,0,1)
+
+
+def test_bgr8_input_through_conversion(built):
+    """Reference fixture encoding is bgr8 (test_cases/apriltag0/image.json): replicate the gray frame
+    into 3 channels, convert on the device, detect."""
+    img, K, _ = synth.scene_pol_golden()
+    bgr = np.repeat(img[:, :, None], 3, axis=2).copy()
+    src = torch.from_numpy(bgr).cuda()
+    dst = torch.empty((1080, 1920), dtype=torch.uint8, device="cuda")
+    rc = capi.lib().amdAprilTagsConvertToMono8(src.data_ptr(), 1920 * 3, b"bgr8", 1920, 1080, dst.data_ptr(), 1920, None)
+    assert rc == 0
+    assert torch.equal(dst.cpu(), torch.from_numpy(img))   # (4899+9617+1868)/16384 == 1 exactly
+    assert capi.lib().amdAprilTagsConvertToMono8(src.data_ptr(), 1920 * 3, b"yuv422", 1920, 1080, dst.data_ptr(), 1920, None) == 2
+    det = AprilTagDetector(1920, 1080, intrinsics=_k4(K), max_batch=1)
+    g = det.detect_batch_ex(dst)[0]
+    det.close()
+    assert [d["id"] for d in g] == [0]
+
+
+def test_batch_properties_full_size(built):
+    """Size-independent properties at BASELINE.json's full size: a batch equals the per-frame results
+    (frames are independent), is permutation-equivariant, deterministic across runs, and per-frame
+    intrinsics only change the pose."""
+    frames = [synth.scene_c2(seed=1234 + i)[0] for i in range(4)]
+    K = synth.default_K(1920, 1080)
+    batch = torch.from_numpy(np.stack(frames)).cuda()
+    det = AprilTagDetector(1920, 1080, intrinsics=_k4(K), max_batch=8)
+    r1 = det.detect_batch_ex(batch)
+    r2 = det.detect_batch_ex(batch)
+    perm = [2, 0, 3, 1]
+    r3 = det.detect_batch_ex(batch[perm].contiguous())
+    single = [det.detect_batch_ex(batch[i])[0] for i in range(4)]
+    K2 = [(1200.0, 1190.0, 950.0, 530.0)] * 4
+    r4 = det.detect_batch_ex(batch, intrinsics=K2)
+    assert det.frame_flags(4) == [0, 0, 0, 0]
+    det.close()
+    for i in range(4):
+        assert not pu.compare_detections(r1[i], r2[i])
+        assert not pu.compare_detections(r1[i], single[i])
+        assert not pu.compare_detections(r3[i], r1[perm[i]])
+        assert [d["id"] for d in r1[i]] == list(range(10))
+        for a, b in zip(r1[i], r4[i]):
+            assert np.array_equal(a["p"], b["p"]) and not np.array_equal(a["t"], b["t"])
+    # pose of frame 0 under K2 equals the oracle's pose for those intrinsics
+    o, _ = po.detect(frames[0], params=pu.oracle_params(np.array([[1200.0, 0, 950.0], [0, 1190.0, 530.0], [0, 0, 1]])))
+    assert not pu.compare_detections(r4[0], o)
+
+
+def test_error_behaviour(built):
+    img, K, _ = synth.scene_c1()
+    det = AprilTagDetector(640, 480, intrinsics=_k4(K), max_batch=2)
+    t = torch.from_numpy(img).cuda()
+    L = capi.lib()
+    imgs = (capi.ImageInput * 3)()
+    for i in range(3):
+        imgs[i].width, imgs[i].height, imgs[i].dev_ptr, imgs[i].pitch = 640, 480, t.data_ptr(), 640
+    out = (capi.TagID * 192)()
+    cnt = (C.c_uint32 * 3)()
+    assert L.amdAprilTagsDetectBatch(det._h, 3, imgs, None, out, cnt, 64, None) == 6      # batch too large
+    imgs[0].width = 320
+    assert L.amdAprilTagsDetectBatch(det._h, 1, imgs, None, out, cnt, 64, None) == 4      # size mismatch
+    imgs[0].width = 640
+    imgs[0].dev_ptr = None
+    assert L.amdAprilTagsDetectBatch(det._h, 1, imgs, None, out, cnt, 64, None) == 1      # null image
+    imgs[0].dev_ptr = t.data_ptr()
+    assert L.amdAprilTagsDetect(det._h, imgs, out, cnt, 64, None) == 0 and cnt[0] == 1
+    # capacity overflow is reported, never UB
+    small = AprilTagDetector(640, 480, intrinsics=_k4(K), max_batch=1, max_points=1000)
+    small.detect_batch_ex(t)
+    assert small.frame_flags(1)[0] & 0x1
+    small.close()
+    det.close()

@@ -1,0 +1,248 @@
+"""CPU tests of the oracle (oracle/apriltag_oracle.c): it is pinned against the reference's own golden
+vector (isaac_ros_apriltag/test/isaac_ros_apriltag_pol_test.py:113-175, re-rendered frame), against the
+renderer's analytic ground truth, and stage by stage against independent numpy/pure-Python
+restatements on small inputs."""
+import math
+
+import numpy as np
+import pytest
+
+from isaac_ros_apriltag_amd import synth
+from oracle import pyoracle as po
+
+
+def _params(K, **kw):
+    return po.default_params(fx=K[0, 0], fy=K[1, 1], cx=K[0, 2], cy=K[1, 2], **kw)
+
+
+def _quat_wxyz(R):
+    # same construction the node uses (Eigen quaternion from a rotation matrix), normalised
+    t = np.trace(R)
+    if t > 0:
+        s = math.sqrt(t + 1.0) * 2
+        q = np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = math.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2
+        q = np.zeros(4)
+        q[1 + i] = 0.25 * s
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    return q / np.linalg.norm(q)
+
+
+def test_family_tables_stride_property(built):
+    P = 982451653
+    for name, nbits in (("tag36h11", 36), ("tag25h9", 25), ("tag16h5", 16)):
+        codes, d = po.family_codes(name)
+        assert d * d == nbits
+        inv = pow(P, -1, 1 << nbits)
+        ks = [((c - codes[0]) * inv) & ((1 << nbits) - 1) for c in codes]
+        assert all(b > a for a, b in zip(ks, ks[1:])), name
+    assert len(po.family_codes("tag25h9")[0]) == 35 and len(po.family_codes("tag16h5")[0]) == 30
+    s36, _ = po.family_codes("synth36h11")
+    assert s36[:27] == po.family_codes("tag36h11")[0]
+
+
+def test_family_min_hamming(built):
+    def rot(w, d):
+        o = 0
+        nb = d * d
+        for r in range(d):
+            for c in range(d):
+                if (w >> (nb - 1 - (c * d + (d - 1 - r)))) & 1:
+                    o |= 1 << (nb - 1 - (r * d + c))
+        return o
+    for name, hmin in (("tag36h11", 11), ("tag25h9", 9), ("tag16h5", 5), ("synth36h11", 11)):
+        codes, d = po.family_codes(name)
+        codes = codes[:120]
+        rots = []
+        for c in codes:
+            r1 = rot(c, d); r2 = rot(r1, d); r3 = rot(r2, d)
+            rots.append((c, r1, r2, r3))
+        best = 99
+        for i in range(len(codes)):
+            for j in range(i + 1, len(codes)):
+                for r in rots[j]:
+                    best = min(best, bin(codes[i] ^ r).count("1"))
+        assert best >= hmin, (name, best)
+
+
+def test_pol_golden_vector(built):
+    """Reference golden numbers, reference tolerances (2 px, 0.01 m, 0.01)."""
+    img, K, truth = synth.scene_pol_golden()
+    dets, _ = po.detect(img, params=_params(K))
+    assert len(dets) >= 1
+    for d in dets:
+        assert d["id"] == 0 and d["family"] == "tag36h11"
+        corners = d["p"][::-1]  # message order: corners[i] = p[3-i]  (apriltag_node.cpp:337-344,512-517)
+        gold = [(1044.0, 665.0), (808.0, 665.0), (808.0, 429.0), (1044.0, 429.0)]
+        for c, g in zip(corners, gold):
+            assert abs(c[0] - g[0]) <= 2 and abs(c[1] - g[1]) <= 2
+        assert abs(d["center"][0] - 926.0) <= 2 and abs(d["center"][1] - 547.0) <= 2
+        for v, g in zip(d["t"], (0.255342, 0.098358, 0.403961)):
+            assert abs(v - g) <= 0.01
+        q = _quat_wxyz(d["R"])
+        if q[3] < 0:
+            q = -q
+        for v, g in zip(q, (0.0, 0.0, 0.0, 1.0)):
+            assert abs(v - g) <= 0.01
+
+
+def test_mono8_at_least_one_detection(built):
+    img, K, _ = synth.scene_pol_golden()
+    dets, _ = po.detect(img, params=_params(K))
+    assert len(dets) >= 1
+
+
+@pytest.mark.parametrize("decimate", [1, 2])
+def test_c1_truth(built, decimate):
+    img, K, truth = synth.scene_c1()
+    dets, _ = po.detect(img, params=_params(K, decimate=decimate))
+    assert [d["id"] for d in dets] == [0]
+    assert np.abs(dets[0]["p"] - truth[0]["p"]).max() < 0.5
+    # upright fronto-parallel tag: identity orientation
+    assert np.abs(dets[0]["R"] - np.eye(3)).max() < 0.02
+
+
+@pytest.mark.parametrize("sigma", [0.0, 2.0])
+def test_c2_truth(built, sigma):
+    img, K, truth = synth.scene_c2(seed=1234, sigma=sigma)
+    dets, _ = po.detect(img, params=_params(K))
+    assert [d["id"] for d in dets] == list(range(10))
+    tm = {t["id"]: t for t in truth}
+    for d in dets:
+        assert d["hamming"] == 0
+        assert np.abs(d["p"] - tm[d["id"]]["p"]).max() < 0.5
+        assert np.abs(d["t"] - tm[d["id"]]["t"]).max() < 0.05
+
+
+def test_c5_two_families(built):
+    img, K, truth = synth.scene_c5()
+    dets, _ = po.detect(img, families=("tag36h11", "tag25h9"), params=_params(K))
+    assert sorted((d["family"], d["id"]) for d in dets) == sorted((t["family"], t["id"]) for t in truth)
+
+
+@pytest.mark.parametrize("quarter", [0, 1, 2, 3])
+def test_rotation_corner_order(built, quarter):
+    ang = quarter * math.pi / 2
+    c, s = math.cos(ang), math.sin(ang)
+    H = np.array([[60 * c, -60 * s, 320.0], [60 * s, 60 * c, 240.0], [0, 0, 1.0]])
+    img = synth.render(640, 480, [{"family": "tag36h11", "id": 3, "H": H}], background=160)
+    dets, _ = po.detect(img, params=_params(synth.default_K(640, 480)))
+    assert [d["id"] for d in dets] == [3]
+    truth = synth.truth_from_H("tag36h11", 3, H)
+    assert np.abs(dets[0]["p"] - truth["p"]).max() < 0.5
+
+
+@pytest.mark.parametrize("nflip", [1, 2, 3])
+def test_hamming_correction(built, nflip):
+    codes, d = po.family_codes("tag36h11")
+    code = codes[5]
+    for b in (3, 17, 30)[:nflip]:
+        code ^= 1 << b
+    H = np.array([[70.0, 0, 300.0], [0, 70.0, 220.0], [0, 0, 1.0]])
+    img = synth.render(640, 480, [{"family": "tag36h11", "id": 5, "H": H, "code": code}], background=160)
+    dets, _ = po.detect(img, params=_params(synth.default_K(640, 480)))
+    if nflip <= 2:
+        assert [(x["id"], x["hamming"]) for x in dets] == [(5, nflip)]
+    else:
+        assert dets == []
+
+
+def test_empty_and_degenerate_inputs(built):
+    flat = np.full((64, 64), 128, dtype=np.uint8)
+    dets, dump = po.detect(flat, want_dump=True)
+    assert dets == [] and (dump["thr"] == 127).all()
+    tiny = np.zeros((4, 4), dtype=np.uint8)
+    assert po.detect(tiny)[0] == []
+
+
+def _numpy_threshold(im, tile=4, min_diff=5):
+    h, w = im.shape
+    tw, th = w // tile, h // tile
+    t = im[:th * tile, :tw * tile].reshape(th, tile, tw, tile)
+    tmin, tmax = t.min(axis=(1, 3)).astype(int), t.max(axis=(1, 3)).astype(int)
+    pmin = np.pad(tmin, 1, constant_values=255)
+    pmax = np.pad(tmax, 1, constant_values=0)
+    dmin = np.min([pmin[1 + dy:1 + dy + th, 1 + dx:1 + dx + tw] for dy in (-1, 0, 1) for dx in (-1, 0, 1)], axis=0)
+    dmax = np.max([pmax[1 + dy:1 + dy + th, 1 + dx:1 + dx + tw] for dy in (-1, 0, 1) for dx in (-1, 0, 1)], axis=0)
+    ty = np.minimum(np.arange(h) // tile, th - 1)
+    tx = np.minimum(np.arange(w) // tile, tw - 1)
+    mn, mx = dmin[ty][:, tx], dmax[ty][:, tx]
+    out = np.where(im.astype(int) > mn + (mx - mn) // 2, 255, 0).astype(np.uint8)
+    low = (mx - mn) < min_diff
+    low[th * tile:, :] = False
+    low[:, tw * tile:] = False
+    out[low] = 127
+    return out
+
+
+@pytest.mark.parametrize("shape", [(32, 48), (37, 50), (16, 16), (5, 9)])
+def test_threshold_vs_numpy(built, shape):
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    im = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    im[: shape[0] // 2] = (im[: shape[0] // 2] // 64) + 100   # low-contrast half
+    assert np.array_equal(po.threshold(im), _numpy_threshold(im))
+
+
+def _bruteforce_cc(thr):
+    h, w = thr.shape
+    parent = list(range(w * h))
+
+    def find(i):
+        while parent[i] != i:
+            parent[i] = parent[parent[i]]
+            i = parent[i]
+        return i
+
+    def union(a, b):
+        a, b = find(a), find(b)
+        if a != b:
+            parent[max(a, b)] = min(a, b)
+    for y in range(h):
+        for x in range(1, w - 1):
+            v = thr[y, x]
+            if v == 127:
+                continue
+            if thr[y, x - 1] == v:
+                union(y * w + x, y * w + x - 1)
+            if y > 0:
+                if thr[y - 1, x] == v:
+                    union(y * w + x, (y - 1) * w + x)
+                if v == 255:
+                    if thr[y - 1, x - 1] == v:
+                        union(y * w + x, (y - 1) * w + x - 1)
+                    if thr[y - 1, x + 1] == v:
+                        union(y * w + x, (y - 1) * w + x + 1)
+    lab = np.array([find(i) if thr.flat[i] != 127 else 0xFFFFFFFF for i in range(w * h)], dtype=np.uint32)
+    return lab.reshape(h, w)
+
+
+def test_cc_vs_bruteforce(built):
+    rng = np.random.default_rng(7)
+    thr = rng.choice(np.array([0, 127, 255], dtype=np.uint8), size=(40, 70), p=[0.45, 0.1, 0.45])
+    label, csize = po.connected_components(thr)
+    ref = _bruteforce_cc(thr)
+    assert np.array_equal(label, ref)
+    for r in np.unique(ref[ref != 0xFFFFFFFF]):
+        assert csize.flat[r] == (ref == r).sum()
+
+
+def test_decimate_point_sampling(built):
+    rng = np.random.default_rng(3)
+    im = rng.integers(0, 256, size=(31, 45), dtype=np.uint8)
+    for f in (1, 2, 3):
+        assert np.array_equal(po.decimate(im, f), im[::f, ::f])
+
+
+def test_pose_matches_truth_homography(built):
+    """Pose from the exact homography of a known pose reproduces it (north_star tolerance 1e-4)."""
+    K = synth.default_K(1920, 1080)
+    R = synth.rot_xyz(0.2, -0.3, 0.4)
+    t = np.array([0.1, -0.05, 1.2])
+    H = synth.homography_from_pose(R, t, K, 0.22)
+    R2, t2 = po.pose_from_homography(H, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 0.22)
+    assert np.abs(R2 - R).max() < 1e-4 and np.abs(t2 - t).max() < 1e-4
