@@ -108,12 +108,14 @@ struct amdAprilTagsDetector_st {
   FrameCounters* d_counters = nullptr;
   FrameDesc* d_frames = nullptr;
   uint64_t* d_codes[AT_MAX_FAMILIES] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned long long* d_fqprof = nullptr;  // optional per-phase cycle counters of k_fit_quads (profiling on)
   // pinned host buffers
   FrameDesc* h_frames = nullptr;
   FrameCounters* h_counters = nullptr;
   DetRec* h_out = nullptr;
   // profiling
   bool profiling = false;
+  bool fq_attr_set = false;
   hipEvent_t ev[AMDAT_NUM_STAGES + 1] = {};
   float stage_ms[AMDAT_NUM_STAGES] = {};
   uint32_t last_n = 0;
@@ -208,6 +210,7 @@ static void free_all(amdAprilTagsDetector_st* D) {
   hipFree(D->d_gray); hipFree(D->d_thr); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_hkeys);
   hipFree(D->d_hcnt); hipFree(D->d_hoff); hipFree(D->d_stage); hipFree(D->d_pts); hipFree(D->d_clusters);
   hipFree(D->d_keys); hipFree(D->d_lf); hipFree(D->d_errs_a); hipFree(D->d_errs_b); hipFree(D->d_quads);
+  hipFree(D->d_fqprof);
   hipFree(D->d_dets); hipFree(D->d_out); hipFree(D->d_order); hipFree(D->d_counters); hipFree(D->d_frames);
   for (int i = 0; i < AT_MAX_FAMILIES; i++) hipFree(D->d_codes[i]);
   if (D->h_frames) hipHostFree(D->h_frames);
@@ -453,12 +456,35 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
     hipLaunchKernelGGL(k_scatter, dim3(gx, 1, n), dim3(256), 0, s, D->d_stage, D->d_hcnt, D->d_hoff, D->d_pts, D->d_counters, P);
   }
   mark();
+  if (prof && !D->d_fqprof) {
+    if (hipMalloc((void**)&D->d_fqprof, 16 * 8) != hipSuccess) D->d_fqprof = nullptr;
+  }
+  if (D->d_fqprof) HIP_TRY(hipMemsetAsync(D->d_fqprof, 0, 16 * 8, s));
   {
-    unsigned gx = 4096 / n;
-    if (gx < 32) gx = 32;
-    if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(k_fit_quads, dim3(gx, n), dim3(256), 0, s, D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_keys,
-                       D->d_lf, D->d_errs_a, D->d_errs_b, D->d_quads, D->d_counters, P);
+    // four size classes: one wave per small cluster, bigger workgroups and LDS key arrays above
+    struct FqClass { int nt, cap, lo, hi; unsigned gx; };
+    auto clampu = [](unsigned v, unsigned a, unsigned b) { return v < a ? a : (v > b ? b : v); };
+    const FqClass cls[4] = {{64, 256, 0, 256, clampu(16384u / n, 128u, 4096u)},
+                            {256, 1024, 256, 1024, clampu(4096u / n, 64u, 1024u)},
+                            {256, 4096, 1024, 4096, clampu(1024u / n, 32u, 512u)},
+                            {512, 16384, 4096, 0x7FFFFFFF, clampu(512u / n, 16u, 256u)}};
+    auto lds_bytes = [](const FqClass& c) { return (size_t)c.cap * 8 + (size_t)(6 * c.nt > 1024 ? 6 * c.nt : 1024) * 8; };
+    if (!D->fq_attr_set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds_bytes(cls[3])));
+      D->fq_attr_set = true;
+    }
+    for (int c = 0; c < 4; c++) {
+      if (P.max_cluster_points <= cls[c].lo) break;
+      const dim3 grid(cls[c].gx, n);
+      const size_t lds = lds_bytes(cls[c]);
+#define FQ_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_keys, D->d_lf, D->d_errs_a, D->d_errs_b, D->d_quads, \
+                D->d_counters, D->d_fqprof, cls[c].cap, cls[c].lo, cls[c].hi, P
+      if (cls[c].nt == 64) hipLaunchKernelGGL(k_fit_quads<64>, grid, dim3(64), lds, s, FQ_ARGS);
+      else if (cls[c].nt == 256) hipLaunchKernelGGL(k_fit_quads<256>, grid, dim3(256), lds, s, FQ_ARGS);
+      else hipLaunchKernelGGL(k_fit_quads<512>, grid, dim3(512), lds, s, FQ_ARGS);
+#undef FQ_ARGS
+    }
   }
   mark();
   hipLaunchKernelGGL(k_decode, dim3(8, n), dim3(64), 0, s, D->d_frames, D->d_quads, D->d_dets, D->d_counters, P);
@@ -634,6 +660,10 @@ int amdAprilTagsDebugCopy(amdAprilTagsHandle handle, uint32_t frame, amdAprilTag
     case AMDAT_DBG_QUADS:
       src = handle->d_quads + (size_t)frame * P.qcap;
       sz = (size_t)(fc.nquads < P.qcap ? fc.nquads : P.qcap) * sizeof(QuadRec);
+      break;
+    case AMDAT_DBG_FQPROF:
+      if (!handle->d_fqprof) { *bytes = 0; return AMDAT_SUCCESS; }
+      src = handle->d_fqprof; sz = 16 * 8;
       break;
     case AMDAT_DBG_COUNTS: {
       uint32_t c[8] = {fc.npoints_raw, fc.nclusters, fc.npoints_kept, fc.nquads, fc.ndets, fc.flags, (uint32_t)P.W, (uint32_t)P.H};

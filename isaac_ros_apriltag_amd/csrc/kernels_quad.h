@@ -1,40 +1,54 @@
 // kernels_quad.h -- S5 quad fitting (inside cuAprilTagsDetect, reference
-// src/apriltag_node.cpp:491-493).  One 256-thread workgroup per cluster:
-//   bbox / gradient-dot by integer block reductions -> slope keys -> in-place bitonic sort (LDS up
-//   to 4096 points, global scratch above) -> per-point weighted moment terms in parallel -> the
-//   cumulative moments as ONE sequential double chain per moment (6 lanes), which is what makes the
-//   result bit-identical to the sequential CPU definition -> windowed line-fit errors, 7-tap
-//   smoothing, local maxima, top-10 selection, all C(10,4) corner choices evaluated from a
-//   precomputed table of pairwise segment fits -> 4 line fits, intersections, area/angle checks.
+// src/apriltag_node.cpp:491-493).  One workgroup per cluster, four launch classes by cluster size
+// (one wave for <= 256 points, 256 threads up to 4096, 512 threads above) so that small clusters do
+// not pay for idle waves and the slope sort always runs in LDS (2 KB ... 128 KB of keys):
+//   bbox / gradient-dot by integer block reductions -> slope keys -> in-place bitonic sort in LDS ->
+//   weighted moment terms NT points at a time into an LDS chunk, cumulative sums as ONE sequential
+//   double chain per moment (6 lanes; this is what makes the result bit-identical to the sequential
+//   CPU definition), chunk streamed to the moment array -> windowed line-fit errors, 7-tap smoothing
+//   -> local maxima compacted into LDS, top-10 selection by 11 block arg-max rounds over that list ->
+//   all C(10,4) corner choices from a table of pairwise segment fits -> 4 line fits, intersections and
+//   the area/angle checks spread over 4 lanes.
 #pragma once
 #include "common.h"
 
-#define FQ_SORT_LDS 4096
 
+template <int NW>
 __device__ __forceinline__ int block_reduce_min_i(int v, int* scratch) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  if (NW == 1) return v;
   if (lane_id() == 0) scratch[threadIdx.x >> 6] = v;
   __syncthreads();
-  int r = min(min(scratch[0], scratch[1]), min(scratch[2], scratch[3]));
+  int r = scratch[0];
+#pragma unroll
+  for (int w = 1; w < NW; w++) r = min(r, scratch[w]);
   __syncthreads();
   return r;
 }
+template <int NW>
 __device__ __forceinline__ int block_reduce_max_i(int v, int* scratch) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  if (NW == 1) return v;
   if (lane_id() == 0) scratch[threadIdx.x >> 6] = v;
   __syncthreads();
-  int r = max(max(scratch[0], scratch[1]), max(scratch[2], scratch[3]));
+  int r = scratch[0];
+#pragma unroll
+  for (int w = 1; w < NW; w++) r = max(r, scratch[w]);
   __syncthreads();
   return r;
 }
+template <int NW>
 __device__ __forceinline__ long long block_reduce_sum_ll(long long v, long long* scratch) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  if (NW == 1) return v;
   if (lane_id() == 0) scratch[threadIdx.x >> 6] = v;
   __syncthreads();
-  long long r = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+  long long r = scratch[0];
+#pragma unroll
+  for (int w = 1; w < NW; w++) r += scratch[w];
   __syncthreads();
   return r;
 }
@@ -79,7 +93,7 @@ __device__ __forceinline__ void fit_line_dev(const double* lf, int sz, int i0, i
   if (mse) *mse = eig_small;
 }
 
-template <typename KeyPtr>
+template <int NT, typename KeyPtr>
 __device__ __forceinline__ void bitonic_sort_block(KeyPtr A, int n) {
   // all-ascending bitonic network; indices >= n act as +infinity and are never touched
   int npow = 1;
@@ -87,7 +101,7 @@ __device__ __forceinline__ void bitonic_sort_block(KeyPtr A, int n) {
   const int half = npow >> 1;
   for (int k = 2; k <= npow; k <<= 1) {
     const int hk = k >> 1;
-    for (int i = threadIdx.x; i < half; i += 256) {
+    for (int i = threadIdx.x; i < half; i += NT) {
       const int blk = i / hk, off = i % hk;
       const int a = blk * k + off, b = blk * k + k - 1 - off;
       if (b < n) {
@@ -97,7 +111,7 @@ __device__ __forceinline__ void bitonic_sort_block(KeyPtr A, int n) {
     }
     __syncthreads();
     for (int j = k >> 2; j >= 1; j >>= 1) {
-      for (int i = threadIdx.x; i < half; i += 256) {
+      for (int i = threadIdx.x; i < half; i += NT) {
         const int a = (i / j) * 2 * j + (i % j), b = a + j;
         if (b < n) {
           unsigned long long x = A[a], y = A[b];
@@ -109,23 +123,52 @@ __device__ __forceinline__ void bitonic_sort_block(KeyPtr A, int n) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_fit_quads(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
+// lexicographic index of the 4-subsets of {0..9}: entry t = {m0,m1,m2,m3} packed 4 bits each
+__device__ __forceinline__ uint32_t combo_of(int t) {
+  int c = 0;
+  for (int m0 = 0; m0 < 7; m0++)
+    for (int m1 = m0 + 1; m1 < 8; m1++)
+      for (int m2 = m1 + 1; m2 < 9; m2++)
+        for (int m3 = m2 + 1; m3 < 10; m3++) {
+          if (c == t) return (uint32_t)(m0 | (m1 << 4) | (m2 << 8) | (m3 << 12));
+          c++;
+        }
+  return 0xFFFFu;
+}
+
+// Dynamic LDS layout: [0, 8*sort_cap) slope keys (later: maxima candidates) | max(6*NT, 1024) doubles
+// moment chunk (later: pair-fit tables).  Clusters with size in (size_lo, size_hi] are processed by this
+// launch; those above sort_cap (only possible in the last class) sort in global scratch.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_fit_quads(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
                                                    const uint32_t* __restrict__ pts_all, const ClusterRec* __restrict__ clusters_all,
                                                    unsigned long long* __restrict__ keys_all, double* __restrict__ lf_all,
                                                    double* __restrict__ errs_a_all, double* __restrict__ errs_b_all,
                                                    QuadRec* __restrict__ quads_all, FrameCounters* __restrict__ counters,
+                                                   unsigned long long* __restrict__ prof, int sort_cap, int size_lo, int size_hi,
                                                    DetParams P) {
-  __shared__ unsigned long long skeys[FQ_SORT_LDS];
-  __shared__ long long sred_ll[4];
-  __shared__ int sred_i[4];
-  __shared__ double sred_d[4];
-  __shared__ int sred_di[4];
-  __shared__ int s_removed[12];
-  __shared__ int s_nrem;
-  __shared__ double s_thresh;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fq_smem[];
+  unsigned long long* skeys = reinterpret_cast<unsigned long long*>(fq_smem);
+  double* chunk = reinterpret_cast<double*>(fq_smem + (size_t)sort_cap * 8);
+  // pair tables alias the chunk buffer (used after the cumulative sums are finished)
+  double* s_ferr = chunk; double* s_fmse = chunk + 100; double* s_fnx = chunk + 200; double* s_fny = chunk + 300;
+  double* s_werr = chunk + 400; double* s_wmse = chunk + 500;
+  double* s_lines = chunk + 600;  // [4][4]
+  double* s_lmse = chunk + 616;   // [4]
+  constexpr int NW = NT / 64;
+  __shared__ long long sred_ll[NW];
+  __shared__ int sred_i[NW];
+  __shared__ double sred_d[NW];
+  __shared__ int sred_di[NW];
+  __shared__ double s_remval[12];
+  __shared__ int s_remidx[12];
+  __shared__ int s_ncand;
   __shared__ int s_maxidx[16];
-  __shared__ int s_nmaxkept;
-  __shared__ double s_ferr[100], s_fmse[100], s_fnx[100], s_fny[100], s_werr[100], s_wmse[100];
+  __shared__ int s_nkept;
+  __shared__ uint16_t s_combo[210];
+  __shared__ float s_corner[4][2];
+  __shared__ int s_ok;
+  __shared__ int s_idx4[4];
 
   const int frame = blockIdx.y;
   const int tid = threadIdx.x;
@@ -136,17 +179,28 @@ __global__ __launch_bounds__(256) void k_fit_quads(const FrameDesc* __restrict__
   uint32_t ncl = counters[frame].nclusters;
   if (ncl > P.ccap) ncl = P.ccap;
 
+  for (int t = tid; t < 210; t += NT) s_combo[t] = (uint16_t)combo_of(t);
+
+#define FQ_TICK(slot)                                                                  \
+  if (prof && tid == 0) {                                                              \
+    const unsigned long long now_ = __builtin_readcyclecounter();                      \
+    atomicAdd(&prof[slot], now_ - t_prev_);                                            \
+    t_prev_ = now_;                                                                    \
+  }
+  unsigned long long t_prev_ = prof ? __builtin_readcyclecounter() : 0ull;
+
   for (uint32_t ci = blockIdx.x; ci < ncl; ci += gridDim.x) {
-    __syncthreads();
     const ClusterRec cl = clusters_all[(size_t)frame * P.ccap + ci];
     const int sz = (int)cl.count;
+    if (sz <= size_lo || sz > size_hi || sz < 24) continue;
+    __syncthreads();
+    FQ_TICK(0)
     const uint32_t* pts = pts_all + (size_t)frame * P.pcap + cl.start;
-    if (sz < 24) continue;
 
     // ---- bbox and exact gradient dot -----------------------------------------------------------
     int xmin = 1 << 30, xmax = -1, ymin = 1 << 30, ymax = -1;
     long long sxg = 0, sgx = 0, sgy = 0;
-    for (int i = tid; i < sz; i += 256) {
+    for (int i = tid; i < sz; i += NT) {
       const uint32_t p = pts[i];
       const int x = (int)(p >> 18), y = (int)((p >> 4) & 0x3FFF);
       const int gx = ((int)((p >> 2) & 3) - 1) * 255, gy = ((int)(p & 3) - 1) * 255;
@@ -154,21 +208,22 @@ __global__ __launch_bounds__(256) void k_fit_quads(const FrameDesc* __restrict__
       sxg += (long long)x * gx + (long long)y * gy;
       sgx += gx; sgy += gy;
     }
-    xmin = block_reduce_min_i(xmin, sred_i); xmax = block_reduce_max_i(xmax, sred_i);
-    ymin = block_reduce_min_i(ymin, sred_i); ymax = block_reduce_max_i(ymax, sred_i);
-    sxg = block_reduce_sum_ll(sxg, sred_ll); sgx = block_reduce_sum_ll(sgx, sred_ll); sgy = block_reduce_sum_ll(sgy, sred_ll);
+    xmin = block_reduce_min_i<NW>(xmin, sred_i); xmax = block_reduce_max_i<NW>(xmax, sred_i);
+    ymin = block_reduce_min_i<NW>(ymin, sred_i); ymax = block_reduce_max_i<NW>(ymax, sred_i);
+    sxg = block_reduce_sum_ll<NW>(sxg, sred_ll); sgx = block_reduce_sum_ll<NW>(sgx, sred_ll); sgy = block_reduce_sum_ll<NW>(sgy, sred_ll);
     if ((xmax - xmin) * (ymax - ymin) < P.min_tag_width) continue;
     const double cxd = (xmin + xmax) * 0.5 + 0.05118, cyd = (ymin + ymax) * 0.5 + -0.028581;
     const double dot = (double)sxg - cxd * (double)sgx - cyd * (double)sgy;
     const int q_reversed = dot < 0;
     if (!P.reversed_border && q_reversed) continue;
     if (!P.normal_border && !q_reversed) continue;
+    FQ_TICK(1)
 
     // ---- slope keys + sort -----------------------------------------------------------------------
     const float cx = (float)cxd, cy = (float)cyd;
-    const bool in_lds = sz <= FQ_SORT_LDS;
+    const bool in_lds = sz <= sort_cap;
     unsigned long long* gkeys = keys_all + (size_t)frame * P.pcap + cl.start;
-    for (int i = tid; i < sz; i += 256) {
+    for (int i = tid; i < sz; i += NT) {
       const uint32_t p = pts[i];
       const int x = (int)(p >> 18), y = (int)((p >> 4) & 0x3FFF);
       float dx = (float)x - cx, dy = (float)y - cy;
@@ -183,86 +238,113 @@ __global__ __launch_bounds__(256) void k_fit_quads(const FrameDesc* __restrict__
       if (in_lds) skeys[i] = key; else gkeys[i] = key;
     }
     __syncthreads();
-    if (in_lds) bitonic_sort_block(skeys, sz); else bitonic_sort_block(gkeys, sz);
+    if (in_lds) bitonic_sort_block<NT>(skeys, sz); else bitonic_sort_block<NT>(gkeys, sz);
+    FQ_TICK(2)
 
-    // ---- per-point weighted moment terms (parallel), then the sequential cumulative sums ---------
+    // ---- weighted moment terms per NT-point chunk, sequential cumulative sums in LDS --------------
     double* lf = lf_all + ((size_t)frame * P.pcap + cl.start) * 6;
-    for (int i = tid; i < sz; i += 256) {
-      const unsigned long long key = in_lds ? skeys[i] : gkeys[i];
-      const int px = (int)((key >> 4) & 0x3FFF), py = (int)((key >> 18) & 0x3FFF);
-      const double x = px * .5 + 0.5, y = py * .5 + 0.5;
-      const int ix = (int)x, iy = (int)y;
-      double Wt = 1;
-      if (ix > 0 && ix + 1 < W && iy > 0 && iy + 1 < H) {
-        const int grad_x = (int)gray[(size_t)iy * gpitch + ix + 1] - (int)gray[(size_t)iy * gpitch + ix - 1];
-        const int grad_y = (int)gray[(size_t)(iy + 1) * gpitch + ix] - (int)gray[(size_t)(iy - 1) * gpitch + ix];
-        Wt = __dsqrt_rn((double)(grad_x * grad_x + grad_y * grad_y)) + 1;
+    double carry = 0;  // lanes 0..5: running sum of moment `tid`
+    for (int base = 0; base < sz; base += NT) {
+      const int i = base + tid;
+      if (i < sz) {
+        const unsigned long long key = in_lds ? skeys[i] : gkeys[i];
+        const int px = (int)((key >> 4) & 0x3FFF), py = (int)((key >> 18) & 0x3FFF);
+        const double x = px * .5 + 0.5, y = py * .5 + 0.5;
+        const int ix = (int)x, iy = (int)y;
+        double Wt = 1;
+        if (ix > 0 && ix + 1 < W && iy > 0 && iy + 1 < H) {
+          const int grad_x = (int)gray[(size_t)iy * gpitch + ix + 1] - (int)gray[(size_t)iy * gpitch + ix - 1];
+          const int grad_y = (int)gray[(size_t)(iy + 1) * gpitch + ix] - (int)gray[(size_t)(iy - 1) * gpitch + ix];
+          Wt = __dsqrt_rn((double)(grad_x * grad_x + grad_y * grad_y)) + 1;
+        }
+        chunk[0 * NT + tid] = Wt * x;
+        chunk[1 * NT + tid] = Wt * y;
+        chunk[2 * NT + tid] = Wt * x * x;
+        chunk[3 * NT + tid] = Wt * x * y;
+        chunk[4 * NT + tid] = Wt * y * y;
+        chunk[5 * NT + tid] = Wt;
       }
-      double* o = lf + (size_t)i * 6;
-      o[0] = Wt * x; o[1] = Wt * y; o[2] = Wt * x * x; o[3] = Wt * x * y; o[4] = Wt * y * y; o[5] = Wt;
-    }
-    __syncthreads();
-    if (tid < 6) {
-      double acc = 0;
-      int i = 0;
-      for (; i + 8 <= sz; i += 8) {
-        double v[8];
+      __syncthreads();
+      if (tid < 6) {
+        const int cnt = min(NT, sz - base);
+        double* row = chunk + tid * NT;
+        double acc = carry;
+        int k = 0;
+        for (; k + 8 <= cnt; k += 8) {
+          double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = lf[(size_t)(i + u) * 6 + tid];
+          for (int u = 0; u < 8; u++) v[u] = row[k + u];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { acc += v[u]; lf[(size_t)(i + u) * 6 + tid] = acc; }
+          for (int u = 0; u < 8; u++) { acc += v[u]; v[u] = acc; }
+#pragma unroll
+          for (int u = 0; u < 8; u++) row[k + u] = v[u];
+        }
+        for (; k < cnt; k++) { acc += row[k]; row[k] = acc; }
+        carry = acc;
       }
-      for (; i < sz; i++) { acc += lf[(size_t)i * 6 + tid]; lf[(size_t)i * 6 + tid] = acc; }
+      __syncthreads();
+      if (i < sz) {
+        double* o = lf + (size_t)i * 6;
+#pragma unroll
+        for (int j = 0; j < 6; j++) o[j] = chunk[j * NT + tid];
+      }
+      __syncthreads();
     }
-    __syncthreads();
+    FQ_TICK(4)
 
     // ---- windowed line-fit error, smoothing ------------------------------------------------------
     const int ksz = min(20, sz / 12);
     double* ea = errs_a_all + (size_t)frame * P.pcap + cl.start;
     double* eb = errs_b_all + (size_t)frame * P.pcap + cl.start;
-    for (int i = tid; i < sz; i += 256) {
+    for (int i = tid; i < sz; i += NT) {
       double e;
       fit_line_dev(lf, sz, (i + sz - ksz) % sz, (i + ksz) % sz, nullptr, &e, nullptr);
       ea[i] = e;
     }
+    if (tid == 0) { s_ncand = 0; s_nkept = 0; s_ok = 1; }
     __syncthreads();
     {
       const float f0 = 0x1.6c0504p-7f, f1 = 0x1.152aaap-3f, f2 = 0x1.368b3p-1f;
-      const double F[7] = {(double)f0, (double)f1, (double)f2, 1.0, (double)f2, (double)f1, (double)f0};
-      for (int i = tid; i < sz; i += 256) {
+      const double F0 = (double)f0, F1 = (double)f1, F2 = (double)f2;
+      for (int i = tid; i < sz; i += NT) {
         double acc = 0;
-#pragma unroll
-        for (int k = 0; k < 7; k++) acc += ea[(i + k - 3 + sz) % sz] * F[k];
+        acc += ea[(i - 3 + sz) % sz] * F0;
+        acc += ea[(i - 2 + sz) % sz] * F1;
+        acc += ea[(i - 1 + sz) % sz] * F2;
+        acc += ea[i] * 1.0;
+        acc += ea[(i + 1) % sz] * F2;
+        acc += ea[(i + 2) % sz] * F1;
+        acc += ea[(i + 3) % sz] * F0;
         eb[i] = acc;
       }
     }
     __syncthreads();
+    FQ_TICK(5)
 
-    // ---- local maxima ----------------------------------------------------------------------------
-    int mycount = 0;
-    for (int i = tid; i < sz; i += 256) {
+    // ---- local maxima -> candidate list (values + indices) ------------------------------------------
+    // list storage: the key array is free now (LDS), or the first error array (global) for huge clusters
+    double* cand_val = in_lds ? reinterpret_cast<double*>(skeys) : ea;
+    int* cand_idx = in_lds ? reinterpret_cast<int*>(skeys + (sort_cap >> 1)) : reinterpret_cast<int*>(ea + (sz >> 1) + 1);
+    for (int i = tid; i < sz; i += NT) {
       const double e = eb[i];
-      if (e > eb[(i + 1) % sz] && e > eb[(i + sz - 1) % sz]) mycount++;
+      if (e > eb[(i + 1) % sz] && e > eb[(i + sz - 1) % sz]) {
+        const int k = atomicAdd(&s_ncand, 1);
+        cand_val[k] = e;
+        cand_idx[k] = i;
+      }
     }
-    const int nmaxima = (int)block_reduce_sum_ll(mycount, sred_ll);
-    if (nmaxima < 4) continue;
-    if (tid == 0) { s_nrem = 0; s_nmaxkept = 0; s_thresh = 0; }
     __syncthreads();
+    const int nmaxima = s_ncand;
+    if (nmaxima < 4) continue;
     const bool select = nmaxima > P.max_nmaxima;
     if (select) {
-      // value of the (max_nmaxima+1)-th largest maximum: remove the current largest max_nmaxima+1 times
+      // remove the current largest (max_nmaxima + 1) times; the last removed value is the threshold
       for (int round = 0; round <= P.max_nmaxima; round++) {
         double bv = 0; int bi = -1;
-        const int nrem = s_nrem;
-        for (int i = tid; i < sz; i += 256) {
-          const double e = eb[i];
-          if (!(e > eb[(i + 1) % sz] && e > eb[(i + sz - 1) % sz])) continue;
-          bool removed = false;
-          for (int r = 0; r < nrem; r++) removed |= (s_removed[r] == i);
-          if (removed) continue;
-          if (bi < 0 || e > bv) { bv = e; bi = i; }
+        for (int k = tid; k < nmaxima; k += NT) {
+          const double e = cand_val[k];
+          if (cand_idx[k] >= 0 && (bi < 0 || e > bv)) { bv = e; bi = k; }
         }
-        // block argmax (value, then lowest index)
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
           const double ov = __shfl_xor(bv, off, 64);
@@ -273,26 +355,29 @@ __global__ __launch_bounds__(256) void k_fit_quads(const FrameDesc* __restrict__
         __syncthreads();
         if (tid == 0) {
           double v = 0; int ix = -1;
-          for (int w = 0; w < 4; w++) {
+          for (int w = 0; w < NW; w++) {
             const double ov = sred_d[w]; const int oi = sred_di[w];
             if (oi >= 0 && (ix < 0 || ov > v || (ov == v && oi < ix))) { v = ov; ix = oi; }
           }
-          s_removed[s_nrem++] = ix;
-          s_thresh = v;
+          s_remval[round] = v;
+          s_remidx[round] = cand_idx[ix];
+          cand_idx[ix] = -1;  // removed
         }
         __syncthreads();
       }
-    }
-    const double thresh = s_thresh;
-    for (int i = tid; i < sz; i += 256) {
-      const double e = eb[i];
-      if (!(e > eb[(i + 1) % sz] && e > eb[(i + sz - 1) % sz])) continue;
-      if (select && e <= thresh) continue;
-      const int k = atomicAdd(&s_nmaxkept, 1);
-      if (k < 16) s_maxidx[k] = i;
+      if (tid == 0) {
+        const double thresh = s_remval[P.max_nmaxima];
+        int m = 0;
+        for (int r = 0; r < P.max_nmaxima; r++)
+          if (s_remval[r] > thresh) s_maxidx[m++] = s_remidx[r];
+        s_nkept = m;
+      }
+    } else if (tid == 0) {
+      for (int k = 0; k < nmaxima; k++) s_maxidx[k] = cand_idx[k];
+      s_nkept = nmaxima;
     }
     __syncthreads();
-    const int m = min(s_nmaxkept, 10);
+    const int m = s_nkept;
     if (tid == 0) {  // ascending index order (<= 10 entries)
       for (int a = 1; a < m; a++) {
         const int v = s_maxidx[a];
@@ -303,15 +388,16 @@ __global__ __launch_bounds__(256) void k_fit_quads(const FrameDesc* __restrict__
     }
     __syncthreads();
     if (m < 4) continue;
+    FQ_TICK(6)
 
     // ---- pairwise segment fits, then all corner quadruples ---------------------------------------
-    if (tid < 200) {
-      const int t = tid % 100, a = t / 10, b = t % 10;
+    for (int task = tid; task < 200; task += NT) {
+      const int t = task % 100, a = t / 10, b = t % 10;
       if (a < b && b < m) {
-        if (tid < 100) {
-          double prm[4], e, ms;
-          fit_line_dev(lf, sz, s_maxidx[a], s_maxidx[b], prm, &e, &ms);
-          s_ferr[t] = e; s_fmse[t] = ms; s_fnx[t] = prm[2]; s_fny[t] = prm[3];
+        if (task < 100) {
+          double e, ms;
+          fit_line_dev(lf, sz, s_maxidx[a], s_maxidx[b], s_lines + 20 + task * 4, &e, &ms);  // params parked past s_lmse
+          s_ferr[t] = e; s_fmse[t] = ms; s_fnx[t] = s_lines[20 + task * 4 + 2]; s_fny[t] = s_lines[20 + task * 4 + 3];
         } else {
           double e, ms;
           fit_line_dev(lf, sz, s_maxidx[b], s_maxidx[a], nullptr, &e, &ms);
@@ -322,24 +408,17 @@ __global__ __launch_bounds__(256) void k_fit_quads(const FrameDesc* __restrict__
     __syncthreads();
     double best_err = (double)HUGE_VALF;
     int best_t = 1 << 30;
-    if (tid < 210) {
-      int c = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-      bool found = false;
-      for (int m0 = 0; m0 < 7 && !found; m0++)
-        for (int m1 = m0 + 1; m1 < 8 && !found; m1++)
-          for (int m2 = m1 + 1; m2 < 9 && !found; m2++)
-            for (int m3 = m2 + 1; m3 < 10; m3++) {
-              if (c == tid) { q0 = m0; q1 = m1; q2 = m2; q3 = m3; found = true; break; }
-              c++;
-            }
-      if (found && q3 < m) {
+    for (int t = tid; t < 210; t += NT) {
+      const uint32_t my_combo = s_combo[t];
+      const int q0 = my_combo & 15, q1 = (my_combo >> 4) & 15, q2 = (my_combo >> 8) & 15, q3 = (my_combo >> 12) & 15;
+      if (q3 < m) {
         const double mse01 = s_fmse[q0 * 10 + q1], mse12 = s_fmse[q1 * 10 + q2], mse23 = s_fmse[q2 * 10 + q3];
         const double mse30 = s_wmse[q0 * 10 + q3];
         const double dotn = s_fnx[q0 * 10 + q1] * s_fnx[q1 * 10 + q2] + s_fny[q0 * 10 + q1] * s_fny[q1 * 10 + q2];
         if (!(mse01 > P.max_line_fit_mse) && !(mse12 > P.max_line_fit_mse) && !(fabs(dotn) > P.cos_critical_rad) &&
             !(mse23 > P.max_line_fit_mse) && !(mse30 > P.max_line_fit_mse)) {
           const double e = s_ferr[q0 * 10 + q1] + s_ferr[q1 * 10 + q2] + s_ferr[q2 * 10 + q3] + s_werr[q0 * 10 + q3];
-          if (e < best_err) { best_err = e; best_t = tid; }
+          if (e < best_err) { best_err = e; best_t = t; }
         }
       }
     }
@@ -353,77 +432,82 @@ __global__ __launch_bounds__(256) void k_fit_quads(const FrameDesc* __restrict__
     __syncthreads();
     if (tid == 0) {
       double be = sred_d[0]; int bt = sred_di[0];
-      for (int w = 1; w < 4; w++)
+#pragma unroll
+      for (int w = 1; w < NW; w++)
         if (sred_d[w] < be || (sred_d[w] == be && sred_di[w] < bt)) { be = sred_d[w]; bt = sred_di[w]; }
-      bool ok = (be != (double)HUGE_VALF) && (be / sz < P.max_line_fit_mse);
-      int indices[4] = {0, 0, 0, 0};
+      const bool ok = (be != (double)HUGE_VALF) && (be / sz < P.max_line_fit_mse);
+      s_ok = ok ? 1 : 0;
       if (ok) {
-        int c = 0;
-        bool found = false;
-        for (int m0 = 0; m0 < 7 && !found; m0++)
-          for (int m1 = m0 + 1; m1 < 8 && !found; m1++)
-            for (int m2 = m1 + 1; m2 < 9 && !found; m2++)
-              for (int m3 = m2 + 1; m3 < 10; m3++) {
-                if (c == bt) {
-                  indices[0] = s_maxidx[m0]; indices[1] = s_maxidx[m1]; indices[2] = s_maxidx[m2]; indices[3] = s_maxidx[m3];
-                  found = true;
-                  break;
-                }
-                c++;
-              }
+        const uint32_t cmb = s_combo[bt];
+        s_idx4[0] = s_maxidx[cmb & 15]; s_idx4[1] = s_maxidx[(cmb >> 4) & 15];
+        s_idx4[2] = s_maxidx[(cmb >> 8) & 15]; s_idx4[3] = s_maxidx[(cmb >> 12) & 15];
       }
-      QuadRec q;
-      double lines[4][4];
-      for (int i = 0; i < 4 && ok; i++) {
-        double ms;
-        fit_line_dev(lf, sz, indices[i], indices[(i + 1) & 3], lines[i], nullptr, &ms);
-        if (ms > P.max_line_fit_mse) ok = false;
-      }
-      for (int i = 0; i < 4 && ok; i++) {
-        const double A00 = lines[i][3], A01 = -lines[(i + 1) & 3][3];
-        const double A10 = -lines[i][2], A11 = lines[(i + 1) & 3][2];
-        const double B0 = -lines[i][0] + lines[(i + 1) & 3][0];
-        const double B1 = -lines[i][1] + lines[(i + 1) & 3][1];
-        const double det = A00 * A11 - A10 * A01;
-        if (fabs(det) < 0.001) { ok = false; break; }
-        const double W00 = A11 / det, W01 = -A01 / det;
-        const double L0 = W00 * B0 + W01 * B1;
-        q.p[i][0] = (float)(lines[i][0] + L0 * A00);
-        q.p[i][1] = (float)(lines[i][1] + L0 * A10);
-      }
-      if (ok) {
-        double area = 0, length[3], pp;
-        for (int i = 0; i < 3; i++) {
-          const int a = i, b = (i + 1) % 3;
-          const double ddx = (double)q.p[b][0] - (double)q.p[a][0], ddy = (double)q.p[b][1] - (double)q.p[a][1];
-          length[i] = __dsqrt_rn(ddx * ddx + ddy * ddy);
-        }
-        pp = (length[0] + length[1] + length[2]) / 2;
-        area += __dsqrt_rn(pp * (pp - length[0]) * (pp - length[1]) * (pp - length[2]));
-        const int idxs[4] = {2, 3, 0, 2};
-        for (int i = 0; i < 3; i++) {
-          const int a = idxs[i], b = idxs[i + 1];
-          const double ddx = (double)q.p[b][0] - (double)q.p[a][0], ddy = (double)q.p[b][1] - (double)q.p[a][1];
-          length[i] = __dsqrt_rn(ddx * ddx + ddy * ddy);
-        }
-        pp = (length[0] + length[1] + length[2]) / 2;
-        area += __dsqrt_rn(pp * (pp - length[0]) * (pp - length[1]) * (pp - length[2]));
+    }
+    __syncthreads();
+    if (!s_ok) continue;
+    // four final line fits (lanes 0..3), then four intersections (lanes 0..3)
+    if (tid < 4) {
+      double ms;
+      fit_line_dev(lf, sz, s_idx4[tid], s_idx4[(tid + 1) & 3], s_lines + tid * 4, nullptr, &ms);
+      s_lmse[tid] = ms;
+    }
+    __syncthreads();
+    if (tid < 4) {
+      const int i = tid, j = (tid + 1) & 3;
+      bool ok = !(s_lmse[0] > P.max_line_fit_mse) && !(s_lmse[1] > P.max_line_fit_mse) &&
+                !(s_lmse[2] > P.max_line_fit_mse) && !(s_lmse[3] > P.max_line_fit_mse);
+      const double A00 = s_lines[i * 4 + 3], A01 = -s_lines[j * 4 + 3];
+      const double A10 = -s_lines[i * 4 + 2], A11 = s_lines[j * 4 + 2];
+      const double B0 = -s_lines[i * 4 + 0] + s_lines[j * 4 + 0];
+      const double B1 = -s_lines[i * 4 + 1] + s_lines[j * 4 + 1];
+      const double det = A00 * A11 - A10 * A01;
+      if (fabs(det) < 0.001) ok = false;
+      const double W00 = A11 / det, W01 = -A01 / det;
+      const double L0 = W00 * B0 + W01 * B1;
+      s_corner[i][0] = (float)(s_lines[i * 4 + 0] + L0 * A00);
+      s_corner[i][1] = (float)(s_lines[i * 4 + 1] + L0 * A10);
+      if (!ok) s_ok = 0;
+    }
+    __syncthreads();
+    if (tid == 0 && s_ok) {
+      bool ok = true;
+      const double p00 = s_corner[0][0], p01 = s_corner[0][1], p10 = s_corner[1][0], p11 = s_corner[1][1];
+      const double p20 = s_corner[2][0], p21 = s_corner[2][1], p30 = s_corner[3][0], p31 = s_corner[3][1];
+      {
+        // triangles (0,1,2) and (2,3,0), Heron
+        const double l0 = __dsqrt_rn((p10 - p00) * (p10 - p00) + (p11 - p01) * (p11 - p01));
+        const double l1 = __dsqrt_rn((p20 - p10) * (p20 - p10) + (p21 - p11) * (p21 - p11));
+        const double l2 = __dsqrt_rn((p00 - p20) * (p00 - p20) + (p01 - p21) * (p01 - p21));
+        const double pp = (l0 + l1 + l2) / 2;
+        double area = 0;
+        area += __dsqrt_rn(pp * (pp - l0) * (pp - l1) * (pp - l2));
+        const double k0 = __dsqrt_rn((p30 - p20) * (p30 - p20) + (p31 - p21) * (p31 - p21));
+        const double k1 = __dsqrt_rn((p00 - p30) * (p00 - p30) + (p01 - p31) * (p01 - p31));
+        const double k2 = __dsqrt_rn((p20 - p00) * (p20 - p00) + (p21 - p01) * (p21 - p01));
+        const double qq = (k0 + k1 + k2) / 2;
+        area += __dsqrt_rn(qq * (qq - k0) * (qq - k1) * (qq - k2));
         if (area < 0.95 * P.min_tag_width * P.min_tag_width) ok = false;
       }
-      for (int i = 0; i < 4 && ok; i++) {
+      const double px[4] = {p00, p10, p20, p30}, py[4] = {p01, p11, p21, p31};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
         const int i0 = i, i1 = (i + 1) & 3, i2 = (i + 2) & 3;
-        const double dx1 = (double)q.p[i1][0] - (double)q.p[i0][0], dy1 = (double)q.p[i1][1] - (double)q.p[i0][1];
-        const double dx2 = (double)q.p[i2][0] - (double)q.p[i1][0], dy2 = (double)q.p[i2][1] - (double)q.p[i1][1];
+        const double dx1 = px[i1] - px[i0], dy1 = py[i1] - py[i0];
+        const double dx2 = px[i2] - px[i1], dy2 = py[i2] - py[i1];
         const double cos_dtheta = (dx1 * dx2 + dy1 * dy2) / __dsqrt_rn((dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2));
         if ((cos_dtheta > P.cos_critical_rad || cos_dtheta < -P.cos_critical_rad) || dx1 * dy2 < dy1 * dx2) ok = false;
       }
       if (ok) {
-        if (P.decimate > 1) {
-          const double f = (double)(float)P.decimate;
-          for (int c = 0; c < 4; c++) {
-            q.p[c][0] = (float)(((double)q.p[c][0] - 0.5) * f + 0.5);
-            q.p[c][1] = (float)(((double)q.p[c][1] - 0.5) * f + 0.5);
+        QuadRec q;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          float fx = s_corner[c][0], fy = s_corner[c][1];
+          if (P.decimate > 1) {
+            const double f = (double)(float)P.decimate;
+            fx = (float)(((double)fx - 0.5) * f + 0.5);
+            fy = (float)(((double)fy - 0.5) * f + 0.5);
           }
+          q.p[c][0] = fx; q.p[c][1] = fy;
         }
         q.reversed_border = q_reversed;
         q.pad = 0;
@@ -433,5 +517,7 @@ __global__ __launch_bounds__(256) void k_fit_quads(const FrameDesc* __restrict__
         else atomicOr(&counters[frame].flags, 0x8u);
       }
     }
+    FQ_TICK(7)
   }
+#undef FQ_TICK
 }

@@ -1,0 +1,17 @@
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from isaac_ros_apriltag_amd import synth
+from isaac_ros_apriltag_amd.detector import AprilTagDetector
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+frames = np.stack([synth.scene_c2(seed=1234 + i)[0] for i in range(4)])
+t = torch.from_numpy(frames).cuda().repeat(B // 4, 1, 1).contiguous()
+det = AprilTagDetector(1920, 1080, max_batch=B)
+det.detect_batch_ex(t)
+det.set_profiling(True)
+det.detect_batch_ex(t)
+print({k: round(v, 3) for k, v in det.stage_ms().items()})
+p = det.debug(0, 8).view(np.uint64)[:8].astype(np.float64)
+names = ["loop/sync", "bbox+dot", "keys+sort", "terms", "prefix", "errs+smooth", "maxima+select", "pairs+combos+final"]
+for n, v in zip(names, p): print("%-22s %6.1f%%  %.3e cycles" % (n, 100 * v / p.sum(), v))
+det.close()
