@@ -168,6 +168,12 @@ int amdAprilTagsGetFrameFlags(amdAprilTagsHandle handle, uint32_t* flags, uint32
 int amdAprilTagsConvertToMono8(const void* src_dev, size_t src_pitch, const char* encoding, uint32_t width,
                                uint32_t height, uint8_t* dst_dev, size_t dst_pitch, amdAprilTagsStream stream);
 
+/* Device-memory helpers for hosts that do not link the HIP runtime themselves (the node shell copies
+ * sensor_msgs/Image payloads with these).  Plain hipMalloc / hipFree / hipMemcpyAsync + sync. */
+int amdAprilTagsDeviceAlloc(void** dev_ptr, size_t bytes);
+int amdAprilTagsDeviceFree(void* dev_ptr);
+int amdAprilTagsCopyToDevice(void* dst_dev, const void* src_host, size_t bytes, amdAprilTagsStream stream);
+
 /* Registers a tag family as data (row-major codes, MSB = top-left data cell) in a custom slot. */
 int amdAprilTagsRegisterFamily(amdAprilTagsFamily slot, const char* name, uint32_t data_bits_per_side,
                                const uint64_t* codes, uint32_t ncodes);

@@ -58,7 +58,8 @@ EXPORTS = ["amdAprilTagsDefaultConfig", "amdCreateAprilTagsDetector", "amdCreate
            "amdAprilTagsGetFrameFlags", "amdAprilTagsConvertToMono8", "amdAprilTagsRegisterFamily",
            "amdAprilTagsFamilyInfo", "amdAprilTagsFamilyFromName", "amdAprilTagsStageName",
            "amdAprilTagsSetProfiling", "amdAprilTagsGetStageMs", "amdAprilTagsThresholdOnly",
-           "amdAprilTagsDebugCopy", "amdAprilTagsDebugMath"]
+           "amdAprilTagsDebugCopy", "amdAprilTagsDebugMath", "amdAprilTagsDeviceAlloc", "amdAprilTagsDeviceFree",
+           "amdAprilTagsCopyToDevice"]
 
 _lib = None
 
@@ -97,6 +98,9 @@ def lib():
     L.amdAprilTagsGetStageMs.argtypes = [H, C.POINTER(C.c_float)]
     L.amdAprilTagsThresholdOnly.argtypes = [H, C.c_uint32, C.POINTER(ImageInput), H]
     L.amdAprilTagsDebugCopy.argtypes = [H, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.amdAprilTagsDeviceAlloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    L.amdAprilTagsDeviceFree.argtypes = [C.c_void_p]
+    L.amdAprilTagsCopyToDevice.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, H]
     L.amdAprilTagsDebugMath.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     for name in EXPORTS:
         fn = getattr(L, name)

@@ -621,6 +621,21 @@ int amdAprilTagsConvertToMono8(const void* src_dev, size_t src_pitch, const char
   return AMDAT_SUCCESS;
 }
 
+int amdAprilTagsDeviceAlloc(void** dev_ptr, size_t bytes) {
+  if (!dev_ptr || bytes == 0) return AMDAT_INVALID_ARGUMENT;
+  return hipMalloc(dev_ptr, bytes) == hipSuccess ? AMDAT_SUCCESS : AMDAT_OUT_OF_MEMORY;
+}
+int amdAprilTagsDeviceFree(void* dev_ptr) {
+  if (!dev_ptr) return AMDAT_INVALID_ARGUMENT;
+  return hipFree(dev_ptr) == hipSuccess ? AMDAT_SUCCESS : AMDAT_HIP_ERROR;
+}
+int amdAprilTagsCopyToDevice(void* dst_dev, const void* src_host, size_t bytes, amdAprilTagsStream stream) {
+  if (!dst_dev || !src_host) return AMDAT_INVALID_ARGUMENT;
+  HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return AMDAT_SUCCESS;
+}
+
 int amdAprilTagsDebugCopy(amdAprilTagsHandle handle, uint32_t frame, amdAprilTagsDebugBuffer what, void* host_dst,
                           size_t capacity, size_t* bytes) {
   if (!handle || !bytes || frame >= handle->last_n) return AMDAT_INVALID_ARGUMENT;

@@ -1,0 +1,374 @@
+// node_shell.cpp -- implementation of include/apriltag_node_shell.hpp: the reference node's host logic
+// (src/apriltag_node.cpp:389-623) over the C ABI of libapriltag_amd.so.  Built into libapriltag_node.so;
+// the detector library is bound at run time (dlopen next to this file's .so), so this translation unit
+// needs neither HIP headers nor ROS.
+#include "../../include/apriltag_node_shell.hpp"
+
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+
+#include "../../include/apriltag_amd.h"
+
+namespace amd {
+namespace isaac_ros {
+namespace apriltag {
+
+namespace {
+
+// Entry points of libapriltag_amd.so used by the shell.
+struct DetectorApi {
+  void* lib = nullptr;
+  decltype(&amdCreateAprilTagsDetectorEx) create_ex = nullptr;
+  decltype(&amdAprilTagsDefaultConfig) default_config = nullptr;
+  decltype(&amdAprilTagsDetect) detect = nullptr;
+  decltype(&amdAprilTagsDestroy) destroy = nullptr;
+  decltype(&amdAprilTagsFamilyFromName) family_from_name = nullptr;
+  decltype(&amdAprilTagsConvertToMono8) to_mono8 = nullptr;
+  decltype(&amdAprilTagsDeviceAlloc) dev_alloc = nullptr;
+  decltype(&amdAprilTagsDeviceFree) dev_free = nullptr;
+  decltype(&amdAprilTagsCopyToDevice) copy_to_device = nullptr;
+};
+
+DetectorApi& api() {
+  static DetectorApi a;
+  if (a.lib) return a;
+  Dl_info info;
+  std::string path = "libapriltag_amd.so";
+  if (dladdr(reinterpret_cast<void*>(&api), &info) && info.dli_fname) {
+    std::string self(info.dli_fname);
+    const size_t slash = self.find_last_of('/');
+    if (slash != std::string::npos) path = self.substr(0, slash + 1) + "libapriltag_amd.so";
+  }
+  a.lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!a.lib) throw std::runtime_error(std::string("cannot load libapriltag_amd.so: ") + dlerror());
+#define BIND(field, name)                                                        \
+  a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, name));             \
+  if (!a.field) throw std::runtime_error(std::string("missing symbol ") + name);
+  BIND(create_ex, "amdCreateAprilTagsDetectorEx")
+  BIND(default_config, "amdAprilTagsDefaultConfig")
+  BIND(detect, "amdAprilTagsDetect")
+  BIND(destroy, "amdAprilTagsDestroy")
+  BIND(family_from_name, "amdAprilTagsFamilyFromName")
+  BIND(to_mono8, "amdAprilTagsConvertToMono8")
+  BIND(dev_alloc, "amdAprilTagsDeviceAlloc")
+  BIND(dev_free, "amdAprilTagsDeviceFree")
+  BIND(copy_to_device, "amdAprilTagsCopyToDevice")
+#undef BIND
+  return a;
+}
+
+// Family strings the reference accepts as parameter values (src/apriltag_node.cpp:47-58).
+const char* const kKnownFamilyStrings[] = {"tag36h11", "tag16h5", "tag25h9", "tag36h10", "circle21h7",
+                                           "circle49h12", "custom48h12", "standard41h12", "standard52h13"};
+
+// Encodings the node's input conversion accepts (src/apriltag_node.cpp:76-82).
+int bytes_per_pixel(const std::string& enc) {
+  if (enc == "mono8") return 1;
+  if (enc == "rgb8" || enc == "bgr8") return 3;
+  if (enc == "rgba8" || enc == "bgra8") return 4;
+  return 0;
+}
+
+bool selects_gpu_backend(const std::string& backends) {
+  return backends == "CUDA" || backends == "HIP" || backends == "GPU";
+}
+
+// Rotation matrix (column-major 3x3 float, as cuAprilTagsID_t::orientation) -> quaternion, the
+// construction Eigen::Quaternion<float>(matrix) performs in ToTransformMsg (src/apriltag_node.cpp:409-427).
+Quaternion quaternion_from_colmajor(const float* o) {
+  auto m = [&](int r, int c) { return o[c * 3 + r]; };
+  float q[4];  // x y z w
+  float t = m(0, 0) + m(1, 1) + m(2, 2);
+  if (t > 0.0f) {
+    t = std::sqrt(t + 1.0f);
+    q[3] = 0.5f * t;
+    t = 0.5f / t;
+    q[0] = (m(2, 1) - m(1, 2)) * t;
+    q[1] = (m(0, 2) - m(2, 0)) * t;
+    q[2] = (m(1, 0) - m(0, 1)) * t;
+  } else {
+    int i = 0;
+    if (m(1, 1) > m(0, 0)) i = 1;
+    if (m(2, 2) > m(i, i)) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(m(i, i) - m(j, j) - m(k, k) + 1.0f);
+    q[i] = 0.5f * t;
+    t = 0.5f / t;
+    q[3] = (m(k, j) - m(j, k)) * t;
+    q[j] = (m(j, i) + m(i, j)) * t;
+    q[k] = (m(k, i) + m(i, k)) * t;
+  }
+  Quaternion out;
+  out.x = q[0]; out.y = q[1]; out.z = q[2]; out.w = q[3];
+  return out;
+}
+
+}  // namespace
+
+struct AprilTagNode::Impl {
+  NodeOptions opt;
+  DetectionsCallback on_detections;
+  TransformsCallback on_transforms;
+  // lazily created on the first frame (src/apriltag_node.cpp:618-620)
+  bool initialized = false;
+  amdAprilTagsHandle detector = nullptr;
+  int family_enum = -1;
+  uint32_t width = 0, height = 0;
+  void* d_input = nullptr;   // staging for host images
+  size_t d_input_bytes = 0;
+  uint8_t* d_mono = nullptr; // converted mono8 frame
+  size_t d_mono_pitch = 0;
+
+  std::set<std::string> SupportedTagFamilies() const {
+    // families this backend can decode = those with a code table in the library
+    std::set<std::string> out;
+    for (const char* f : kKnownFamilyStrings)
+      if (api().family_from_name(f) >= 0) out.insert(f);
+    // user-registered tables
+    if (api().family_from_name(opt.tag_family.c_str()) >= 0) out.insert(opt.tag_family);
+    return out;
+  }
+
+  void Initialize(const Image& image, const CameraInfo& info) {
+    initialized = true;
+    // intrinsics from K, double -> float as the reference does (src/apriltag_node.cpp:442-447)
+    amdAprilTagsConfig_t cfg;
+    api().default_config(&cfg, info.width, info.height);
+    cfg.tile_size = opt.tile_size;
+    cfg.decimate = opt.decimate;
+    cfg.num_families = 1;
+    cfg.families[0] = static_cast<amdAprilTagsFamily>(family_enum);
+    cfg.intrinsics.fx = static_cast<float>(info.k[0]);
+    cfg.intrinsics.fy = static_cast<float>(info.k[4]);
+    cfg.intrinsics.cx = static_cast<float>(info.k[2]);
+    cfg.intrinsics.cy = static_cast<float>(info.k[5]);
+    cfg.tag_size = static_cast<float>(opt.size);
+    cfg.max_batch = 1;
+    const int error = api().create_ex(&detector, &cfg);
+    if (error != 0) {
+      // same text as src/apriltag_node.cpp:453-457 with the library name replaced
+      throw std::runtime_error("Failed to create AprilTags detector (error code " + std::to_string(error) + ")");
+    }
+    width = info.width;
+    height = info.height;
+    d_mono_pitch = (static_cast<size_t>(width) + 63) & ~static_cast<size_t>(63);
+    void* p = nullptr;
+    if (api().dev_alloc(&p, d_mono_pitch * height) != 0) throw std::runtime_error("device allocation failed");
+    d_mono = static_cast<uint8_t*>(p);
+    (void)image;
+  }
+
+  void OnCameraFrame(const Image& image, const CameraInfo& info) {
+    const int bpp = bytes_per_pixel(image.encoding);
+    if (bpp == 0) {
+      std::fprintf(stderr, "[apriltag_node] Unsupported image encoding: %s\n", image.encoding.c_str());
+      throw std::runtime_error("AprilTags detector only supports 'mono8', 'rgb8', 'bgr8', 'rgba8' or 'bgra8' image input");
+    }
+    const uint8_t* dev_src = image.data;
+    if (!image.is_device) {
+      const size_t bytes = static_cast<size_t>(image.step) * image.height;
+      if (bytes > d_input_bytes) {
+        if (d_input) api().dev_free(d_input);
+        d_input = nullptr;
+        if (api().dev_alloc(&d_input, bytes) != 0) throw std::runtime_error("device allocation failed");
+        d_input_bytes = bytes;
+      }
+      if (api().copy_to_device(d_input, image.data, bytes, nullptr) != 0) {
+        std::fprintf(stderr, "[apriltag_node] host-to-device copy failed\n");
+        return;
+      }
+      dev_src = static_cast<const uint8_t*>(d_input);
+    }
+    amdAprilTagsImageInput_t input;
+    input.width = image.width;
+    input.height = image.height;
+    if (bpp == 1) {
+      input.dev_ptr = dev_src;
+      input.pitch = image.step;
+    } else {
+      if (api().to_mono8(dev_src, image.step, image.encoding.c_str(), image.width, image.height, d_mono, d_mono_pitch, nullptr) != 0) {
+        std::fprintf(stderr, "[apriltag_node] colour conversion failed\n");
+        return;
+      }
+      input.dev_ptr = d_mono;
+      input.pitch = d_mono_pitch;
+    }
+    uint32_t num_detections = 0;
+    std::vector<amdAprilTagsID_t> tags(static_cast<size_t>(opt.max_tags));
+    const int error = api().detect(detector, &input, tags.data(), &num_detections, static_cast<uint32_t>(opt.max_tags), nullptr);
+    if (error != 0) {
+      // the reference logs and drops the frame (src/apriltag_node.cpp:494-497)
+      std::fprintf(stderr, "[apriltag_node] Failed to run AprilTags detector (error code %d)\n", error);
+      return;
+    }
+    AprilTagDetectionArray msg;
+    msg.header = info.header;  // camera_info header, not the image header (src/apriltag_node.cpp:501)
+    std::vector<TransformStamped> tfs;
+    for (uint32_t i = 0; i < num_detections; i++) {
+      const amdAprilTagsID_t& d = tags[i];
+      AprilTagDetection det;
+      det.family = opt.tag_family;
+      det.id = d.id;
+      for (int c = 0; c < 4; c++) {
+        det.corners[c].x = d.corners[c].x;
+        det.corners[c].y = d.corners[c].y;
+      }
+      // The reference intersects the diagonals in slope/intercept form, which divides by zero when a
+      // diagonal is vertical (src/apriltag_node.cpp:519-530); the library reports H(0,0) directly.
+      det.center.x = d.center.x;
+      det.center.y = d.center.y;
+      TransformStamped tf;
+      tf.header = info.header;
+      tf.child_frame_id = opt.tag_family + ":" + std::to_string(d.id);
+      tf.transform.translation.x = d.translation[0];
+      tf.transform.translation.y = d.translation[1];
+      tf.transform.translation.z = d.translation[2];
+      tf.transform.rotation = quaternion_from_colmajor(d.orientation);
+      tfs.push_back(tf);
+      det.pose.pose.pose.position.x = tf.transform.translation.x;
+      det.pose.pose.pose.position.y = tf.transform.translation.y;
+      det.pose.pose.pose.position.z = tf.transform.translation.z;
+      det.pose.pose.pose.orientation = tf.transform.rotation;
+      msg.detections.push_back(det);
+    }
+    if (on_detections) on_detections(msg);
+    if (on_transforms) on_transforms(tfs);
+  }
+};
+
+AprilTagNode::AprilTagNode(const NodeOptions& options) : impl_(new Impl()) {
+  impl_->opt = options;
+  // Backend selection (src/apriltag_node.cpp:575-582): this build has exactly one implementation, the
+  // HIP detector; CPU / PVA backends of VPI do not exist here and support no family.
+  std::set<std::string> supported;
+  if (selects_gpu_backend(options.backends)) supported = impl_->SupportedTagFamilies();
+  if (supported.find(options.tag_family) == supported.end()) {
+    std::ostringstream os;
+    os << "Tag family not supported by specified backend: '" << options.tag_family << "'" << std::endl;
+    os << "'tag_family' parameter must be one of:" << std::endl;
+    for (const auto& f : supported) os << f << std::endl;
+    std::fprintf(stderr, "[apriltag_node] FATAL: Tag family not supported by specified backend: '%s'\n", options.tag_family.c_str());
+    throw std::runtime_error(os.str());
+  }
+  impl_->family_enum = api().family_from_name(options.tag_family.c_str());
+}
+
+AprilTagNode::~AprilTagNode() {
+  if (impl_ && impl_->initialized) {
+    if (impl_->detector) api().destroy(impl_->detector);
+    if (impl_->d_input) api().dev_free(impl_->d_input);
+    if (impl_->d_mono) api().dev_free(impl_->d_mono);
+  }
+}
+
+void AprilTagNode::set_detections_callback(DetectionsCallback cb) { impl_->on_detections = std::move(cb); }
+void AprilTagNode::set_transforms_callback(TransformsCallback cb) { impl_->on_transforms = std::move(cb); }
+const NodeOptions& AprilTagNode::options() const { return impl_->opt; }
+bool AprilTagNode::initialized() const { return impl_->initialized; }
+
+bool AprilTagNode::CameraImageCallback(const Image& image, const CameraInfo& camera_info) {
+  if (image.header.stamp.sec != camera_info.header.stamp.sec || image.header.stamp.nanosec != camera_info.header.stamp.nanosec)
+    return false;  // ExactTime synchroniser would not fire
+  if (!impl_->initialized) impl_->Initialize(image, camera_info);
+  impl_->OnCameraFrame(image, camera_info);
+  return true;
+}
+
+}  // namespace apriltag
+}  // namespace isaac_ros
+}  // namespace amd
+
+// ---- flat C view of the shell for the Python test harness (tests/test_node_shell_*.py) ---------------
+using amd::isaac_ros::apriltag::AprilTagDetectionArray;
+using amd::isaac_ros::apriltag::AprilTagNode;
+using amd::isaac_ros::apriltag::CameraInfo;
+using amd::isaac_ros::apriltag::Image;
+using amd::isaac_ros::apriltag::NodeOptions;
+using amd::isaac_ros::apriltag::TransformStamped;
+
+struct NodeShellHarness {
+  std::unique_ptr<AprilTagNode> node;
+  AprilTagDetectionArray last;
+  std::vector<TransformStamped> last_tf;
+  int publishes = 0;
+};
+
+struct NodeShellDetection {
+  int32_t id;
+  char family[32];
+  double center[2];
+  double corners[4][2];
+  double position[3];
+  double orientation_xyzw[4];
+  char child_frame_id[48];
+};
+
+extern "C" {
+
+// Returns nullptr and fills err on a constructor exception (mirrors test/apriltag_node_test.cpp).
+NodeShellHarness* node_shell_create(int max_tags, double size, int tile_size, const char* tag_family, const char* backends,
+                                    int decimate, char* err, size_t err_len) {
+  try {
+    NodeOptions o;
+    o.max_tags = max_tags; o.size = size; o.tile_size = static_cast<uint16_t>(tile_size);
+    o.tag_family = tag_family; o.backends = backends; o.decimate = static_cast<uint32_t>(decimate);
+    auto* h = new NodeShellHarness();
+    h->node.reset(new AprilTagNode(o));
+    h->node->set_detections_callback([h](const AprilTagDetectionArray& m) { h->last = m; h->publishes++; });
+    h->node->set_transforms_callback([h](const std::vector<TransformStamped>& t) { h->last_tf = t; });
+    return h;
+  } catch (const std::exception& e) {
+    if (err && err_len) { std::strncpy(err, e.what(), err_len - 1); err[err_len - 1] = 0; }
+    return nullptr;
+  }
+}
+
+void node_shell_destroy(NodeShellHarness* h) { delete h; }
+
+// Feeds one image + camera_info pair.  Returns the number of detections published, -1 if the stamps
+// differ (no callback), -2 on an exception (message in err).
+int node_shell_on_frame(NodeShellHarness* h, const uint8_t* data, int is_device, const char* encoding, uint32_t width,
+                        uint32_t height, uint32_t step, const double* k9, const char* frame_id, int32_t sec, uint32_t nanosec,
+                        int32_t info_sec, uint32_t info_nanosec, NodeShellDetection* out, int max_out, char* out_frame_id,
+                        size_t frame_id_len, char* err, size_t err_len) {
+  try {
+    Image img;
+    img.header.frame_id = "image_frame"; img.header.stamp.sec = sec; img.header.stamp.nanosec = nanosec;
+    img.width = width; img.height = height; img.step = step; img.encoding = encoding; img.data = data; img.is_device = is_device != 0;
+    CameraInfo info;
+    info.header.frame_id = frame_id; info.header.stamp.sec = info_sec; info.header.stamp.nanosec = info_nanosec;
+    info.width = width; info.height = height;
+    for (int i = 0; i < 9; i++) info.k[i] = k9[i];
+    const int before = h->publishes;
+    if (!h->node->CameraImageCallback(img, info)) return -1;
+    if (h->publishes == before) return 0;  // frame dropped
+    const auto& m = h->last;
+    if (out_frame_id && frame_id_len) { std::strncpy(out_frame_id, m.header.frame_id.c_str(), frame_id_len - 1); out_frame_id[frame_id_len - 1] = 0; }
+    int n = static_cast<int>(m.detections.size());
+    for (int i = 0; i < n && i < max_out; i++) {
+      const auto& d = m.detections[i];
+      NodeShellDetection& o = out[i];
+      std::memset(&o, 0, sizeof(o));
+      o.id = d.id;
+      std::strncpy(o.family, d.family.c_str(), sizeof(o.family) - 1);
+      o.center[0] = d.center.x; o.center[1] = d.center.y;
+      for (int c = 0; c < 4; c++) { o.corners[c][0] = d.corners[c].x; o.corners[c][1] = d.corners[c].y; }
+      o.position[0] = d.pose.pose.pose.position.x; o.position[1] = d.pose.pose.pose.position.y; o.position[2] = d.pose.pose.pose.position.z;
+      o.orientation_xyzw[0] = d.pose.pose.pose.orientation.x; o.orientation_xyzw[1] = d.pose.pose.pose.orientation.y;
+      o.orientation_xyzw[2] = d.pose.pose.pose.orientation.z; o.orientation_xyzw[3] = d.pose.pose.pose.orientation.w;
+      std::strncpy(o.child_frame_id, h->last_tf[i].child_frame_id.c_str(), sizeof(o.child_frame_id) - 1);
+    }
+    return n;
+  } catch (const std::exception& e) {
+    if (err && err_len) { std::strncpy(err, e.what(), err_len - 1); err[err_len - 1] = 0; }
+    return -2;
+  }
+}
+
+}  // extern "C"

@@ -223,3 +223,39 @@ def test_error_behaviour(built):
     assert small.frame_flags(1)[0] & 0x1
     small.close()
     det.close()
+
+
+def test_node_shell_pol_and_mono8(built):
+    """The reference's launch tests through the node shell: pol_test (bgr8 host image -> assertions of
+    isaac_ros_apriltag_pol_test.py:113-175), mono8_test (>= 1 detection), TF naming, header mapping,
+    ExactTime gating and the encoding error."""
+    from isaac_ros_apriltag_amd import node as nd
+    img, K, _ = synth.scene_pol_golden()
+    bgr = np.ascontiguousarray(np.repeat(img[:, :, None], 3, axis=2))
+    K9 = [K[0, 0], 0, K[0, 2], 0, K[1, 1], K[1, 2], 0, 0, 1]
+    n = nd.AprilTagNode(max_tags=64, size=0.22, tile_size=4)
+    dets, frame_id = n.on_frame(bgr.ctypes.data, False, "bgr8", 1920, 1080, 1920 * 3, K9, frame_id="tf_camera")
+    assert frame_id == "tf_camera" and len(dets) >= 1
+    for d in dets:
+        assert d["id"] == 0 and d["family"] == "tag36h11" and d["child_frame_id"] == "tag36h11:0"
+        gold = [(1044.0, 665.0), (808.0, 665.0), (808.0, 429.0), (1044.0, 429.0)]
+        for c, g in zip(d["corners"], gold):
+            assert abs(c[0] - g[0]) <= 2 and abs(c[1] - g[1]) <= 2
+        assert abs(d["center"][0] - 926.0) <= 2 and abs(d["center"][1] - 547.0) <= 2
+        for v, g in zip(d["position"], (0.255342, 0.098358, 0.403961)):
+            assert abs(v - g) <= 0.01
+        x, y, z, w = d["orientation_xyzw"]
+        if z < 0:
+            x, y, z, w = -x, -y, -z, -w
+        assert abs(w) <= 0.01 and abs(x) <= 0.01 and abs(y) <= 0.01 and abs(z - 1.0) <= 0.01
+    # mono8 host image and device pointer
+    d2, _ = n.on_frame(img.ctypes.data, False, "mono8", 1920, 1080, 1920, K9)
+    assert len(d2) >= 1 and d2[0]["corners"] == dets[0]["corners"]
+    t = torch.from_numpy(img).cuda()
+    d3, _ = n.on_frame(t.data_ptr(), True, "mono8", 1920, 1080, 1920, K9)
+    assert d3[0]["corners"] == dets[0]["corners"]
+    # stamps differ -> the synchroniser does not fire
+    assert n.on_frame(img.ctypes.data, False, "mono8", 1920, 1080, 1920, K9, stamp=(1, 0), info_stamp=(1, 5)) == (None, None)
+    with pytest.raises(RuntimeError):
+        n.on_frame(img.ctypes.data, False, "yuv422", 1920, 1080, 1920 * 2, K9)
+    n.close()
