@@ -95,6 +95,7 @@ struct amdAprilTagsDetector_st {
   uint32_t* d_hcnt = nullptr;
   uint32_t* d_hoff = nullptr;
   uint2* d_stage = nullptr;
+  uint32_t* d_rank = nullptr;
   uint32_t* d_pts = nullptr;
   ClusterRec* d_clusters = nullptr;
   unsigned long long* d_keys = nullptr;
@@ -208,7 +209,7 @@ const char* amdAprilTagsStageName(uint32_t stage) { return stage < AMDAT_NUM_STA
 
 static void free_all(amdAprilTagsDetector_st* D) {
   hipFree(D->d_gray); hipFree(D->d_thr); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_hkeys);
-  hipFree(D->d_hcnt); hipFree(D->d_hoff); hipFree(D->d_stage); hipFree(D->d_pts); hipFree(D->d_clusters);
+  hipFree(D->d_hcnt); hipFree(D->d_hoff); hipFree(D->d_stage); hipFree(D->d_rank); hipFree(D->d_pts); hipFree(D->d_clusters);
   hipFree(D->d_keys); hipFree(D->d_lf); hipFree(D->d_errs_a); hipFree(D->d_errs_b); hipFree(D->d_quads);
   hipFree(D->d_fqprof);
   hipFree(D->d_dets); hipFree(D->d_out); hipFree(D->d_order); hipFree(D->d_counters); hipFree(D->d_frames);
@@ -293,6 +294,7 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   alloc((void**)&D->d_hcnt, B * (size_t)P.hcap * 4);
   alloc((void**)&D->d_hoff, B * (size_t)P.hcap * 4);
   alloc((void**)&D->d_stage, B * (size_t)P.pcap * 8);
+  alloc((void**)&D->d_rank, B * (size_t)P.pcap * 4);
   alloc((void**)&D->d_pts, B * (size_t)P.pcap * 4);
   alloc((void**)&D->d_clusters, B * (size_t)P.ccap * sizeof(ClusterRec));
   alloc((void**)&D->d_keys, B * (size_t)P.pcap * 8);
@@ -445,15 +447,15 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
                      D->d_csize, P);
   mark();
   hipLaunchKernelGGL(k_points, dim3((P.W + PT_TW - 1) / PT_TW, (P.H + PT_TH - 1) / PT_TH, n), dim3(256), 0, s, D->d_thr,
-                     D->d_label, D->d_csize, D->d_hkeys, D->d_hcnt, D->d_stage, D->d_counters, P);
+                     D->d_label, D->d_csize, D->d_hkeys, D->d_hcnt, D->d_stage, D->d_rank, D->d_counters, P);
   mark();
-  hipLaunchKernelGGL(k_cluster_select, dim3(P.hcap / 256, 1, n), dim3(256), 0, s, D->d_hkeys, D->d_hcnt, D->d_hoff,
+  hipLaunchKernelGGL(k_cluster_select, dim3((P.hcap + 1023) / 1024, 1, n), dim3(1024), 0, s, D->d_hkeys, D->d_hcnt, D->d_hoff,
                      D->d_clusters, D->d_counters, P);
   mark();
   {
     unsigned gx = (P.pcap + 255) / 256;
     if (gx > 2048) gx = 2048;
-    hipLaunchKernelGGL(k_scatter, dim3(gx, 1, n), dim3(256), 0, s, D->d_stage, D->d_hcnt, D->d_hoff, D->d_pts, D->d_counters, P);
+    hipLaunchKernelGGL(k_scatter, dim3(gx, 1, n), dim3(256), 0, s, D->d_stage, D->d_rank, D->d_hoff, D->d_pts, D->d_counters, P);
   }
   mark();
   if (prof && !D->d_fqprof) {

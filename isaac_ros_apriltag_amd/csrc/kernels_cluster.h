@@ -2,13 +2,14 @@
 // (inside cuAprilTagsDetect, reference src/apriltag_node.cpp:491-493).
 //
 //   k_points          every pixel of a 64x16 tile looks at its 4 forward neighbours (LDS halo tile of
-//                     {value, label-if-component>=25}); points are compacted with a block scan and one
-//                     atomic per block, and counted per component pair in a per-frame open-addressing
-//                     hash table (64-bit CAS on the key, 32-bit add on the count).
+//                     {value, label-if-component>=25}); points are counted per component pair in a
+//                     per-block LDS table, then once per (block, pair) in the per-frame open-addressing
+//                     hash table (64-bit CAS on the key, 32-bit add on the count, whose return value is
+//                     the block's base rank in the cluster); points are compacted with a block scan.
 //   k_cluster_select  keeps pairs with min_cluster_points <= count <= 3*(2W+2H), allocates their point
-//                     ranges with one atomic per wave (ballot/scan), emits the cluster list.
-//   k_scatter         moves the staged points into their cluster's range (order inside a cluster is
-//                     fixed later by the slope sort, so the atomics' arrival order never shows).
+//                     ranges with one atomic per 1024-slot block (ballot/scan), emits the cluster list.
+//   k_scatter         moves the staged points to range start + rank -- no atomics (order inside a
+//                     cluster is fixed later by the slope sort, so arrival order never shows).
 #pragma once
 #include "common.h"
 
@@ -36,14 +37,47 @@ __device__ __forceinline__ uint32_t hash_insert(unsigned long long* hkeys, uint3
   return AT_INVALID_SLOT;
 }
 
+#define PT_TB 256  // entries of the per-block component-pair table
+
+// per-block table in LDS: returns entry index or -1 when full
+__device__ __forceinline__ int ltab_insert(unsigned long long* tkey, uint64_t key) {
+  uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 56) & (PT_TB - 1);
+  for (int probe = 0; probe < PT_TB; probe++) {
+    const unsigned long long cur = *reinterpret_cast<volatile unsigned long long*>(&tkey[h]);
+    if (cur == key) return (int)h;
+    if (cur == AT_EMPTY_KEY) {
+      const unsigned long long old = atomicCAS(&tkey[h], AT_EMPTY_KEY, (unsigned long long)key);
+      if (old == AT_EMPTY_KEY || old == key) return (int)h;
+    }
+    h = (h + 1) & (PT_TB - 1);
+  }
+  return -1;
+}
+__device__ __forceinline__ int ltab_find(const unsigned long long* tkey, uint64_t key) {
+  uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 56) & (PT_TB - 1);
+  for (int probe = 0; probe < PT_TB; probe++) {
+    const unsigned long long cur = tkey[h];
+    if (cur == key) return (int)h;
+    if (cur == AT_EMPTY_KEY) return -1;
+    h = (h + 1) & (PT_TB - 1);
+  }
+  return -1;
+}
+
+// Boundary points of one 64x16 tile.  Points are counted per component pair in a per-block LDS table
+// first, so that the per-frame hash table sees ONE insert and ONE atomicAdd per (block, pair); the
+// value the add returns is the block's base rank inside the cluster, so every staged point carries its
+// final position (hoff[slot] + rank) and the scatter pass needs no atomics at all.
 __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_all, const uint32_t* __restrict__ label_all,
                                                 const uint32_t* __restrict__ csize_all, unsigned long long* __restrict__ hkeys_all,
                                                 uint32_t* __restrict__ hcnt_all, uint2* __restrict__ stage_all,
-                                                FrameCounters* __restrict__ counters, DetParams P) {
+                                                uint32_t* __restrict__ rank_all, FrameCounters* __restrict__ counters, DetParams P) {
   __shared__ uint8_t sv[PT_LH * PT_LW];
   __shared__ uint32_t slab[PT_LH * PT_LW];
   __shared__ uint32_t sscan[4];
   __shared__ uint32_t sbase;
+  __shared__ unsigned long long tkey[PT_TB];
+  __shared__ uint32_t tcnt[PT_TB], tslot[PT_TB], tbase[PT_TB];
   const int frame = blockIdx.z;
   const int W = P.W, H = P.H;
   const size_t npx = (size_t)W * H;
@@ -67,43 +101,68 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     sv[i] = (uint8_t)v;
     slab[i] = lab;
   }
+  tkey[tid] = AT_EMPTY_KEY;
+  tcnt[tid] = 0;
   __syncthreads();
 
   const int lx = tid & 63;
   const int gx = X0 + lx;
   const int DX[4] = {1, 0, -1, 1}, DY[4] = {0, 1, 1, 1};
-  // pass 1: count
+  // pass 1: count per pair in the block table
   uint32_t cnt = 0;
+  {
+    uint64_t last_key = AT_EMPTY_KEY;
+    int last_e = -1;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int ly = (tid >> 6) + 4 * k;
-    const int gy = Y0 + ly;
-    if (gx < 1 || gx > W - 2 || gy < 1 || gy > H - 2) continue;
-    const int c = ly * PT_LW + lx + 1;
-    const uint32_t r0 = slab[c];
-    if (r0 == AT_NO_LABEL) continue;
-    const int v0 = sv[c];
+    for (int k = 0; k < 4; k++) {
+      const int ly = (tid >> 6) + 4 * k;
+      const int gy = Y0 + ly;
+      if (gx < 1 || gx > W - 2 || gy < 1 || gy > H - 2) continue;
+      const int c = ly * PT_LW + lx + 1;
+      const uint32_t r0 = slab[c];
+      if (r0 == AT_NO_LABEL) continue;
+      const int v0 = sv[c];
 #pragma unroll
-    for (int d = 0; d < 4; d++) {
-      const int n = c + DY[d] * PT_LW + DX[d];
-      if (slab[n] != AT_NO_LABEL && v0 + (int)sv[n] == 255) cnt++;
+      for (int d = 0; d < 4; d++) {
+        const int n = c + DY[d] * PT_LW + DX[d];
+        const uint32_t r1 = slab[n];
+        if (r1 == AT_NO_LABEL || v0 + (int)sv[n] != 255) continue;
+        const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
+        if (key != last_key) { last_key = key; last_e = ltab_insert(tkey, key); }
+        if (last_e >= 0) atomicAdd(&tcnt[last_e], 1u);
+        cnt++;
+      }
     }
   }
   uint32_t total;
-  uint32_t off = block_excl_scan256(cnt, sscan, &total);
-  if (tid == 0) sbase = total ? atomicAdd(&counters[frame].npoints_raw, total) : 0;
-  __syncthreads();
+  const uint32_t off = block_excl_scan256(cnt, sscan, &total);  // contains __syncthreads
   if (total == 0) return;
+  unsigned long long* hkeys = hkeys_all + (size_t)frame * P.hcap;
+  uint32_t* hcnt = hcnt_all + (size_t)frame * P.hcap;
+  if (tid == 0) sbase = atomicAdd(&counters[frame].npoints_raw, total);
+  {
+    // one global insert + one global add per distinct pair of this block
+    const unsigned long long key = tkey[tid];
+    if (key != AT_EMPTY_KEY) {
+      const uint32_t slot = hash_insert(hkeys, P.hcap, P.hshift, key);
+      uint32_t base = 0;
+      if (slot != AT_INVALID_SLOT) base = atomicAdd(&hcnt[slot], tcnt[tid]);
+      else atomicOr(&counters[frame].flags, 0x2u);
+      tslot[tid] = slot;
+      tbase[tid] = base;
+      tcnt[tid] = 0;
+    }
+  }
+  __syncthreads();
   const uint32_t base = sbase;
   if (base + total > P.pcap) {
     if (tid == 0) atomicOr(&counters[frame].flags, 0x1u);
-    if (base >= P.pcap) return;
   }
-  // pass 2: emit
-  unsigned long long* hkeys = hkeys_all + (size_t)frame * P.hcap;
-  uint32_t* hcnt = hcnt_all + (size_t)frame * P.hcap;
+  // pass 2: emit {slot, point} and the rank inside the cluster
   uint2* stage = stage_all + (size_t)frame * P.pcap;
+  uint32_t* rank = rank_all + (size_t)frame * P.pcap;
   uint64_t last_key = AT_EMPTY_KEY;
+  int last_e = -1;
   uint32_t last_slot = AT_INVALID_SLOT;
   uint32_t pos = base + off;
 #pragma unroll
@@ -124,61 +183,75 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
       const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
       if (key != last_key) {
         last_key = key;
-        last_slot = hash_insert(hkeys, P.hcap, P.hshift, key);
-        if (last_slot == AT_INVALID_SLOT) atomicOr(&counters[frame].flags, 0x2u);
+        last_e = ltab_find(tkey, key);
+        if (last_e >= 0) last_slot = tslot[last_e];
+        else {  // block table was full: this pair goes straight to the frame table
+          last_slot = hash_insert(hkeys, P.hcap, P.hshift, key);
+          if (last_slot == AT_INVALID_SLOT) atomicOr(&counters[frame].flags, 0x2u);
+        }
+      }
+      uint32_t rk = 0;
+      if (last_slot != AT_INVALID_SLOT) {
+        if (last_e >= 0) rk = tbase[last_e] + atomicAdd(&tcnt[last_e], 1u);
+        else rk = atomicAdd(&hcnt[last_slot], 1u);
       }
       if (pos < P.pcap) {
-        if (last_slot != AT_INVALID_SLOT) atomicAdd(&hcnt[last_slot], 1u);
         stage[pos] = make_uint2(last_slot, pack_point(2 * gx + DX[d], 2 * gy + DY[d], DX[d] * (v1 - v0), DY[d] * (v1 - v0)));
+        rank[pos] = rk;
       }
       pos++;
     }
   }
 }
 
-// one thread per hash slot
-__global__ __launch_bounds__(256) void k_cluster_select(const unsigned long long* __restrict__ hkeys_all,
-                                                        const uint32_t* __restrict__ hcnt_all, uint32_t* __restrict__ hoff_all,
-                                                        ClusterRec* __restrict__ clusters_all,
-                                                        FrameCounters* __restrict__ counters, DetParams P) {
+// one thread per hash slot; 1024-thread blocks so that the two allocation counters see one atomic each
+// per block
+__global__ __launch_bounds__(1024) void k_cluster_select(const unsigned long long* __restrict__ hkeys_all,
+                                                         const uint32_t* __restrict__ hcnt_all, uint32_t* __restrict__ hoff_all,
+                                                         ClusterRec* __restrict__ clusters_all,
+                                                         FrameCounters* __restrict__ counters, DetParams P) {
+  __shared__ uint32_t wsum[16], wcnt[16];
+  __shared__ uint32_t s_pbase, s_cbase;
   const int frame = blockIdx.z;
-  const uint32_t slot = blockIdx.x * 256 + threadIdx.x;  // hcap is a multiple of 256
-  const size_t hi = (size_t)frame * P.hcap + slot;
-  const unsigned long long key = hkeys_all[hi];
-  const uint32_t c = hcnt_all[hi];
-  const bool keep = key != AT_EMPTY_KEY && (int)c >= P.min_cluster_points && (int)c <= P.max_cluster_points;
+  const uint32_t slot = blockIdx.x * 1024 + threadIdx.x;
+  const bool in_range = slot < P.hcap;
+  const size_t hi = (size_t)frame * P.hcap + (in_range ? slot : 0);
+  const unsigned long long key = in_range ? hkeys_all[hi] : AT_EMPTY_KEY;
+  const uint32_t c = in_range ? hcnt_all[hi] : 0;
+  // a frame whose point staging overflowed has pair counts that exceed what was staged: it yields no
+  // clusters at all (the overflow bit is reported), never an out-of-range range
+  const bool frame_ok = (counters[frame].flags & 0x1u) == 0;
+  const bool keep = frame_ok && key != AT_EMPTY_KEY && (int)c >= P.min_cluster_points && (int)c <= P.max_cluster_points;
   const unsigned long long mask = __ballot(keep);
+  const uint32_t inc = wave_incl_scan(keep ? c : 0u);
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  if (lane == 63) { wsum[wv] = inc; wcnt[wv] = (uint32_t)__popcll(mask); }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t ps = 0, cs = 0;
+    for (int w = 0; w < 16; w++) { const uint32_t a = wsum[w], b = wcnt[w]; wsum[w] = ps; wcnt[w] = cs; ps += a; cs += b; }
+    s_pbase = ps ? atomicAdd(&counters[frame].npoints_kept, ps) : 0;
+    s_cbase = cs ? atomicAdd(&counters[frame].nclusters, cs) : 0;
+  }
+  __syncthreads();
   uint32_t off = AT_INVALID_SLOT;
-  if (mask) {  // wave-uniform
-    const uint32_t inc = wave_incl_scan(keep ? c : 0u);
-    const int lane = lane_id();
-    const uint32_t wave_total = __shfl(inc, 63, 64);
-    const uint32_t nkeep = (uint32_t)__popcll(mask);
-    uint32_t pbase = 0, cbase = 0;
-    if (lane == 0) {
-      pbase = atomicAdd(&counters[frame].npoints_kept, wave_total);
-      cbase = atomicAdd(&counters[frame].nclusters, nkeep);
-    }
-    pbase = __shfl(pbase, 0, 64);
-    cbase = __shfl(cbase, 0, 64);
-    if (keep) {
-      const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-      const uint32_t ci = cbase + rank;
-      if (ci < P.ccap) {
-        off = pbase + inc - c;
-        ClusterRec rec;
-        rec.key = key; rec.start = off; rec.count = c;
-        clusters_all[(size_t)frame * P.ccap + ci] = rec;
-      } else {
-        atomicOr(&counters[frame].flags, 0x4u);
-      }
+  if (keep) {
+    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    const uint32_t ci = s_cbase + wcnt[wv] + rank;
+    if (ci < P.ccap) {
+      off = s_pbase + wsum[wv] + inc - c;
+      ClusterRec rec;
+      rec.key = key; rec.start = off; rec.count = c;
+      clusters_all[(size_t)frame * P.ccap + ci] = rec;
+    } else {
+      atomicOr(&counters[frame].flags, 0x4u);
     }
   }
-  hoff_all[hi] = off;
+  if (in_range) hoff_all[hi] = off;
 }
 
-// one thread per staged point
-__global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ stage_all, uint32_t* __restrict__ hcnt_all,
+// one thread per staged point: final position = cluster range start + rank, no atomics
+__global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ stage_all, const uint32_t* __restrict__ rank_all,
                                                  const uint32_t* __restrict__ hoff_all, uint32_t* __restrict__ pts_all,
                                                  const FrameCounters* __restrict__ counters, DetParams P) {
   const int frame = blockIdx.z;
@@ -187,10 +260,8 @@ __global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ stage
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const uint2 rec = stage_all[(size_t)frame * P.pcap + i];
     if (rec.x == AT_INVALID_SLOT) continue;
-    const size_t hi = (size_t)frame * P.hcap + rec.x;
-    const uint32_t off = hoff_all[hi];
+    const uint32_t off = hoff_all[(size_t)frame * P.hcap + rec.x];
     if (off == AT_INVALID_SLOT) continue;
-    const uint32_t k = atomicSub(&hcnt_all[hi], 1u) - 1u;
-    pts_all[(size_t)frame * P.pcap + off + k] = rec.y;
+    pts_all[(size_t)frame * P.pcap + off + rank_all[(size_t)frame * P.pcap + i]] = rec.y;
   }
 }
