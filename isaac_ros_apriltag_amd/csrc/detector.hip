@@ -459,9 +459,9 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
   }
   mark();
   if (prof && !D->d_fqprof) {
-    if (hipMalloc((void**)&D->d_fqprof, 16 * 8) != hipSuccess) D->d_fqprof = nullptr;
+    if (hipMalloc((void**)&D->d_fqprof, 32 * 8) != hipSuccess) D->d_fqprof = nullptr;
   }
-  if (D->d_fqprof) HIP_TRY(hipMemsetAsync(D->d_fqprof, 0, 16 * 8, s));
+  if (D->d_fqprof) HIP_TRY(hipMemsetAsync(D->d_fqprof, 0, 32 * 8, s));
   {
     // four size classes: one wave per small cluster, bigger workgroups and LDS key arrays above
     struct FqClass { int nt, cap, lo, hi; unsigned gx; };
@@ -481,7 +481,7 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
       const dim3 grid(cls[c].gx, n);
       const size_t lds = lds_bytes(cls[c]);
 #define FQ_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_keys, D->d_lf, D->d_errs_a, D->d_errs_b, D->d_quads, \
-                D->d_counters, D->d_fqprof, cls[c].cap, cls[c].lo, cls[c].hi, P
+                D->d_counters, (D->d_fqprof ? D->d_fqprof + 8 * c : nullptr), cls[c].cap, cls[c].lo, cls[c].hi, P
       if (cls[c].nt == 64) hipLaunchKernelGGL(k_fit_quads<64>, grid, dim3(64), lds, s, FQ_ARGS);
       else if (cls[c].nt == 256) hipLaunchKernelGGL(k_fit_quads<256>, grid, dim3(256), lds, s, FQ_ARGS);
       else hipLaunchKernelGGL(k_fit_quads<512>, grid, dim3(512), lds, s, FQ_ARGS);
@@ -680,7 +680,7 @@ int amdAprilTagsDebugCopy(amdAprilTagsHandle handle, uint32_t frame, amdAprilTag
       break;
     case AMDAT_DBG_FQPROF:
       if (!handle->d_fqprof) { *bytes = 0; return AMDAT_SUCCESS; }
-      src = handle->d_fqprof; sz = 16 * 8;
+      src = handle->d_fqprof; sz = 32 * 8;
       break;
     case AMDAT_DBG_COUNTS: {
       uint32_t c[8] = {fc.npoints_raw, fc.nclusters, fc.npoints_kept, fc.nquads, fc.ndets, fc.flags, (uint32_t)P.W, (uint32_t)P.H};

@@ -95,24 +95,26 @@ __device__ __forceinline__ void fit_line_dev(const double* lf, int sz, int i0, i
 
 template <int NT, typename KeyPtr>
 __device__ __forceinline__ void bitonic_sort_block(KeyPtr A, int n) {
-  // all-ascending bitonic network; indices >= n act as +infinity and are never touched
-  int npow = 1;
-  while (npow < n) npow <<= 1;
-  const int half = npow >> 1;
-  for (int k = 2; k <= npow; k <<= 1) {
-    const int hk = k >> 1;
+  // all-ascending bitonic network; indices >= n act as +infinity and are never touched.
+  // All strides are powers of two: index arithmetic is shifts and masks only.
+  int lpow = 0;
+  while ((1 << lpow) < n) lpow++;
+  const int half = (1 << lpow) >> 1;
+  for (int lk = 1; lk <= lpow; lk++) {          // merge block size k = 2^lk
+    const int lhk = lk - 1, hkm = (1 << lhk) - 1;
     for (int i = threadIdx.x; i < half; i += NT) {
-      const int blk = i / hk, off = i % hk;
-      const int a = blk * k + off, b = blk * k + k - 1 - off;
+      const int blk = i >> lhk, off = i & hkm;
+      const int a = (blk << lk) + off, b = (blk << lk) + (1 << lk) - 1 - off;
       if (b < n) {
         unsigned long long x = A[a], y = A[b];
         if (x > y) { A[a] = y; A[b] = x; }
       }
     }
     __syncthreads();
-    for (int j = k >> 2; j >= 1; j >>= 1) {
+    for (int lj = lk - 2; lj >= 0; lj--) {      // half-cleaners with stride j = 2^lj
+      const int jm = (1 << lj) - 1;
       for (int i = threadIdx.x; i < half; i += NT) {
-        const int a = (i / j) * 2 * j + (i % j), b = a + j;
+        const int a = ((i >> lj) << (lj + 1)) + (i & jm), b = a + (1 << lj);
         if (b < n) {
           unsigned long long x = A[a], y = A[b];
           if (x > y) { A[a] = y; A[b] = x; }
