@@ -470,7 +470,7 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
                             {256, 1024, 256, 1024, clampu(4096u / n, 64u, 1024u)},
                             {256, 4096, 1024, 4096, clampu(1024u / n, 32u, 512u)},
                             {512, 16384, 4096, 0x7FFFFFFF, clampu(512u / n, 16u, 256u)}};
-    auto lds_bytes = [](const FqClass& c) { return (size_t)c.cap * 8 + (size_t)(6 * c.nt > 1024 ? 6 * c.nt : 1024) * 8; };
+    auto lds_bytes = [](const FqClass& c) { return (size_t)c.cap * 8 + (size_t)1024 * 8; };
     if (!D->fq_attr_set) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds_bytes(cls[3])));

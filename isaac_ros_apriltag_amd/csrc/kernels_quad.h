@@ -3,9 +3,9 @@
 // (one wave for <= 256 points, 256 threads up to 4096, 512 threads above) so that small clusters do
 // not pay for idle waves and the slope sort always runs in LDS (2 KB ... 128 KB of keys):
 //   bbox / gradient-dot by integer block reductions -> slope keys -> in-place bitonic sort in LDS ->
-//   weighted moment terms NT points at a time into an LDS chunk, cumulative sums as ONE sequential
-//   double chain per moment (6 lanes; this is what makes the result bit-identical to the sequential
-//   CPU definition), chunk streamed to the moment array -> windowed line-fit errors, 7-tap smoothing
+//   weighted moment terms widened to 128-bit fixed point, where sums are exact, so the cumulative
+//   moments are a workgroup-wide parallel scan rounded once per prefix (bit-identical to the CPU
+//   definition in any order) -> windowed line-fit errors, 7-tap smoothing
 //   -> local maxima compacted into LDS, top-10 selection by 11 block arg-max rounds over that list ->
 //   all C(10,4) corner choices from a table of pairwise segment fits -> 4 line fits, intersections and
 //   the area/angle checks spread over 4 lanes.
@@ -51,6 +51,54 @@ __device__ __forceinline__ long long block_reduce_sum_ll(long long v, long long*
   for (int w = 1; w < NW; w++) r += scratch[w];
   __syncthreads();
   return r;
+}
+
+// ---- exact 128-bit fixed-point sums of doubles (52 fractional bits) --------------------------------
+struct U128 { unsigned long long lo, hi; };
+__device__ __forceinline__ U128 u128_zero() { U128 r; r.lo = 0; r.hi = 0; return r; }
+__device__ __forceinline__ U128 u128_add(U128 a, U128 b) {
+  U128 r;
+  r.lo = a.lo + b.lo;
+  r.hi = a.hi + b.hi + (r.lo < a.lo ? 1ull : 0ull);
+  return r;
+}
+// value * 2^52 of a double >= 1 (every moment term is: W >= 1, x,y >= 1) and < 2^64
+__device__ __forceinline__ U128 exact_to_fixed(double t) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(t);
+  const int exp = (int)((bits >> 52) & 0x7FF);
+  const unsigned long long m = (bits & ((1ull << 52) - 1)) | (1ull << 52);
+  const int shift = exp - 1023;
+  U128 r;
+  if (shift <= 0) { r.lo = shift < -63 ? 0 : (m >> (-shift)); r.hi = 0; return r; }  // t < 2 (shift 0) or never
+  r.lo = m << shift;
+  r.hi = m >> (64 - shift);
+  return r;
+}
+// nearest-even rounding of v / 2^52 to double
+__device__ __forceinline__ double exact_from_fixed(U128 v) {
+  if (v.hi == 0 && v.lo < (1ull << 53)) return (double)(long long)v.lo * 0x1p-52;
+  const int p = v.hi ? 127 - __clzll((long long)v.hi) : 63 - __clzll((long long)v.lo);
+  int r = p - 52;  // 1 .. 75
+  unsigned long long mant, below;  // below: the r bits under the mantissa, top-aligned test done separately
+  bool halfbit, sticky;
+  if (r < 64) {
+    mant = (v.lo >> r) | (v.hi << (64 - r));
+    halfbit = (v.lo >> (r - 1)) & 1;
+    sticky = (v.lo & ((1ull << (r - 1)) - 1)) != 0;
+  } else if (r == 64) {
+    mant = v.hi;
+    halfbit = (v.lo >> 63) & 1;
+    sticky = (v.lo & ((1ull << 63) - 1)) != 0;
+  } else {
+    mant = v.hi >> (r - 64);
+    halfbit = (v.hi >> (r - 65)) & 1;
+    sticky = ((v.hi & ((1ull << (r - 65)) - 1)) != 0) || (v.lo != 0);
+  }
+  (void)below;
+  if (halfbit && (sticky || (mant & 1))) mant++;
+  if (mant >> 53) { mant >>= 1; r++; }
+  const unsigned long long bits = ((unsigned long long)(1023 + r) << 52) | (mant & ((1ull << 52) - 1));
+  return __longlong_as_double((long long)bits);
 }
 
 // Line fit over the cumulative moments lf[i*6 + {Mx,My,Mxx,Mxy,Myy,W}] of points i0..i1 (circular).
@@ -138,8 +186,8 @@ __device__ __forceinline__ uint32_t combo_of(int t) {
   return 0xFFFFu;
 }
 
-// Dynamic LDS layout: [0, 8*sort_cap) slope keys (later: maxima candidates) | max(6*NT, 1024) doubles
-// moment chunk (later: pair-fit tables).  Clusters with size in (size_lo, size_hi] are processed by this
+// Dynamic LDS layout: [0, 8*sort_cap) slope keys (later: maxima candidates) | 1024 doubles of pair-fit
+// tables.  Clusters with size in (size_lo, size_hi] are processed by this
 // launch; those above sort_cap (only possible in the last class) sort in global scratch.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_fit_quads(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
@@ -171,6 +219,8 @@ __global__ __launch_bounds__(NT) void k_fit_quads(const FrameDesc* __restrict__ 
   __shared__ float s_corner[4][2];
   __shared__ int s_ok;
   __shared__ int s_idx4[4];
+  __shared__ U128 s_carry[6];
+  __shared__ U128 s_wtot[(NW > 1 ? NW : 1) * 6];
 
   const int frame = blockIdx.y;
   const int tid = threadIdx.x;
@@ -243,11 +293,18 @@ __global__ __launch_bounds__(NT) void k_fit_quads(const FrameDesc* __restrict__ 
     if (in_lds) bitonic_sort_block<NT>(skeys, sz); else bitonic_sort_block<NT>(gkeys, sz);
     FQ_TICK(2)
 
-    // ---- weighted moment terms per NT-point chunk, sequential cumulative sums in LDS --------------
+    // ---- weighted moment terms, exact cumulative sums (parallel scan of 128-bit fixed point) -------
+    // Each term (a double >= 1) is widened to value*2^52 in a 128-bit integer, where addition is exact
+    // and associative; the inclusive scan runs over the whole workgroup and every prefix is rounded to
+    // nearest-even double once -- the same definition the CPU oracle uses, independent of order.
     double* lf = lf_all + ((size_t)frame * P.pcap + cl.start) * 6;
-    double carry = 0;  // lanes 0..5: running sum of moment `tid`
+    if (tid < 6) s_carry[tid] = u128_zero();
+    __syncthreads();
     for (int base = 0; base < sz; base += NT) {
       const int i = base + tid;
+      U128 v[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) v[j] = u128_zero();
       if (i < sz) {
         const unsigned long long key = in_lds ? skeys[i] : gkeys[i];
         const int px = (int)((key >> 4) & 0x3FFF), py = (int)((key >> 18) & 0x3FFF);
@@ -259,36 +316,47 @@ __global__ __launch_bounds__(NT) void k_fit_quads(const FrameDesc* __restrict__ 
           const int grad_y = (int)gray[(size_t)(iy + 1) * gpitch + ix] - (int)gray[(size_t)(iy - 1) * gpitch + ix];
           Wt = __dsqrt_rn((double)(grad_x * grad_x + grad_y * grad_y)) + 1;
         }
-        chunk[0 * NT + tid] = Wt * x;
-        chunk[1 * NT + tid] = Wt * y;
-        chunk[2 * NT + tid] = Wt * x * x;
-        chunk[3 * NT + tid] = Wt * x * y;
-        chunk[4 * NT + tid] = Wt * y * y;
-        chunk[5 * NT + tid] = Wt;
+        v[0] = exact_to_fixed(Wt * x);
+        v[1] = exact_to_fixed(Wt * y);
+        v[2] = exact_to_fixed(Wt * x * x);
+        v[3] = exact_to_fixed(Wt * x * y);
+        v[4] = exact_to_fixed(Wt * y * y);
+        v[5] = exact_to_fixed(Wt);
       }
-      __syncthreads();
-      if (tid < 6) {
-        const int cnt = min(NT, sz - base);
-        double* row = chunk + tid * NT;
-        double acc = carry;
-        int k = 0;
-        for (; k + 8 <= cnt; k += 8) {
-          double v[8];
+      const int lane = lane_id(), wv = tid >> 6;
 #pragma unroll
-          for (int u = 0; u < 8; u++) v[u] = row[k + u];
+      for (int off = 1; off < 64; off <<= 1) {
 #pragma unroll
-          for (int u = 0; u < 8; u++) { acc += v[u]; v[u] = acc; }
-#pragma unroll
-          for (int u = 0; u < 8; u++) row[k + u] = v[u];
+        for (int j = 0; j < 6; j++) {
+          U128 n;
+          n.lo = __shfl_up(v[j].lo, off, 64);
+          n.hi = __shfl_up(v[j].hi, off, 64);
+          if (lane >= off) v[j] = u128_add(v[j], n);
         }
-        for (; k < cnt; k++) { acc += row[k]; row[k] = acc; }
-        carry = acc;
       }
-      __syncthreads();
+      if (NW > 1) {
+        if (lane == 63) {
+#pragma unroll
+          for (int j = 0; j < 6; j++) s_wtot[wv * 6 + j] = v[j];
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        U128 add = s_carry[j];
+        if (NW > 1)
+          for (int w = 0; w < wv; w++) add = u128_add(add, s_wtot[w * 6 + j]);
+        v[j] = u128_add(v[j], add);
+      }
       if (i < sz) {
         double* o = lf + (size_t)i * 6;
 #pragma unroll
-        for (int j = 0; j < 6; j++) o[j] = chunk[j * NT + tid];
+        for (int j = 0; j < 6; j++) o[j] = exact_from_fixed(v[j]);
+      }
+      __syncthreads();
+      if (tid == NT - 1) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) s_carry[j] = v[j];
       }
       __syncthreads();
     }
@@ -298,9 +366,12 @@ __global__ __launch_bounds__(NT) void k_fit_quads(const FrameDesc* __restrict__ 
     const int ksz = min(20, sz / 12);
     double* ea = errs_a_all + (size_t)frame * P.pcap + cl.start;
     double* eb = errs_b_all + (size_t)frame * P.pcap + cl.start;
+    // (indices wrap with compare/subtract: integer division by a run-time value costs ~40 instructions)
     for (int i = tid; i < sz; i += NT) {
       double e;
-      fit_line_dev(lf, sz, (i + sz - ksz) % sz, (i + ksz) % sz, nullptr, &e, nullptr);
+      const int i0 = (i >= ksz) ? i - ksz : i - ksz + sz;
+      const int i1 = (i + ksz < sz) ? i + ksz : i + ksz - sz;
+      fit_line_dev(lf, sz, i0, i1, nullptr, &e, nullptr);
       ea[i] = e;
     }
     if (tid == 0) { s_ncand = 0; s_nkept = 0; s_ok = 1; }
@@ -309,14 +380,15 @@ __global__ __launch_bounds__(NT) void k_fit_quads(const FrameDesc* __restrict__ 
       const float f0 = 0x1.6c0504p-7f, f1 = 0x1.152aaap-3f, f2 = 0x1.368b3p-1f;
       const double F0 = (double)f0, F1 = (double)f1, F2 = (double)f2;
       for (int i = tid; i < sz; i += NT) {
+        auto wrap = [sz](int k) { return k < 0 ? k + sz : (k >= sz ? k - sz : k); };
         double acc = 0;
-        acc += ea[(i - 3 + sz) % sz] * F0;
-        acc += ea[(i - 2 + sz) % sz] * F1;
-        acc += ea[(i - 1 + sz) % sz] * F2;
+        acc += ea[wrap(i - 3)] * F0;
+        acc += ea[wrap(i - 2)] * F1;
+        acc += ea[wrap(i - 1)] * F2;
         acc += ea[i] * 1.0;
-        acc += ea[(i + 1) % sz] * F2;
-        acc += ea[(i + 2) % sz] * F1;
-        acc += ea[(i + 3) % sz] * F0;
+        acc += ea[wrap(i + 1)] * F2;
+        acc += ea[wrap(i + 2)] * F1;
+        acc += ea[wrap(i + 3)] * F0;
         eb[i] = acc;
       }
     }
@@ -329,7 +401,7 @@ __global__ __launch_bounds__(NT) void k_fit_quads(const FrameDesc* __restrict__ 
     int* cand_idx = in_lds ? reinterpret_cast<int*>(skeys + (sort_cap >> 1)) : reinterpret_cast<int*>(ea + (sz >> 1) + 1);
     for (int i = tid; i < sz; i += NT) {
       const double e = eb[i];
-      if (e > eb[(i + 1) % sz] && e > eb[(i + sz - 1) % sz]) {
+      if (e > eb[i + 1 < sz ? i + 1 : 0] && e > eb[i > 0 ? i - 1 : sz - 1]) {
         const int k = atomicAdd(&s_ncand, 1);
         cand_val[k] = e;
         cand_idx[k] = i;

@@ -100,6 +100,34 @@ class AprilTagDetector:
             res.append(dets)
         return res
 
+    # ---- prepared submissions: argument marshalling done once, the timed call is only the C ABI call ----
+    def prepare(self, frames, max_dets=64):
+        imgs, keep = _as_images(frames, self.width, self.height)
+        n = len(imgs)
+        return {"imgs": imgs, "keep": keep, "n": n, "max_dets": max_dets,
+                "out": (capi.DetectionEx * (n * max_dets))(), "cnt": (C.c_uint32 * n)()}
+
+    def run_prepared(self, prep, stream=None):
+        """One blocking amdAprilTagsDetectBatchEx call; results stay in prep['out'] / prep['cnt']."""
+        capi._check("amdAprilTagsDetectBatchEx",
+                    self._L.amdAprilTagsDetectBatchEx(self._h, prep["n"], prep["imgs"], None, prep["out"], prep["cnt"],
+                                                      prep["max_dets"], stream))
+
+    def unpack(self, prep):
+        res = []
+        out, cnt, max_dets = prep["out"], prep["cnt"], prep["max_dets"]
+        for f in range(prep["n"]):
+            dets = []
+            for i in range(cnt[f]):
+                d = out[f * max_dets + i]
+                dets.append({"family": self.families[d.family], "id": int(d.id), "hamming": int(d.hamming),
+                             "decision_margin": float(d.decision_margin),
+                             "H": np.array(list(d.H)).reshape(3, 3), "center": np.array(list(d.c)),
+                             "p": np.array([[d.p[k][0], d.p[k][1]] for k in range(4)]),
+                             "R": np.array(list(d.R)).reshape(3, 3), "t": np.array(list(d.t))})
+            res.append(dets)
+        return res
+
     def detect_batch_raw(self, frames, max_tags=64, intrinsics=None, stream=None):
         """Returns (TagID ctypes array of n*max_tags, counts) -- the cuAprilTagsID_t-shaped records."""
         imgs, keep = _as_images(frames, self.width, self.height)

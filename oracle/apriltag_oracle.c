@@ -374,6 +374,33 @@ static int u64_cmp(const void* a, const void* b) {
   return (x > y) - (x < y);
 }
 
+/* exact fixed-point view of a double >= 1: value * 2^52 as a 128-bit integer (terms < 2^36 fit easily) */
+static unsigned __int128 exact_to_fixed(double t) {
+  uint64_t bits;
+  memcpy(&bits, &t, 8);
+  int exp = (int)((bits >> 52) & 0x7FF);
+  uint64_t m = (bits & ((1ULL << 52) - 1)) | (1ULL << 52);
+  int shift = exp - 1023;            /* t = m * 2^(exp-1075); fixed = t * 2^52 = m * 2^(exp-1023) */
+  if (shift < 0) return (unsigned __int128)(m >> (-shift > 63 ? 63 : -shift));   /* t < 1 never occurs */
+  return (unsigned __int128)m << shift;
+}
+/* nearest-even rounding of fixed / 2^52 to double */
+static double exact_from_fixed(unsigned __int128 v) {
+  uint64_t hi = (uint64_t)(v >> 64), lo = (uint64_t)v;
+  if (hi == 0 && lo < (1ULL << 53)) return (double)(int64_t)lo * 0x1p-52;
+  int p = hi ? 127 - __builtin_clzll(hi) : 63 - __builtin_clzll(lo);
+  int r = p - 52;
+  uint64_t mant = (uint64_t)(v >> r);
+  int halfbit = (int)((v >> (r - 1)) & 1);
+  int sticky = (v & ((((unsigned __int128)1) << (r - 1)) - 1)) != 0;
+  if (halfbit && (sticky || (mant & 1))) mant++;
+  if (mant >> 53) { mant >>= 1; r++; }
+  uint64_t bits = ((uint64_t)(1023 + r) << 52) | (mant & ((1ULL << 52) - 1));
+  double out;
+  memcpy(&out, &bits, 8);
+  return out;
+}
+
 /* fit one quad to the cluster pts[0..sz) (packed points); gray = working image (w x h). */
 static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, const uint32_t* pts, int sz,
                     int tag_width, int normal_border, int reversed_border, ato_quad_t* quad) {
@@ -416,9 +443,13 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
   }
   qsort(keys, sz, sizeof(uint64_t), u64_cmp);
 
-  /* cumulative weighted moments (compute_lfps), sequential double accumulation */
+  /* cumulative weighted moments (compute_lfps).  Per-point terms are formed exactly as upstream does
+   * (W*x, W*y, (W*x)*x, (W*x)*y, (W*y)*y, W in double).  CANONICAL: the running sums are the EXACT sums
+   * of those doubles, rounded once to nearest-even (upstream adds them sequentially in double, which
+   * differs by accumulated rounding noise and makes the value depend on the summation order).  Every
+   * term is >= 1 and < 2^36, so 52 fractional bits in a 128-bit integer hold each term exactly. */
   lfp_t* lfps = (lfp_t*)malloc(sizeof(lfp_t) * sz);
-  lfp_t acc = {0, 0, 0, 0, 0, 0};
+  unsigned __int128 acc[6] = {0, 0, 0, 0, 0, 0};
   for (int i = 0; i < sz; i++) {
     int px = (int)((keys[i] >> 4) & 0x3FFF), py = (int)((keys[i] >> 18) & 0x3FFF);
     double x = px * .5 + 0.5, y = py * .5 + 0.5;
@@ -429,8 +460,10 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
       int grad_y = gray[(iy + 1) * w + ix] - gray[(iy - 1) * w + ix];
       W = sqrt((double)(grad_x * grad_x + grad_y * grad_y)) + 1;
     }
-    acc.Mx += W * x; acc.My += W * y; acc.Mxx += W * x * x; acc.Mxy += W * x * y; acc.Myy += W * y * y; acc.W += W;
-    lfps[i] = acc;
+    double t[6] = {W * x, W * y, W * x * x, W * x * y, W * y * y, W};
+    double r[6];
+    for (int j = 0; j < 6; j++) { acc[j] += exact_to_fixed(t[j]); r[j] = exact_from_fixed(acc[j]); }
+    lfps[i].Mx = r[0]; lfps[i].My = r[1]; lfps[i].Mxx = r[2]; lfps[i].Mxy = r[3]; lfps[i].Myy = r[4]; lfps[i].W = r[5];
   }
   free(keys);
 
