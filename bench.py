@@ -83,8 +83,17 @@ def threshold_roofline(frames_dev, width, height, decimate, reps=20):
     alg_bytes = 2.0 * w * h * nb
     avg_ms = float(np.mean(ms))
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    # HBM traffic per launch comes from separate rocprofv3 --pmc passes of the same launch shape
+    # (tools/thr_only.py; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), committed under
+    # profiles/; bench.py cannot collect PMC counters itself.
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_threshold_pmc.json")
+    if decimate == 1 and os.path.exists(pmc):
+        rec = json.load(open(pmc))
+        if rec.get("frames_per_launch") == nb:
+            traffic, traffic_src = rec["traffic_bytes"], "profiles/r01_threshold_pmc.json"
     return {"bound": "hbm", "kernel": "k_threshold<%d>" % decimate, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4), "min_launch_ms": round(float(np.min(ms)), 4),
             "frames_per_launch": nb, "footprint_mib": round((big.numel() * 2) / 2 ** 20, 1)}
 

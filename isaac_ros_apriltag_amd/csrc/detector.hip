@@ -390,25 +390,27 @@ static void fill_frames(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTa
 
 static void launch_threshold(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s) {
   const DetParams& P = D->P;
-  dim3 grid((unsigned)(((P.W + 3) / 4 + 127) / 128), (unsigned)(((P.H + 3) / 4 + 7) / 8), n);
+  const int gx = ((P.W + 3) / 4 + 127) / 128, gy = ((P.H + 3) / 4 + 7) / 8;
+  const unsigned ntiles = (unsigned)gx * gy * n;
+  dim3 grid(8u * ((ntiles + 7u) / 8u));
   const bool leftover = (P.W % 4) || (P.H % 4);
   const int nleft = (P.W - P.tw * 4) * (P.th * 4) + (P.H - P.th * 4) * P.W;
   dim3 lgrid((unsigned)((nleft + 255) / 256), 1, n);
   switch (P.decimate) {
     case 1:
-      hipLaunchKernelGGL(k_threshold<1>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
+      hipLaunchKernelGGL(k_threshold<1>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, gx, gy, (int)n, P);
       if (leftover) hipLaunchKernelGGL(k_threshold_leftover<1>, lgrid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
       break;
     case 2:
-      hipLaunchKernelGGL(k_threshold<2>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
+      hipLaunchKernelGGL(k_threshold<2>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, gx, gy, (int)n, P);
       if (leftover) hipLaunchKernelGGL(k_threshold_leftover<2>, lgrid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
       break;
     case 3:
-      hipLaunchKernelGGL(k_threshold<3>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
+      hipLaunchKernelGGL(k_threshold<3>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, gx, gy, (int)n, P);
       if (leftover) hipLaunchKernelGGL(k_threshold_leftover<3>, lgrid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
       break;
     default:
-      hipLaunchKernelGGL(k_threshold<4>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
+      hipLaunchKernelGGL(k_threshold<4>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, gx, gy, (int)n, P);
       if (leftover) hipLaunchKernelGGL(k_threshold_leftover<4>, lgrid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
       break;
   }

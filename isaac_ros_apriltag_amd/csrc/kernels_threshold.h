@@ -68,18 +68,29 @@ __device__ __forceinline__ void th_minmax_word(uint32_t w, uint32_t& mn, uint32_
   }
 }
 
+// Launch: 1-D grid of 8*ceil(T/8) blocks, T = gx*gy*frames tiles.  Workgroups are dispatched to the 8
+// XCDs round-robin, so block L runs on XCD L%8; the remap below hands every XCD one contiguous run of
+// tiles (x fastest, then y, then frame), which keeps the halo rows a block re-reads from its vertical
+// neighbours in that XCD's own L2 instead of fetching them again over the fabric.  Placement is a speed
+// matter only: any block->tile bijection gives the same result.
 template <int DEC>
 __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__ frames, uint8_t* __restrict__ gray_all,
-                                                   uint8_t* __restrict__ thr_all, DetParams P) {
+                                                   uint8_t* __restrict__ thr_all, int gx, int gy, int nframes, DetParams P) {
   __shared__ __attribute__((aligned(16))) uint8_t smin[10 * TH_LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) uint8_t smax[10 * TH_LDS_STRIDE];
 
-  const int frame = blockIdx.z;
+  const int ntiles = gx * gy * nframes;
+  const int per_xcd = (int)(gridDim.x >> 3);
+  const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  const int frame = tile / (gx * gy);
+  const int trem = tile - frame * (gx * gy);
+  const int bx = trem % gx, by = trem / gx;
   const FrameDesc fd = frames[frame];
   const bool aligned = ((((uintptr_t)fd.img) | (uintptr_t)fd.pitch) & 15) == 0;
   const int tid = threadIdx.x;
   const int tx32 = tid & 31, ty8 = tid >> 5;
-  const int TX0 = blockIdx.x * 128, TY0 = blockIdx.y * 8;  // first tile of the block
+  const int TX0 = bx * 128, TY0 = by * 8;  // first tile of the block
   uint8_t* thr = thr_all + (size_t)frame * P.H * P.WS;
   uint8_t* gray = (DEC > 1) ? gray_all + (size_t)frame * P.H * P.WS : nullptr;
 

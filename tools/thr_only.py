@@ -1,0 +1,17 @@
+"""Runs only the threshold pass on a 160-frame 1080p batch (for rocprofv3 --pmc runs)."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from isaac_ros_apriltag_amd import synth
+from isaac_ros_apriltag_amd.detector import AprilTagDetector
+dec = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+frames = np.stack([synth.scene_c2(seed=1234 + i)[0] for i in range(8)])
+big = torch.from_numpy(frames).cuda().repeat(20, 1, 1).contiguous()
+det = AprilTagDetector(1920, 1080, decimate=dec, max_batch=160, max_points=4096, hash_slots=256, max_clusters=256, max_quads=64, max_detections=16)
+det.set_profiling(True)
+ms = []
+for _ in range(10):
+    det.threshold_only(big)
+    ms.append(det.stage_ms()["threshold"])
+print("threshold ms per 160-frame launch:", [round(m, 4) for m in ms])
+det.close()
