@@ -189,7 +189,8 @@ int amdAprilTagsFamilyFromName(const char* name);
 /* Stage names, index-aligned with amdAprilTagsGetStageMs. */
 const char* amdAprilTagsStageName(uint32_t stage);
 /* enable != 0: bracket every stage of subsequent submissions with HIP events on the submission
- * stream. */
+ * stream.  enable == 2 additionally accumulates per-phase shader-cycle counters inside the quad-fit
+ * kernel (AMDAT_DBG_FQPROF; perturbs its timing). */
 int amdAprilTagsSetProfiling(amdAprilTagsHandle handle, int enable);
 /* Milliseconds per stage of the last submission (AMDAT_NUM_STAGES floats). */
 int amdAprilTagsGetStageMs(amdAprilTagsHandle handle, float* ms);

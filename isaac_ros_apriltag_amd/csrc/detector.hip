@@ -116,6 +116,7 @@ struct amdAprilTagsDetector_st {
   DetRec* h_out = nullptr;
   // profiling
   bool profiling = false;
+  bool fq_counters = false;  // per-phase cycle counters inside k_fit_quads (profiling level 2; perturbs timing)
   bool fq_attr_set = false;
   hipEvent_t ev[AMDAT_NUM_STAGES + 1] = {};
   float stage_ms[AMDAT_NUM_STAGES] = {};
@@ -356,6 +357,7 @@ int amdAprilTagsDestroy(amdAprilTagsHandle handle) {
 int amdAprilTagsSetProfiling(amdAprilTagsHandle handle, int enable) {
   if (!handle) return AMDAT_INVALID_ARGUMENT;
   handle->profiling = enable != 0;
+  handle->fq_counters = enable >= 2;
   return AMDAT_SUCCESS;
 }
 
@@ -460,10 +462,10 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
     hipLaunchKernelGGL(k_scatter, dim3(gx, 1, n), dim3(256), 0, s, D->d_stage, D->d_rank, D->d_hoff, D->d_pts, D->d_counters, P);
   }
   mark();
-  if (prof && !D->d_fqprof) {
+  if (D->fq_counters && !D->d_fqprof) {
     if (hipMalloc((void**)&D->d_fqprof, 32 * 8) != hipSuccess) D->d_fqprof = nullptr;
   }
-  if (D->d_fqprof) HIP_TRY(hipMemsetAsync(D->d_fqprof, 0, 32 * 8, s));
+  if (D->fq_counters && D->d_fqprof) HIP_TRY(hipMemsetAsync(D->d_fqprof, 0, 32 * 8, s));
   {
     // four size classes: one wave per small cluster, bigger workgroups and LDS key arrays above
     struct FqClass { int nt, cap, lo, hi; unsigned gx; };
@@ -483,7 +485,7 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
       const dim3 grid(cls[c].gx, n);
       const size_t lds = lds_bytes(cls[c]);
 #define FQ_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_keys, D->d_lf, D->d_errs_a, D->d_errs_b, D->d_quads, \
-                D->d_counters, (D->d_fqprof ? D->d_fqprof + 8 * c : nullptr), cls[c].cap, cls[c].lo, cls[c].hi, P
+                D->d_counters, ((D->fq_counters && D->d_fqprof) ? D->d_fqprof + 8 * c : nullptr), cls[c].cap, cls[c].lo, cls[c].hi, P
       if (cls[c].nt == 64) hipLaunchKernelGGL(k_fit_quads<64>, grid, dim3(64), lds, s, FQ_ARGS);
       else if (cls[c].nt == 256) hipLaunchKernelGGL(k_fit_quads<256>, grid, dim3(256), lds, s, FQ_ARGS);
       else hipLaunchKernelGGL(k_fit_quads<512>, grid, dim3(512), lds, s, FQ_ARGS);

@@ -147,7 +147,8 @@ class AprilTagDetector:
 
     # ---- measurement / inspection ---------------------------------------------------------------------
     def set_profiling(self, enable=True):
-        capi._check("amdAprilTagsSetProfiling", self._L.amdAprilTagsSetProfiling(self._h, 1 if enable else 0))
+        """True/1: HIP events per stage; 2: plus cycle counters inside the quad-fit kernel."""
+        capi._check("amdAprilTagsSetProfiling", self._L.amdAprilTagsSetProfiling(self._h, int(enable)))
 
     def stage_ms(self):
         ms = (C.c_float * capi.NUM_STAGES)()

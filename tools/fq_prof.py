@@ -8,7 +8,7 @@ frames = np.stack([synth.scene_c2(seed=1234 + i)[0] for i in range(4)])
 t = torch.from_numpy(frames).cuda().repeat(B // 4, 1, 1).contiguous()
 det = AprilTagDetector(1920, 1080, max_batch=B)
 det.detect_batch_ex(t)
-det.set_profiling(True)
+det.set_profiling(2)
 det.detect_batch_ex(t)
 print({k: round(v, 3) for k, v in det.stage_ms().items()})
 pa = det.debug(0, 8).view(np.uint64)[:32].astype(np.float64).reshape(4, 8)
