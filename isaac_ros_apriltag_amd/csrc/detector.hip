@@ -19,6 +19,7 @@
 #include "kernels_cc.h"
 #include "kernels_cluster.h"
 #include "kernels_decode.h"
+#include "kernels_decode_wave.h"
 #include "kernels_quad.h"
 #include "kernels_threshold.h"
 
@@ -493,7 +494,12 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
     }
   }
   mark();
-  hipLaunchKernelGGL(k_decode, dim3(8, n), dim3(64), 0, s, D->d_frames, D->d_quads, D->d_dets, D->d_counters, P);
+  {
+    unsigned gq = 2048u / n;
+    if (gq < 16u) gq = 16u;
+    if (gq > 256u) gq = 256u;
+    hipLaunchKernelGGL(k_decode_wave, dim3(gq, n), dim3(64), 0, s, D->d_frames, D->d_quads, D->d_dets, D->d_counters, P);
+  }
   mark();
   hipLaunchKernelGGL(k_reconcile, dim3(n), dim3(64), 0, s, D->d_frames, D->d_dets, D->d_out, D->d_counters, D->d_order, P);
   mark();

@@ -2,10 +2,12 @@
 // (the tail of the closed cuAprilTagsDetect call, reference
 // src/apriltag_node.cpp:491-493, whose outputs the node reads at :503-546).
 //
-// Quad-parallel: one lane per candidate quad (tens to a few hundred per frame, thousands per batch);
-// every floating-point statement is evaluated in the same order as the sequential CPU definition so
-// that ids, corners and poses come out bit-identical.  The code lookup is a brute-force popcount
-// scan over the family table (<= 587 codes x 4 rotations), not a hash table.
+// This file holds the scalar building blocks (projection, gray model, bilinear sample, code rotation),
+// a one-lane-per-quad kernel k_decode kept as the simple form of the stage, and the per-frame
+// reconcile/pose kernel.  The production launch is the one-wave-per-quad kernel in
+// kernels_decode_wave.h.  Every floating-point statement is evaluated in the same order as the
+// sequential CPU definition so that ids, corners and poses come out bit-identical.  The code lookup is
+// a brute-force popcount scan over the family table (<= 587 codes x 4 rotations), not a hash table.
 #pragma once
 #include "common.h"
 
