@@ -122,8 +122,13 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
       const uint32_t r0 = slab[c];
       if (r0 == AT_NO_LABEL) continue;
       const int v0 = sv[c];
+      // upstream's connected_last: the left neighbour (a valid source itself) emitted its (1,1) point,
+      // which is this pixel's (-1,1) half-pixel location
+      const bool left_emits = gx - 1 >= 1 && slab[c - 1] != AT_NO_LABEL && slab[c + PT_LW] != AT_NO_LABEL &&
+                              (int)sv[c - 1] + (int)sv[c + PT_LW] == 255;
 #pragma unroll
       for (int d = 0; d < 4; d++) {
+        if (d == 2 && left_emits) continue;
         const int n = c + DY[d] * PT_LW + DX[d];
         const uint32_t r1 = slab[n];
         if (r1 == AT_NO_LABEL || v0 + (int)sv[n] != 255) continue;
@@ -174,8 +179,11 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     const uint32_t r0 = slab[c];
     if (r0 == AT_NO_LABEL) continue;
     const int v0 = sv[c];
+    const bool left_emits = gx - 1 >= 1 && slab[c - 1] != AT_NO_LABEL && slab[c + PT_LW] != AT_NO_LABEL &&
+                            (int)sv[c - 1] + (int)sv[c + PT_LW] == 255;
 #pragma unroll
     for (int d = 0; d < 4; d++) {
+      if (d == 2 && left_emits) continue;
       const int n = c + DY[d] * PT_LW + DX[d];
       const uint32_t r1 = slab[n];
       const int v1 = sv[n];

@@ -291,7 +291,43 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : (NT == 64 ? 4 : 2))) void k_fi
     }
     __syncthreads();
     if (in_lds) bitonic_sort_block<NT>(skeys, sz); else bitonic_sort_block<NT>(gkeys, sz);
+    // ---- remove duplicate points (same half-pixel location; adjacent after the sort) ----------------
+    // chunk by chunk: a chunk is read, the block synchronises, then it is written at or below where it
+    // was read, so no unread element is ever overwritten
+    {
+      if (tid == 0) s_ncand = 0;  // running output position
+      __syncthreads();
+      for (int base = 0; base < sz; base += NT) {
+        const int i = base + tid;
+        unsigned long long key = 0;
+        bool keep = false;
+        if (i < sz) {
+          key = in_lds ? skeys[i] : gkeys[i];
+          const unsigned long long prev = (i > 0) ? (in_lds ? skeys[i - 1] : gkeys[i - 1]) : ~key;
+          keep = (i == 0) || ((key >> 4) != (prev >> 4));
+        }
+        const unsigned long long m = __ballot(keep);
+        const int wv = tid >> 6, ln = lane_id();
+        if (NW > 1 && ln == 0) sred_i[wv] = (int)__popcll(m);
+        __syncthreads();
+        int off = s_ncand + (int)__popcll(m & ((1ull << ln) - 1ull));
+        if (NW > 1)
+          for (int w2 = 0; w2 < wv; w2++) off += sred_i[w2];
+        int tot = (int)__popcll(m);
+        if (NW > 1) { tot = 0; for (int w2 = 0; w2 < NW; w2++) tot += sred_i[w2]; }
+        if (keep) { if (in_lds) skeys[off] = key; else gkeys[off] = key; }
+        __syncthreads();
+        if (tid == 0) s_ncand += tot;
+        __syncthreads();
+      }
+    }
+    const int sz_all = sz;
+    (void)sz_all;
+    const int sz_dedup = s_ncand;
+    __syncthreads();
+    if (sz_dedup < 24) continue;
     FQ_TICK(2)
+    const int szd = sz_dedup;
 
     // ---- weighted moment terms, exact cumulative sums (parallel scan of 128-bit fixed point) -------
     // Each term (a double >= 1) is widened to value*2^52 in a 128-bit integer, where addition is exact
@@ -300,12 +336,12 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : (NT == 64 ? 4 : 2))) void k_fi
     double* lf = lf_all + ((size_t)frame * P.pcap + cl.start) * 6;
     if (tid < 6) s_carry[tid] = u128_zero();
     __syncthreads();
-    for (int base = 0; base < sz; base += NT) {
+    for (int base = 0; base < szd; base += NT) {
       const int i = base + tid;
       U128 v[6];
 #pragma unroll
       for (int j = 0; j < 6; j++) v[j] = u128_zero();
-      if (i < sz) {
+      if (i < szd) {
         const unsigned long long key = in_lds ? skeys[i] : gkeys[i];
         const int px = (int)((key >> 4) & 0x3FFF), py = (int)((key >> 18) & 0x3FFF);
         const double x = px * .5 + 0.5, y = py * .5 + 0.5;
@@ -348,7 +384,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : (NT == 64 ? 4 : 2))) void k_fi
           for (int w = 0; w < wv; w++) add = u128_add(add, s_wtot[w * 6 + j]);
         v[j] = u128_add(v[j], add);
       }
-      if (i < sz) {
+      if (i < szd) {
         double* o = lf + (size_t)i * 6;
 #pragma unroll
         for (int j = 0; j < 6; j++) o[j] = exact_from_fixed(v[j]);
@@ -363,15 +399,15 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : (NT == 64 ? 4 : 2))) void k_fi
     FQ_TICK(4)
 
     // ---- windowed line-fit error, smoothing ------------------------------------------------------
-    const int ksz = min(20, sz / 12);
+    const int ksz = min(20, szd / 12);
     double* ea = errs_a_all + (size_t)frame * P.pcap + cl.start;
     double* eb = errs_b_all + (size_t)frame * P.pcap + cl.start;
     // (indices wrap with compare/subtract: integer division by a run-time value costs ~40 instructions)
-    for (int i = tid; i < sz; i += NT) {
+    for (int i = tid; i < szd; i += NT) {
       double e;
-      const int i0 = (i >= ksz) ? i - ksz : i - ksz + sz;
-      const int i1 = (i + ksz < sz) ? i + ksz : i + ksz - sz;
-      fit_line_dev(lf, sz, i0, i1, nullptr, &e, nullptr);
+      const int i0 = (i >= ksz) ? i - ksz : i - ksz + szd;
+      const int i1 = (i + ksz < szd) ? i + ksz : i + ksz - szd;
+      fit_line_dev(lf, szd, i0, i1, nullptr, &e, nullptr);
       ea[i] = e;
     }
     if (tid == 0) { s_ncand = 0; s_nkept = 0; s_ok = 1; }
@@ -379,8 +415,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : (NT == 64 ? 4 : 2))) void k_fi
     {
       const float f0 = 0x1.6c0504p-7f, f1 = 0x1.152aaap-3f, f2 = 0x1.368b3p-1f;
       const double F0 = (double)f0, F1 = (double)f1, F2 = (double)f2;
-      for (int i = tid; i < sz; i += NT) {
-        auto wrap = [sz](int k) { return k < 0 ? k + sz : (k >= sz ? k - sz : k); };
+      for (int i = tid; i < szd; i += NT) {
+        auto wrap = [szd](int k) { return k < 0 ? k + szd : (k >= szd ? k - szd : k); };
         double acc = 0;
         acc += ea[wrap(i - 3)] * F0;
         acc += ea[wrap(i - 2)] * F1;
@@ -398,10 +434,10 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : (NT == 64 ? 4 : 2))) void k_fi
     // ---- local maxima -> candidate list (values + indices) ------------------------------------------
     // list storage: the key array is free now (LDS), or the first error array (global) for huge clusters
     double* cand_val = in_lds ? reinterpret_cast<double*>(skeys) : ea;
-    int* cand_idx = in_lds ? reinterpret_cast<int*>(skeys + (sort_cap >> 1)) : reinterpret_cast<int*>(ea + (sz >> 1) + 1);
-    for (int i = tid; i < sz; i += NT) {
+    int* cand_idx = in_lds ? reinterpret_cast<int*>(skeys + (sort_cap >> 1)) : reinterpret_cast<int*>(ea + (szd >> 1) + 1);
+    for (int i = tid; i < szd; i += NT) {
       const double e = eb[i];
-      if (e > eb[i + 1 < sz ? i + 1 : 0] && e > eb[i > 0 ? i - 1 : sz - 1]) {
+      if (e > eb[i + 1 < szd ? i + 1 : 0] && e > eb[i > 0 ? i - 1 : szd - 1]) {
         const int k = atomicAdd(&s_ncand, 1);
         cand_val[k] = e;
         cand_idx[k] = i;
@@ -470,11 +506,11 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : (NT == 64 ? 4 : 2))) void k_fi
       if (a < b && b < m) {
         if (task < 100) {
           double e, ms;
-          fit_line_dev(lf, sz, s_maxidx[a], s_maxidx[b], s_lines + 20 + task * 4, &e, &ms);  // params parked past s_lmse
+          fit_line_dev(lf, szd, s_maxidx[a], s_maxidx[b], s_lines + 20 + task * 4, &e, &ms);  // params parked past s_lmse
           s_ferr[t] = e; s_fmse[t] = ms; s_fnx[t] = s_lines[20 + task * 4 + 2]; s_fny[t] = s_lines[20 + task * 4 + 3];
         } else {
           double e, ms;
-          fit_line_dev(lf, sz, s_maxidx[b], s_maxidx[a], nullptr, &e, &ms);
+          fit_line_dev(lf, szd, s_maxidx[b], s_maxidx[a], nullptr, &e, &ms);
           s_werr[t] = e; s_wmse[t] = ms;
         }
       }
@@ -509,7 +545,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : (NT == 64 ? 4 : 2))) void k_fi
 #pragma unroll
       for (int w = 1; w < NW; w++)
         if (sred_d[w] < be || (sred_d[w] == be && sred_di[w] < bt)) { be = sred_d[w]; bt = sred_di[w]; }
-      const bool ok = (be != (double)HUGE_VALF) && (be / sz < P.max_line_fit_mse);
+      const bool ok = (be != (double)HUGE_VALF) && (be / szd < P.max_line_fit_mse);
       s_ok = ok ? 1 : 0;
       if (ok) {
         const uint32_t cmb = s_combo[bt];
@@ -522,7 +558,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : (NT == 64 ? 4 : 2))) void k_fi
     // four final line fits (lanes 0..3), then four intersections (lanes 0..3)
     if (tid < 4) {
       double ms;
-      fit_line_dev(lf, sz, s_idx4[tid], s_idx4[(tid + 1) & 3], s_lines + tid * 4, nullptr, &ms);
+      fit_line_dev(lf, szd, s_idx4[tid], s_idx4[(tid + 1) & 3], s_lines + tid * 4, nullptr, &ms);
       s_lmse[tid] = ms;
     }
     __syncthreads();

@@ -217,13 +217,19 @@ static kp_t* gradient_points(const uint8_t* thr, const uint32_t* label, const ui
   static const int DX[4] = {1, 0, -1, 1}, DY[4] = {0, 1, 1, 1};
   size_t cap = 1 << 16, n = 0;
   kp_t* pts = (kp_t*)malloc(cap * sizeof(kp_t));
-  for (int y = 1; y < h - 1; y++)
+  for (int y = 1; y < h - 1; y++) {
+    /* connected_last: the previous pixel of this row emitted its (1,1) point.  That point and this
+     * pixel's (-1,1) point sit on the same half-pixel location, so (-1,1) is skipped then (upstream
+     * do_gradient_clusters). */
+    int connected_last = 0;
     for (int x = 1; x < w - 1; x++) {
       int v0 = thr[y * w + x];
-      if (v0 == 127) continue;
+      if (v0 == 127) { connected_last = 0; continue; }
       uint32_t r0 = label[y * w + x];
-      if ((int)csize[r0] < min_comp) continue;
+      if ((int)csize[r0] < min_comp) { connected_last = 0; continue; }
+      int connected = 0;
       for (int k = 0; k < 4; k++) {
+        if (k == 2 && connected_last) continue;
         int x1 = x + DX[k], y1 = y + DY[k];
         int v1 = thr[y1 * w + x1];
         if (v0 + v1 != 255) continue;
@@ -234,8 +240,11 @@ static kp_t* gradient_points(const uint8_t* thr, const uint32_t* label, const ui
         pts[n].key = key;
         pts[n].pt = pack_point(2 * x + DX[k], 2 * y + DY[k], DX[k] * (v1 - v0), DY[k] * (v1 - v0));
         n++;
+        if (k == 3) connected = 1;
       }
+      connected_last = connected;
     }
+  }
   qsort(pts, n, sizeof(kp_t), kp_cmp);
   *nout = n;
   return pts;
@@ -442,6 +451,15 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
     keys[i] = ((uint64_t)float_sortable(slope) << 32) | ((uint64_t)y << 18) | ((uint64_t)x << 4) | (pts[i] & 15u);
   }
   qsort(keys, sz, sizeof(uint64_t), u64_cmp);
+  /* remove duplicate points (same half-pixel location, a by-product of the segmentation); the
+   * gradient-direction test above has already seen all of them (upstream fit_quad) */
+  {
+    int outpos = 1;
+    for (int i = 1; i < sz; i++)
+      if ((keys[i] >> 4) != (keys[i - 1] >> 4)) keys[outpos++] = keys[i];   /* bits 4..31 = (y,x) */
+    sz = outpos;
+  }
+  if (sz < 24) { free(keys); return 0; }
 
   /* cumulative weighted moments (compute_lfps).  Per-point terms are formed exactly as upstream does
    * (W*x, W*y, (W*x)*x, (W*x)*y, (W*y)*y, W in double).  CANONICAL: the running sums are the EXACT sums
