@@ -259,3 +259,79 @@ def test_node_shell_pol_and_mono8(built):
     with pytest.raises(RuntimeError):
         n.on_frame(img.ctypes.data, False, "yuv422", 1920, 1080, 1920 * 2, K9)
     n.close()
+
+
+@pytest.mark.parametrize("shape", [(4, 4), (8, 8), (16, 20), (5, 7), (64, 4)])
+def test_tiny_and_degenerate_frames(built, shape):
+    """Smallest legal sizes, flat frames (everything 127) and frames without any tag: no detections, no
+    flags, integer stages still bit-exact."""
+    h, w = shape
+    K = synth.default_K(w, h)
+    rng = np.random.default_rng(h * 31 + w)
+    for img in (np.full((h, w), 77, dtype=np.uint8), rng.integers(0, 256, size=(h, w), dtype=np.uint8)):
+        det, g = _run(img, K)
+        errs, odets = pu.compare_stages(det, 0, img, ("tag36h11",), K, 1)
+        det.close()
+        assert not errs, errs[:3]
+        assert g == [] and odets == []
+
+
+def test_create_rejects_unsupported_sizes(built):
+    L = capi.lib()
+    h = C.c_void_p()
+    cam = capi.Intrinsics(100, 100, 1, 1)
+    assert L.amdCreateAprilTagsDetector(C.byref(h), 3, 3, 4, 0, C.byref(cam), 0.1) == 2       # smaller than one tile
+    assert L.amdCreateAprilTagsDetector(C.byref(h), 10000, 100, 4, 0, C.byref(cam), 0.1) == 2  # 2x+1 must fit 14 bits
+
+
+def test_max_tags_truncation_and_order(built):
+    """More tags than max_tags: the first max_tags records of the canonical order are returned."""
+    img, K, truth = synth.scene_c2(sigma=0)
+    det = AprilTagDetector(1920, 1080, intrinsics=_k4(K), max_batch=1)
+    t = torch.from_numpy(img).cuda()
+    full = det.detect_batch_ex(t, max_dets=64)[0]
+    part = det.detect_batch_ex(t, max_dets=4)[0]
+    tags, cnt = det.detect_batch_raw(t, max_tags=3)
+    det.close()
+    assert [d["id"] for d in full] == list(range(10))
+    assert not pu.compare_detections(part, full[:4])
+    assert cnt == [3] and [tags[i].id for i in range(3)] == [0, 1, 2]
+
+
+def test_mixed_batch_with_empty_frames(built):
+    """A batch mixing tag frames, a flat frame and a pure-noise frame equals the per-frame oracle."""
+    a = synth.scene_c2(seed=1250)[0]
+    b = np.full((1080, 1920), 200, dtype=np.uint8)
+    c = np.random.default_rng(3).integers(0, 256, size=(1080, 1920), dtype=np.uint8)
+    d = synth.scene_c2(seed=1251, sigma=0)[0]
+    K = synth.default_K(1920, 1080)
+    det = AprilTagDetector(1920, 1080, intrinsics=_k4(K), max_batch=4)
+    res = det.detect_batch_ex(torch.from_numpy(np.stack([a, b, c, d])).cuda(), max_dets=64)
+    flags = det.frame_flags(4)
+    for i, img in enumerate((a, b, c, d)):
+        errs, odets = pu.compare_stages(det, i, img, ("tag36h11",), K, 1)
+        errs += pu.compare_detections(res[i], odets)
+        assert not errs, (i, errs[:3])
+    det.close()
+    assert flags == [0, 0, 0, 0]
+    assert len(res[0]) == 10 and res[1] == [] and len(res[3]) == 10
+
+
+def test_large_single_cluster_uses_global_sort_path(built):
+    """One component pair with 27 000 boundary points (4K frame, where clusters up to 36 000 points are
+    legal): larger than the 16 384-key LDS sort of the biggest size class, so the quad fit sorts in
+    global scratch; result still equals the oracle."""
+    W, H = 3840, 2160
+    img = np.full((H, W), 200, dtype=np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    ang = np.arctan2(yy - H / 2, xx - W / 2)
+    rad = np.hypot(yy - H / 2, xx - W / 2)
+    img[rad < 600 + 100 * np.sin(24 * ang)] = 30   # wavy star: long boundary, one black/white pair
+    K = synth.default_K(W, H)
+    det, g = _run(img, K)
+    cl = det.debug(0, capi.DBG_CLUSTERS)
+    errs, odets = pu.compare_stages(det, 0, img, ("tag36h11",), K, 1)
+    errs += pu.compare_detections(g, odets)
+    det.close()
+    assert not errs, errs[:3]
+    assert len(cl) == 1 and 16384 < cl["count"].max() <= 36000
