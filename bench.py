@@ -178,6 +178,19 @@ def main():
             det.run_prepared(cprep)
         clean = args.batch * args.steps / (time.perf_counter() - tc)
     det.close()
+    # informational: same noisy frames at AprilRobotics' default quad_decimate = 2
+    dec2 = None
+    if args.decimate == 1 and not args.no_clean:
+        d2 = AprilTagDetector(W, H, families=("tag36h11",), decimate=2, intrinsics=(sp["fx"], sp["fy"], sp["cx"], sp["cy"]),
+                              tag_size=sp["tag_size"], max_batch=args.batch, device=local_rank)
+        p2 = d2.prepare(batch, max_dets=64)
+        d2.run_prepared(p2)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(args.steps):
+            d2.run_prepared(p2)
+        dec2 = args.batch * args.steps / (time.perf_counter() - tc)
+        d2.close()
 
     if rank == 0:
         fps = world * args.batch * args.steps / dt
@@ -197,6 +210,8 @@ def main():
         }
         if clean is not None:
             rec["fps_per_gpu_same_scenes_sigma0"] = round(clean, 1)
+        if dec2 is not None:
+            rec["fps_per_gpu_same_frames_decimate2"] = round(dec2, 1)
         byframe = None
         if not args.no_cpu_baseline:
             rec["cpu_baseline"], byframe = cpu_baseline(frames_np, K, args.decimate, sp["tag_size"])

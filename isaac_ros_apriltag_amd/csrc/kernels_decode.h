@@ -390,19 +390,27 @@ __global__ __launch_bounds__(64) void k_reconcile(const FrameDesc* __restrict__ 
   DetRec* out = out_all + (size_t)frame * P.dcap;
   uint16_t* order = order_all + (size_t)frame * P.dcap;
   __shared__ uint32_t s_nout;
+  // rank sort by the canonical preference order: every lane counts the records that precede its own
+  // (ties cannot occur between distinct records except exact duplicates, broken by index)
+  for (uint32_t a = threadIdx.x; a < nd; a += 64) {
+    uint32_t rank = 0;
+    for (uint32_t b = 0; b < nd; b++)
+      if (b != a && (det_before_dev(&dets[b], &dets[a]) || (!det_before_dev(&dets[a], &dets[b]) && b < a))) rank++;
+    order[rank] = (uint16_t)a;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    // insertion sort of indices by the canonical preference order
-    for (uint32_t a = 0; a < nd; a++) {
-      int b = (int)a - 1;
-      while (b >= 0 && det_before_dev(&dets[a], &dets[order[b]])) { order[b + 1] = order[b]; b--; }
-      order[b + 1] = (uint16_t)a;
-    }
-    // keep a detection unless an already-kept one with the same family+id overlaps it
-    uint32_t nk = 0;
+    // keep a detection unless an already-kept one with the same family+id overlaps it; records of one
+    // (family, id) are contiguous in the order, so only that run is scanned
+    uint32_t nk = 0, run_start = 0;
     for (uint32_t i = 0; i < nd; i++) {
       const DetRec* di = &dets[order[i]];
+      if (nk > 0) {
+        const DetRec* dl = &dets[order[nk - 1]];
+        if (dl->family != di->family || dl->id != di->id) run_start = nk;
+      }
       bool dead = false;
-      for (uint32_t j = 0; j < nk && !dead; j++) {
+      for (uint32_t j = run_start; j < nk && !dead; j++) {
         const DetRec* dj = &dets[order[j]];
         if (dj->family == di->family && dj->id == di->id && quads_overlap_dev(dj->p, di->p)) dead = true;
       }
