@@ -62,6 +62,20 @@ __device__ __forceinline__ U128 u128_add(U128 a, U128 b) {
   r.hi = a.hi + b.hi + (r.lo < a.lo ? 1ull : 0ull);
   return r;
 }
+// DPP move of a 128-bit value: CTRL 0x110+n = row_shr:n, 0x142 = row_bcast:15, 0x143 = row_bcast:31;
+// lanes without a source (or masked rows) receive zero
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ U128 u128_dpp(U128 v) {
+  uint32_t a0 = (uint32_t)v.lo, a1 = (uint32_t)(v.lo >> 32), a2 = (uint32_t)v.hi, a3 = (uint32_t)(v.hi >> 32);
+  a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a0, CTRL, ROW_MASK, 0xF, true);
+  a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a1, CTRL, ROW_MASK, 0xF, true);
+  a2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a2, CTRL, ROW_MASK, 0xF, true);
+  a3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a3, CTRL, ROW_MASK, 0xF, true);
+  U128 r;
+  r.lo = (unsigned long long)a0 | ((unsigned long long)a1 << 32);
+  r.hi = (unsigned long long)a2 | ((unsigned long long)a3 << 32);
+  return r;
+}
 // value * 2^52 of a double >= 1 (every moment term is: W >= 1, x,y >= 1) and < 2^64
 __device__ __forceinline__ U128 exact_to_fixed(double t) {
   const unsigned long long bits = (unsigned long long)__double_as_longlong(t);
@@ -360,15 +374,16 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : (NT == 64 ? 4 : 2))) void k_fi
         v[5] = exact_to_fixed(Wt);
       }
       const int lane = lane_id(), wv = tid >> 6;
+      // wave-inclusive scan with DPP lane shifts (row_shr 1/2/4/8 inside each row of 16, then the row
+      // broadcasts 15 and 31): out-of-range sources read as zero, so no per-step select is needed
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-          U128 n;
-          n.lo = __shfl_up(v[j].lo, off, 64);
-          n.hi = __shfl_up(v[j].hi, off, 64);
-          if (lane >= off) v[j] = u128_add(v[j], n);
-        }
+      for (int j = 0; j < 6; j++) {
+        v[j] = u128_add(v[j], u128_dpp<0x111, 0xF>(v[j]));
+        v[j] = u128_add(v[j], u128_dpp<0x112, 0xF>(v[j]));
+        v[j] = u128_add(v[j], u128_dpp<0x114, 0xF>(v[j]));
+        v[j] = u128_add(v[j], u128_dpp<0x118, 0xF>(v[j]));
+        v[j] = u128_add(v[j], u128_dpp<0x142, 0xA>(v[j]));
+        v[j] = u128_add(v[j], u128_dpp<0x143, 0xC>(v[j]));
       }
       if (NW > 1) {
         if (lane == 63) {
