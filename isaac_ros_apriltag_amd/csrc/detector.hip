@@ -471,14 +471,28 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
     // four size classes: one wave per small cluster, bigger workgroups and LDS key arrays above
     struct FqClass { int nt, cap, lo, hi; unsigned gx; };
     auto clampu = [](unsigned v, unsigned a, unsigned b) { return v < a ? a : (v > b ? b : v); };
-    const FqClass cls[4] = {{64, 256, 0, 256, clampu(16384u / n, 128u, 4096u)},
-                            {256, 1024, 256, 1024, clampu(4096u / n, 64u, 1024u)},
-                            {256, 4096, 1024, 4096, clampu(1024u / n, 32u, 512u)},
-                            {512, 16384, 4096, 0x7FFFFFFF, clampu(512u / n, 16u, 256u)}};
+    FqClass cls[4] = {{64, 256, 0, 256, clampu(32768u / n, 128u, 4096u)},
+                      {128, 1024, 256, 1024, clampu(16384u / n, 64u, 2048u)},
+                      {256, 4096, 1024, 4096, clampu(2048u / n, 32u, 512u)},
+                      {512, 16384, 4096, 0x7FFFFFFF, clampu(512u / n, 16u, 256u)}};
+    if (const char* ov = getenv("AMDAT_FQ_CLASSES")) {  // tuning override: "nt:cap:gxbudget" x 4 (size bounds follow cap)
+      int nt[4], cap[4], bud[4];
+      if (sscanf(ov, "%d:%d:%d,%d:%d:%d,%d:%d:%d,%d:%d:%d", &nt[0], &cap[0], &bud[0], &nt[1], &cap[1], &bud[1], &nt[2], &cap[2],
+                 &bud[2], &nt[3], &cap[3], &bud[3]) == 12) {
+        int lo = 0;
+        for (int c = 0; c < 4; c++) {
+          cls[c].nt = nt[c]; cls[c].cap = cap[c]; cls[c].lo = lo; cls[c].hi = (c == 3) ? 0x7FFFFFFF : cap[c];
+          cls[c].gx = clampu((unsigned)bud[c] / n, 16u, 4096u);
+          lo = cap[c];
+        }
+      }
+    }
     auto lds_bytes = [](const FqClass& c) { return (size_t)c.cap * 8 + (size_t)1024 * 8; };
     if (!D->fq_attr_set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds_bytes(cls[3])));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150000));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150000));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 150000));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150000));
       D->fq_attr_set = true;
     }
     for (int c = 0; c < 4; c++) {
@@ -488,6 +502,7 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
 #define FQ_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_keys, D->d_lf, D->d_errs_a, D->d_errs_b, D->d_quads, \
                 D->d_counters, ((D->fq_counters && D->d_fqprof) ? D->d_fqprof + 8 * c : nullptr), cls[c].cap, cls[c].lo, cls[c].hi, P
       if (cls[c].nt == 64) hipLaunchKernelGGL(k_fit_quads<64>, grid, dim3(64), lds, s, FQ_ARGS);
+      else if (cls[c].nt == 128) hipLaunchKernelGGL(k_fit_quads<128>, grid, dim3(128), lds, s, FQ_ARGS);
       else if (cls[c].nt == 256) hipLaunchKernelGGL(k_fit_quads<256>, grid, dim3(256), lds, s, FQ_ARGS);
       else hipLaunchKernelGGL(k_fit_quads<512>, grid, dim3(512), lds, s, FQ_ARGS);
 #undef FQ_ARGS

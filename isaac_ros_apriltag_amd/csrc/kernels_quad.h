@@ -204,7 +204,7 @@ __device__ __forceinline__ uint32_t combo_of(int t) {
 // tables.  Clusters with size in (size_lo, size_hi] are processed by this
 // launch; those above sort_cap (only possible in the last class) sort in global scratch.
 template <int NT>
-__global__ __launch_bounds__(NT, (NT == 256 ? 4 : (NT == 64 ? 4 : 2))) void k_fit_quads(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
+__global__ __launch_bounds__(NT, (NT <= 256 ? 4 : 2)) void k_fit_quads(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
                                                    const uint32_t* __restrict__ pts_all, const ClusterRec* __restrict__ clusters_all,
                                                    unsigned long long* __restrict__ keys_all, double* __restrict__ lf_all,
                                                    double* __restrict__ errs_a_all, double* __restrict__ errs_b_all,
