@@ -193,7 +193,7 @@ void ato_connected_components(const uint8_t* thr, int w, int h, uint32_t* label,
 /* ------------------------------------------------------------------------------------------- */
 typedef struct { uint64_t key; uint32_t pt; } kp_t;
 
-static int kp_cmp(const void* a, const void* b) {
+static __attribute__((unused)) int kp_cmp(const void* a, const void* b) {
   const kp_t* x = (const kp_t*)a; const kp_t* y = (const kp_t*)b;
   if (x->key != y->key) return x->key < y->key ? -1 : 1;
   if (x->pt != y->pt) return x->pt < y->pt ? -1 : 1;
@@ -211,7 +211,7 @@ static inline void unpack_point(uint32_t p, int* x, int* y, int* gx, int* gy) {
   *gy = ((int)(p & 3) - 1) * 255;
 }
 
-/* Collects every boundary point with its component-pair key, sorted by (key, packed point). */
+/* Collects every boundary point with its component-pair key (raster order; grouped by group_points). */
 static kp_t* gradient_points(const uint8_t* thr, const uint32_t* label, const uint32_t* csize, int w, int h,
                              int min_comp, size_t* nout) {
   static const int DX[4] = {1, 0, -1, 1}, DY[4] = {0, 1, 1, 1};
@@ -245,9 +245,77 @@ static kp_t* gradient_points(const uint8_t* thr, const uint32_t* label, const ui
       connected_last = connected;
     }
   }
-  qsort(pts, n, sizeof(kp_t), kp_cmp);
   *nout = n;
   return pts;
+}
+
+/* Groups the points by key with an open-addressing hash (upstream uses a hash map as well): fills
+ * clusters[] (sorted by key afterwards, CANONICAL) and pts_out[] (points of a cluster contiguous). */
+static uint32_t u32_cmp_store;
+static int u32_cmp(const void* a, const void* b) {
+  uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
+  (void)u32_cmp_store;
+  return (x > y) - (x < y);
+}
+static int cluster_key_cmp(const void* a, const void* b) {
+  const ato_cluster_t* x = (const ato_cluster_t*)a; const ato_cluster_t* y = (const ato_cluster_t*)b;
+  return (x->key > y->key) - (x->key < y->key);
+}
+static size_t group_points(const kp_t* kp, size_t n, ato_cluster_t** clusters_out, uint32_t* pts_out, int sort_points) {
+  size_t cap = 1024;
+  while (cap < n / 4 + 16) cap <<= 1;
+  uint64_t* hk = (uint64_t*)malloc(cap * 8);
+  uint32_t* hi = (uint32_t*)malloc(cap * 4);
+  memset(hk, 0xFF, cap * 8);
+  size_t ccap = 1024, nc = 0;
+  ato_cluster_t* cl = (ato_cluster_t*)malloc(ccap * sizeof(ato_cluster_t));
+  uint32_t* cidx = (uint32_t*)malloc((n ? n : 1) * 4);
+  for (size_t i = 0; i < n; i++) {
+    uint64_t key = kp[i].key;
+    size_t h = (size_t)((key * 0x9E3779B97F4A7C15ULL) >> 20) & (cap - 1);
+    while (hk[h] != key && hk[h] != ~0ULL) h = (h + 1) & (cap - 1);
+    if (hk[h] == ~0ULL) {
+      if (nc * 2 > cap) {  /* cannot happen with cap >= n/4 unless nearly every point is its own pair; grow by rebuild */
+        size_t ncap = cap * 4;
+        uint64_t* nk = (uint64_t*)malloc(ncap * 8);
+        uint32_t* ni = (uint32_t*)malloc(ncap * 4);
+        memset(nk, 0xFF, ncap * 8);
+        for (size_t j = 0; j < cap; j++)
+          if (hk[j] != ~0ULL) {
+            size_t g = (size_t)((hk[j] * 0x9E3779B97F4A7C15ULL) >> 20) & (ncap - 1);
+            while (nk[g] != ~0ULL) g = (g + 1) & (ncap - 1);
+            nk[g] = hk[j]; ni[g] = hi[j];
+          }
+        free(hk); free(hi);
+        hk = nk; hi = ni; cap = ncap;
+        h = (size_t)((key * 0x9E3779B97F4A7C15ULL) >> 20) & (cap - 1);
+        while (hk[h] != ~0ULL) h = (h + 1) & (cap - 1);
+      }
+      if (nc == ccap) { ccap *= 2; cl = (ato_cluster_t*)realloc(cl, ccap * sizeof(ato_cluster_t)); }
+      hk[h] = key; hi[h] = (uint32_t)nc;
+      cl[nc].key = key; cl[nc].start = 0; cl[nc].count = 0;
+      nc++;
+    }
+    cidx[i] = hi[h];
+    cl[hi[h]].count++;
+  }
+  /* canonical cluster order: by key; remap through a rank table */
+  uint32_t* rank = (uint32_t*)malloc((nc ? nc : 1) * 4);
+  ato_cluster_t* sorted = (ato_cluster_t*)malloc((nc ? nc : 1) * sizeof(ato_cluster_t));
+  for (size_t c = 0; c < nc; c++) { sorted[c] = cl[c]; sorted[c].start = (uint32_t)c; }  /* start temporarily = old index */
+  qsort(sorted, nc, sizeof(ato_cluster_t), cluster_key_cmp);
+  uint32_t off = 0;
+  for (size_t c = 0; c < nc; c++) { rank[sorted[c].start] = (uint32_t)c; sorted[c].start = off; off += sorted[c].count; }
+  uint32_t* fill = (uint32_t*)calloc(nc ? nc : 1, 4);
+  for (size_t i = 0; i < n; i++) {
+    uint32_t c = rank[cidx[i]];
+    pts_out[sorted[c].start + fill[c]++] = kp[i].pt;
+  }
+  if (sort_points)
+    for (size_t c = 0; c < nc; c++) qsort(pts_out + sorted[c].start, sorted[c].count, 4, u32_cmp);
+  free(hk); free(hi); free(cl); free(cidx); free(rank); free(fill);
+  *clusters_out = sorted;
+  return nc;
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -951,19 +1019,20 @@ int ato_detect(const ato_params_t* prm, const ato_family_t* fams, int nfam, cons
   size_t qcap = 64, nq = 0;
   ato_quad_t* quads = (ato_quad_t*)malloc(qcap * sizeof(ato_quad_t));
   uint32_t* ptsbuf = (uint32_t*)malloc((npts ? npts : 1) * 4);
-  size_t ccap = 64, nc = 0, npk = 0;
-  ato_cluster_t* clusters = (ato_cluster_t*)malloc(ccap * sizeof(ato_cluster_t));
-  for (size_t i = 0; i < npts;) {
-    size_t j = i;
-    while (j < npts && kp[j].key == kp[i].key) j++;
-    size_t cnt = j - i;
+  ato_cluster_t* all_clusters = NULL;
+  size_t nall = group_points(kp, npts, &all_clusters, ptsbuf, dump != NULL);
+  /* kept clusters are compacted to the front of ptsbuf (their points stay contiguous) */
+  size_t nc = 0, npk = 0;
+  ato_cluster_t* clusters = (ato_cluster_t*)malloc((nall ? nall : 1) * sizeof(ato_cluster_t));
+  for (size_t ci = 0; ci < nall; ci++) {
+    size_t cnt = all_clusters[ci].count;
     if (cnt >= (size_t)prm->min_cluster_points && cnt <= maxpts) {
-      if (nc == ccap) { ccap *= 2; clusters = (ato_cluster_t*)realloc(clusters, ccap * sizeof(ato_cluster_t)); }
-      clusters[nc].key = kp[i].key; clusters[nc].start = (uint32_t)npk; clusters[nc].count = (uint32_t)cnt; nc++;
-      for (size_t k = i; k < j; k++) ptsbuf[npk++] = kp[k].pt;
+      if (npk != all_clusters[ci].start) memmove(&ptsbuf[npk], &ptsbuf[all_clusters[ci].start], cnt * 4);
+      clusters[nc].key = all_clusters[ci].key; clusters[nc].start = (uint32_t)npk; clusters[nc].count = (uint32_t)cnt; nc++;
+      npk += cnt;
       ato_quad_t q;
       memset(&q, 0, sizeof(q));
-      q.key = kp[i].key;
+      q.key = all_clusters[ci].key;
       if (fit_quad(prm, gray, w, h, &ptsbuf[npk - cnt], (int)cnt, min_tag_width, normal_border, reversed_border, &q)) {
         if (f > 1)
           for (int c = 0; c < 4; c++) {
@@ -974,8 +1043,8 @@ int ato_detect(const ato_params_t* prm, const ato_family_t* fams, int nfam, cons
         quads[nq++] = q;
       }
     }
-    i = j;
   }
+  free(all_clusters);
   free(kp);
   qsort(quads, nq, sizeof(ato_quad_t), quad_key_cmp);
 
