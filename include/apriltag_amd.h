@@ -208,7 +208,7 @@ typedef enum {
   AMDAT_DBG_POINTS = 5,    /* u32 packed points, grouped by cluster */
   AMDAT_DBG_QUADS = 6,     /* {float p[4][2]; i32 reversed_border; u32 pad; u64 key} x nquads */
   AMDAT_DBG_COUNTS = 7,    /* u32[8]: npoints_raw, nclusters, npoints_kept, nquads, ndets, flags, w, h */
-  AMDAT_DBG_FQPROF = 8     /* u64[32]: shader-cycle totals, 8 phases x 4 size classes of the quad-fit kernel (profiling on) */
+  AMDAT_DBG_FQPROF = 8     /* u64[64]: shader-cycle totals, 8 phases x up to 8 size classes of the quad-fit kernel (profiling on) */
 } amdAprilTagsDebugBuffer;
 /* Copies an intermediate buffer of frame `frame` of the last submission to host memory.
  * Returns the number of bytes the buffer holds through *bytes (copy truncated to capacity). */

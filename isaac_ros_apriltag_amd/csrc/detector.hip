@@ -87,6 +87,8 @@ struct amdAprilTagsDetector_st {
   DetParams P;
   int device = 0;
   hipStream_t own_stream = nullptr;
+  hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};  // size classes of the quad fit run concurrently
+  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   // device buffers
   uint8_t* d_gray = nullptr;
   uint8_t* d_thr = nullptr;
@@ -221,6 +223,9 @@ static void free_all(amdAprilTagsDetector_st* D) {
   if (D->h_out) hipHostFree(D->h_out);
   for (auto& e : D->ev) if (e) hipEventDestroy(e);
   if (D->own_stream) hipStreamDestroy(D->own_stream);
+  for (auto& a : D->aux_stream) if (a) hipStreamDestroy(a);
+  if (D->ev_fork) hipEventDestroy(D->ev_fork);
+  for (auto& e : D->ev_join) if (e) hipEventDestroy(e);
 }
 
 int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsConfig_t* cfg_in) {
@@ -320,6 +325,9 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   if (ok && hipHostMalloc((void**)&D->h_out, B * (size_t)P.dcap * sizeof(DetRec)) != hipSuccess) ok = false;
   if (ok && hipStreamCreateWithFlags(&D->own_stream, hipStreamNonBlocking) != hipSuccess) ok = false;
   for (auto& e : D->ev) if (ok && hipEventCreate(&e) != hipSuccess) ok = false;
+  for (auto& a : D->aux_stream) if (ok && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) ok = false;
+  if (ok && hipEventCreateWithFlags(&D->ev_fork, hipEventDisableTiming) != hipSuccess) ok = false;
+  for (auto& e : D->ev_join) if (ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
   if (ok && D->d_thr) {
     // the padding columns of the working images are read by vector loads; define them once
     if (hipMemset(D->d_thr, 127, B * (size_t)H * P.WS) != hipSuccess) ok = false;
@@ -464,25 +472,27 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
   }
   mark();
   if (D->fq_counters && !D->d_fqprof) {
-    if (hipMalloc((void**)&D->d_fqprof, 32 * 8) != hipSuccess) D->d_fqprof = nullptr;
+    if (hipMalloc((void**)&D->d_fqprof, 64 * 8) != hipSuccess) D->d_fqprof = nullptr;
   }
-  if (D->fq_counters && D->d_fqprof) HIP_TRY(hipMemsetAsync(D->d_fqprof, 0, 32 * 8, s));
+  if (D->fq_counters && D->d_fqprof) HIP_TRY(hipMemsetAsync(D->d_fqprof, 0, 64 * 8, s));
   {
-    // four size classes: one wave per small cluster, bigger workgroups and LDS key arrays above
+    // five size classes: one wave per small cluster, bigger workgroups and LDS key arrays above
     struct FqClass { int nt, cap, lo, hi; unsigned gx; };
     auto clampu = [](unsigned v, unsigned a, unsigned b) { return v < a ? a : (v > b ? b : v); };
-    FqClass cls[4] = {{64, 256, 0, 256, clampu(32768u / n, 128u, 4096u)},
-                      {128, 1024, 256, 1024, clampu(16384u / n, 64u, 2048u)},
-                      {256, 4096, 1024, 4096, clampu(2048u / n, 32u, 512u)},
-                      {512, 16384, 4096, 0x7FFFFFFF, clampu(512u / n, 16u, 256u)}};
-    if (const char* ov = getenv("AMDAT_FQ_CLASSES")) {  // tuning override: "nt:cap:gxbudget" x 4 (size bounds follow cap)
-      int nt[4], cap[4], bud[4];
-      if (sscanf(ov, "%d:%d:%d,%d:%d:%d,%d:%d:%d,%d:%d:%d", &nt[0], &cap[0], &bud[0], &nt[1], &cap[1], &bud[1], &nt[2], &cap[2],
-                 &bud[2], &nt[3], &cap[3], &bud[3]) == 12) {
+    constexpr int NCLS = 5;
+    FqClass cls[NCLS] = {{64, 256, 0, 256, clampu(32768u / n, 128u, 4096u)},
+                         {128, 1024, 256, 1024, clampu(16384u / n, 64u, 2048u)},
+                         {256, 4096, 1024, 4096, clampu(2048u / n, 32u, 512u)},
+                         {512, 8192, 4096, 8192, clampu(1024u / n, 16u, 256u)},
+                         {512, 16384, 8192, 0x7FFFFFFF, clampu(512u / n, 8u, 256u)}};
+    if (const char* ov = getenv("AMDAT_FQ_CLASSES")) {  // tuning override: "nt:cap:gxbudget" x 5 (size bounds follow cap)
+      int nt[NCLS], cap[NCLS], bud[NCLS];
+      if (sscanf(ov, "%d:%d:%d,%d:%d:%d,%d:%d:%d,%d:%d:%d,%d:%d:%d", &nt[0], &cap[0], &bud[0], &nt[1], &cap[1], &bud[1], &nt[2],
+                 &cap[2], &bud[2], &nt[3], &cap[3], &bud[3], &nt[4], &cap[4], &bud[4]) == 15) {
         int lo = 0;
-        for (int c = 0; c < 4; c++) {
-          cls[c].nt = nt[c]; cls[c].cap = cap[c]; cls[c].lo = lo; cls[c].hi = (c == 3) ? 0x7FFFFFFF : cap[c];
-          cls[c].gx = clampu((unsigned)bud[c] / n, 16u, 4096u);
+        for (int c = 0; c < NCLS; c++) {
+          cls[c].nt = nt[c]; cls[c].cap = cap[c]; cls[c].lo = lo; cls[c].hi = (c == NCLS - 1) ? 0x7FFFFFFF : cap[c];
+          cls[c].gx = clampu((unsigned)bud[c] / n, 8u, 4096u);
           lo = cap[c];
         }
       }
@@ -495,17 +505,35 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150000));
       D->fq_attr_set = true;
     }
-    for (int c = 0; c < 4; c++) {
+    // The classes are independent (they only append to the quad list), so they run concurrently: class
+    // 0 stays on the submission stream, the others fork to auxiliary streams and join before decode.
+    // Small-cluster waves fill the CUs that the one-workgroup-per-CU big-cluster class leaves mostly idle.
+    const bool fork = getenv("AMDAT_FQ_SERIAL") == nullptr;
+    if (fork) HIP_TRY(hipEventRecord(D->ev_fork, s));
+    int nlaunched = 0;
+    for (int c = 0; c < NCLS; c++) {
       if (P.max_cluster_points <= cls[c].lo) break;
       const dim3 grid(cls[c].gx, n);
       const size_t lds = lds_bytes(cls[c]);
+      hipStream_t sc = s;
+      if (fork && c > 0) {
+        sc = D->aux_stream[(c - 1) & 3];
+        HIP_TRY(hipStreamWaitEvent(sc, D->ev_fork, 0));
+      }
 #define FQ_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_keys, D->d_lf, D->d_errs_a, D->d_errs_b, D->d_quads, \
                 D->d_counters, ((D->fq_counters && D->d_fqprof) ? D->d_fqprof + 8 * c : nullptr), cls[c].cap, cls[c].lo, cls[c].hi, P
-      if (cls[c].nt == 64) hipLaunchKernelGGL(k_fit_quads<64>, grid, dim3(64), lds, s, FQ_ARGS);
-      else if (cls[c].nt == 128) hipLaunchKernelGGL(k_fit_quads<128>, grid, dim3(128), lds, s, FQ_ARGS);
-      else if (cls[c].nt == 256) hipLaunchKernelGGL(k_fit_quads<256>, grid, dim3(256), lds, s, FQ_ARGS);
-      else hipLaunchKernelGGL(k_fit_quads<512>, grid, dim3(512), lds, s, FQ_ARGS);
+      if (cls[c].nt == 64) hipLaunchKernelGGL(k_fit_quads<64>, grid, dim3(64), lds, sc, FQ_ARGS);
+      else if (cls[c].nt == 128) hipLaunchKernelGGL(k_fit_quads<128>, grid, dim3(128), lds, sc, FQ_ARGS);
+      else if (cls[c].nt == 256) hipLaunchKernelGGL(k_fit_quads<256>, grid, dim3(256), lds, sc, FQ_ARGS);
+      else hipLaunchKernelGGL(k_fit_quads<512>, grid, dim3(512), lds, sc, FQ_ARGS);
 #undef FQ_ARGS
+      nlaunched = c + 1;
+    }
+    if (fork) {
+      for (int c = 1; c < nlaunched; c++) {
+        HIP_TRY(hipEventRecord(D->ev_join[(c - 1) & 3], D->aux_stream[(c - 1) & 3]));
+        HIP_TRY(hipStreamWaitEvent(s, D->ev_join[(c - 1) & 3], 0));
+      }
     }
   }
   mark();
@@ -705,7 +733,7 @@ int amdAprilTagsDebugCopy(amdAprilTagsHandle handle, uint32_t frame, amdAprilTag
       break;
     case AMDAT_DBG_FQPROF:
       if (!handle->d_fqprof) { *bytes = 0; return AMDAT_SUCCESS; }
-      src = handle->d_fqprof; sz = 32 * 8;
+      src = handle->d_fqprof; sz = 64 * 8;
       break;
     case AMDAT_DBG_COUNTS: {
       uint32_t c[8] = {fc.npoints_raw, fc.nclusters, fc.npoints_kept, fc.nquads, fc.ndets, fc.flags, (uint32_t)P.W, (uint32_t)P.H};
