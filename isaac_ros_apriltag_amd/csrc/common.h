@@ -63,6 +63,7 @@ struct FamilyDev {
 
 // Geometry + algorithm parameters shared by all kernels of a handle.
 struct DetParams {
+  int frame0;        // first batch slot of this launch (a submission may be split into concurrent halves)
   int W0, H0;        // input size
   int W, H;          // working (decimated) size
   int WS;            // pitch of the working u8 images (multiple of 16)

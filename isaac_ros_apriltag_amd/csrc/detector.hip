@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -87,8 +88,11 @@ struct amdAprilTagsDetector_st {
   DetParams P;
   int device = 0;
   hipStream_t own_stream = nullptr;
-  hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};  // size classes of the quad fit run concurrently
-  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+  // Inside a lane the size classes of the quad fit fork to auxiliary streams and join before decode.
+  // A second lane exists for the opt-in half-batch experiment (AMDAT_SPLIT, see run_batch).
+  hipStream_t lane_stream = nullptr;  // main stream of lane 1 (lane 0 uses the submission stream)
+  hipStream_t aux_stream[2][4] = {};
+  hipEvent_t ev_fork[2] = {}, ev_join[2][4] = {}, ev_lane_begin = nullptr, ev_lane_end = nullptr;
   // device buffers
   uint8_t* d_gray = nullptr;
   uint8_t* d_thr = nullptr;
@@ -223,9 +227,12 @@ static void free_all(amdAprilTagsDetector_st* D) {
   if (D->h_out) hipHostFree(D->h_out);
   for (auto& e : D->ev) if (e) hipEventDestroy(e);
   if (D->own_stream) hipStreamDestroy(D->own_stream);
-  for (auto& a : D->aux_stream) if (a) hipStreamDestroy(a);
-  if (D->ev_fork) hipEventDestroy(D->ev_fork);
-  for (auto& e : D->ev_join) if (e) hipEventDestroy(e);
+  for (auto& l : D->aux_stream) for (auto& a : l) if (a) hipStreamDestroy(a);
+  for (auto& e : D->ev_fork) if (e) hipEventDestroy(e);
+  for (auto& l : D->ev_join) for (auto& e : l) if (e) hipEventDestroy(e);
+  if (D->lane_stream) hipStreamDestroy(D->lane_stream);
+  if (D->ev_lane_begin) hipEventDestroy(D->ev_lane_begin);
+  if (D->ev_lane_end) hipEventDestroy(D->ev_lane_end);
 }
 
 int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsConfig_t* cfg_in) {
@@ -325,9 +332,12 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   if (ok && hipHostMalloc((void**)&D->h_out, B * (size_t)P.dcap * sizeof(DetRec)) != hipSuccess) ok = false;
   if (ok && hipStreamCreateWithFlags(&D->own_stream, hipStreamNonBlocking) != hipSuccess) ok = false;
   for (auto& e : D->ev) if (ok && hipEventCreate(&e) != hipSuccess) ok = false;
-  for (auto& a : D->aux_stream) if (ok && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) ok = false;
-  if (ok && hipEventCreateWithFlags(&D->ev_fork, hipEventDisableTiming) != hipSuccess) ok = false;
-  for (auto& e : D->ev_join) if (ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
+  for (auto& l : D->aux_stream) for (auto& a : l) if (ok && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) ok = false;
+  for (auto& e : D->ev_fork) if (ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
+  for (auto& l : D->ev_join) for (auto& e : l) if (ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
+  if (ok && hipStreamCreateWithFlags(&D->lane_stream, hipStreamNonBlocking) != hipSuccess) ok = false;
+  if (ok && hipEventCreateWithFlags(&D->ev_lane_begin, hipEventDisableTiming) != hipSuccess) ok = false;
+  if (ok && hipEventCreateWithFlags(&D->ev_lane_end, hipEventDisableTiming) != hipSuccess) ok = false;
   if (ok && D->d_thr) {
     // the padding columns of the working images are read by vector loads; define them once
     if (hipMemset(D->d_thr, 127, B * (size_t)H * P.WS) != hipSuccess) ok = false;
@@ -399,52 +409,35 @@ static void fill_frames(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTa
   }
 }
 
-static void launch_threshold(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s) {
-  const DetParams& P = D->P;
+static void launch_threshold(amdAprilTagsDetector_st* D, const DetParams& P, uint32_t n, hipStream_t s) {
   const int gx = ((P.W + 3) / 4 + 127) / 128, gy = ((P.H + 3) / 4 + 7) / 8;
   const unsigned ntiles = (unsigned)gx * gy * n;
   dim3 grid(8u * ((ntiles + 7u) / 8u));
   const bool leftover = (P.W % 4) || (P.H % 4);
   const int nleft = (P.W - P.tw * 4) * (P.th * 4) + (P.H - P.th * 4) * P.W;
   dim3 lgrid((unsigned)((nleft + 255) / 256), 1, n);
+#define TH_LAUNCH(DEC)                                                                                                   \
+  hipLaunchKernelGGL(k_threshold<DEC>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, gx, gy, (int)n, P);     \
+  if (leftover) hipLaunchKernelGGL(k_threshold_leftover<DEC>, lgrid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
   switch (P.decimate) {
-    case 1:
-      hipLaunchKernelGGL(k_threshold<1>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, gx, gy, (int)n, P);
-      if (leftover) hipLaunchKernelGGL(k_threshold_leftover<1>, lgrid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
-      break;
-    case 2:
-      hipLaunchKernelGGL(k_threshold<2>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, gx, gy, (int)n, P);
-      if (leftover) hipLaunchKernelGGL(k_threshold_leftover<2>, lgrid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
-      break;
-    case 3:
-      hipLaunchKernelGGL(k_threshold<3>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, gx, gy, (int)n, P);
-      if (leftover) hipLaunchKernelGGL(k_threshold_leftover<3>, lgrid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
-      break;
-    default:
-      hipLaunchKernelGGL(k_threshold<4>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, gx, gy, (int)n, P);
-      if (leftover) hipLaunchKernelGGL(k_threshold_leftover<4>, lgrid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
-      break;
+    case 1: TH_LAUNCH(1) break;
+    case 2: TH_LAUNCH(2) break;
+    case 3: TH_LAUNCH(3) break;
+    default: TH_LAUNCH(4) break;
   }
+#undef TH_LAUNCH
 }
 
-// One batched submission; results land in h_out / h_counters with `ostride` records per frame.
-static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images,
-                     const amdAprilTagsCameraIntrinsics_t* intr, uint32_t ostride, hipStream_t s) {
-  const DetParams& P = D->P;
-  HIP_TRY(hipSetDevice(D->device));
-  fill_frames(D, n, images, intr);
-  D->last_n = n;
-  const bool prof = D->profiling;
-  int evi = 0;
-  auto mark = [&]() { if (prof) hipEventRecord(D->ev[evi++], s); };
+struct FqClass { int nt, cap, lo, hi; unsigned gx; };
 
-  mark();
-  HIP_TRY(hipMemcpyAsync(D->d_frames, D->h_frames, n * sizeof(FrameDesc), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(D->d_counters, 0, n * sizeof(FrameCounters), s));
-  HIP_TRY(hipMemsetAsync(D->d_hkeys, 0xFF, (size_t)n * P.hcap * 8, s));
-  HIP_TRY(hipMemsetAsync(D->d_hcnt, 0, (size_t)n * P.hcap * 4, s));
-  mark();
-  launch_threshold(D, n, s);
+// Issues the whole stage sequence for batch slots [frame0, frame0 + n) on stream s.  `lane` selects the
+// auxiliary streams/events the quad-fit size classes fork to.  mark() is called between stages (event
+// timing of lane 0 when profiling).
+static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0, uint32_t n, uint32_t ostride, hipStream_t s,
+                          const std::function<void()>& mark) {
+  DetParams P = D->P;
+  P.frame0 = (int)frame0;
+  launch_threshold(D, P, n, s);
   mark();
   hipLaunchKernelGGL(k_cc_local, dim3((P.W + CC_T - 1) / CC_T, (P.H + CC_T - 1) / CC_T, n), dim3(256), 0, s, D->d_thr,
                      D->d_label, D->d_csize, P);
@@ -471,13 +464,8 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
     hipLaunchKernelGGL(k_scatter, dim3(gx, 1, n), dim3(256), 0, s, D->d_stage, D->d_rank, D->d_hoff, D->d_pts, D->d_counters, P);
   }
   mark();
-  if (D->fq_counters && !D->d_fqprof) {
-    if (hipMalloc((void**)&D->d_fqprof, 64 * 8) != hipSuccess) D->d_fqprof = nullptr;
-  }
-  if (D->fq_counters && D->d_fqprof) HIP_TRY(hipMemsetAsync(D->d_fqprof, 0, 64 * 8, s));
   {
     // five size classes: one wave per small cluster, bigger workgroups and LDS key arrays above
-    struct FqClass { int nt, cap, lo, hi; unsigned gx; };
     auto clampu = [](unsigned v, unsigned a, unsigned b) { return v < a ? a : (v > b ? b : v); };
     constexpr int NCLS = 5;
     FqClass cls[NCLS] = {{64, 256, 0, 256, clampu(32768u / n, 128u, 4096u)},
@@ -506,10 +494,10 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
       D->fq_attr_set = true;
     }
     // The classes are independent (they only append to the quad list), so they run concurrently: class
-    // 0 stays on the submission stream, the others fork to auxiliary streams and join before decode.
+    // 0 stays on the lane's stream, the others fork to auxiliary streams and join before decode.
     // Small-cluster waves fill the CUs that the one-workgroup-per-CU big-cluster class leaves mostly idle.
     const bool fork = getenv("AMDAT_FQ_SERIAL") == nullptr;
-    if (fork) HIP_TRY(hipEventRecord(D->ev_fork, s));
+    if (fork) HIP_TRY(hipEventRecord(D->ev_fork[lane], s));
     int nlaunched = 0;
     for (int c = 0; c < NCLS; c++) {
       if (P.max_cluster_points <= cls[c].lo) break;
@@ -517,8 +505,8 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
       const size_t lds = lds_bytes(cls[c]);
       hipStream_t sc = s;
       if (fork && c > 0) {
-        sc = D->aux_stream[(c - 1) & 3];
-        HIP_TRY(hipStreamWaitEvent(sc, D->ev_fork, 0));
+        sc = D->aux_stream[lane][(c - 1) & 3];
+        HIP_TRY(hipStreamWaitEvent(sc, D->ev_fork[lane], 0));
       }
 #define FQ_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_keys, D->d_lf, D->d_errs_a, D->d_errs_b, D->d_quads, \
                 D->d_counters, ((D->fq_counters && D->d_fqprof) ? D->d_fqprof + 8 * c : nullptr), cls[c].cap, cls[c].lo, cls[c].hi, P
@@ -531,8 +519,8 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
     }
     if (fork) {
       for (int c = 1; c < nlaunched; c++) {
-        HIP_TRY(hipEventRecord(D->ev_join[(c - 1) & 3], D->aux_stream[(c - 1) & 3]));
-        HIP_TRY(hipStreamWaitEvent(s, D->ev_join[(c - 1) & 3], 0));
+        HIP_TRY(hipEventRecord(D->ev_join[lane][(c - 1) & 3], D->aux_stream[lane][(c - 1) & 3]));
+        HIP_TRY(hipStreamWaitEvent(s, D->ev_join[lane][(c - 1) & 3], 0));
       }
     }
   }
@@ -546,6 +534,51 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
   mark();
   hipLaunchKernelGGL(k_reconcile, dim3(n), dim3(64), 0, s, D->d_frames, D->d_dets, D->d_out, D->d_counters, D->d_order, P);
   mark();
+  (void)ostride;
+  return AMDAT_SUCCESS;
+}
+
+// One batched submission; results land in h_out / h_counters with `ostride` records per frame.
+static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images,
+                     const amdAprilTagsCameraIntrinsics_t* intr, uint32_t ostride, hipStream_t s) {
+  const DetParams& P = D->P;
+  HIP_TRY(hipSetDevice(D->device));
+  fill_frames(D, n, images, intr);
+  D->last_n = n;
+  const bool prof = D->profiling;
+  int evi = 0;
+  const std::function<void()> mark = [&]() { if (prof) hipEventRecord(D->ev[evi++], s); };
+  const std::function<void()> nomark = []() {};
+
+  mark();
+  HIP_TRY(hipMemcpyAsync(D->d_frames, D->h_frames, n * sizeof(FrameDesc), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(D->d_counters, 0, n * sizeof(FrameCounters), s));
+  HIP_TRY(hipMemsetAsync(D->d_hkeys, 0xFF, (size_t)n * P.hcap * 8, s));
+  HIP_TRY(hipMemsetAsync(D->d_hcnt, 0, (size_t)n * P.hcap * 4, s));
+  if (D->fq_counters && !D->d_fqprof) {
+    if (hipMalloc((void**)&D->d_fqprof, 64 * 8) != hipSuccess) D->d_fqprof = nullptr;
+  }
+  if (D->fq_counters && D->d_fqprof) HIP_TRY(hipMemsetAsync(D->d_fqprof, 0, 64 * 8, s));
+  mark();
+  // Opt-in experiment (AMDAT_SPLIT=1): run a large submission as two concurrent halves so that stages
+  // with different bottlenecks overlap.  Measured SLOWER on MI355X (2.95k vs 3.30k frames/s at sigma 2,
+  // 21k vs 26k noise-free): every kernel already fills the chip at 64 frames and halving its grid costs
+  // more than the overlap returns, so the default is one lane.
+  const bool split = !prof && n >= 16 && getenv("AMDAT_SPLIT") != nullptr;
+  if (!split) {
+    int rc = issue_pipeline(D, 0, 0, n, ostride, s, mark);
+    if (rc) return rc;
+  } else {
+    const uint32_t n0 = n / 2, n1 = n - n0;
+    HIP_TRY(hipEventRecord(D->ev_lane_begin, s));
+    HIP_TRY(hipStreamWaitEvent(D->lane_stream, D->ev_lane_begin, 0));
+    int rc = issue_pipeline(D, 0, 0, n0, ostride, s, nomark);
+    if (rc) return rc;
+    rc = issue_pipeline(D, 1, n0, n1, ostride, D->lane_stream, nomark);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(D->ev_lane_end, D->lane_stream));
+    HIP_TRY(hipStreamWaitEvent(s, D->ev_lane_end, 0));
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(D->h_counters, D->d_counters, n * sizeof(FrameCounters), hipMemcpyDeviceToHost, s));
   if (ostride > P.dcap) ostride = P.dcap;
@@ -641,7 +674,7 @@ int amdAprilTagsThresholdOnly(amdAprilTagsHandle handle, uint32_t n, const amdAp
   handle->last_n = n;
   HIP_TRY(hipMemcpyAsync(handle->d_frames, handle->h_frames, n * sizeof(FrameDesc), hipMemcpyHostToDevice, s));
   if (handle->profiling) hipEventRecord(handle->ev[1], s);
-  launch_threshold(handle, n, s);
+  { DetParams P0 = handle->P; P0.frame0 = 0; launch_threshold(handle, P0, n, s); }
   if (handle->profiling) hipEventRecord(handle->ev[2], s);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));

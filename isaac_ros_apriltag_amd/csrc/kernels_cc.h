@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
                                                   uint32_t* __restrict__ csize_all, DetParams P) {
   __shared__ __attribute__((aligned(16))) uint8_t st[CC_T * CC_T];
   __shared__ uint32_t sl[CC_T * CC_T];
-  const int frame = blockIdx.z;
+  const int frame = (int)blockIdx.z + P.frame0;
   const int X0 = blockIdx.x * CC_T, Y0 = blockIdx.y * CC_T;
   const int W = P.W, H = P.H;
   const uint8_t* thr = thr_all + (size_t)frame * H * P.WS;
@@ -193,7 +193,7 @@ __device__ __forceinline__ void cc_global_links(const uint8_t* thr, uint32_t* la
 // grid.x covers [border rows: nrows*W pixels][left columns: ncols*H][right columns: ncols*H]
 __global__ __launch_bounds__(256) void k_cc_border(const uint8_t* __restrict__ thr_all, uint32_t* __restrict__ label_all,
                                                    DetParams P) {
-  const int frame = blockIdx.z;
+  const int frame = (int)blockIdx.z + P.frame0;
   const int W = P.W, H = P.H;
   const uint8_t* thr = thr_all + (size_t)frame * H * P.WS;
   uint32_t* label = label_all + (size_t)frame * W * H;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_cc_border(const uint8_t* __restrict__ t
 
 __global__ __launch_bounds__(256) void k_cc_flatten(uint32_t* __restrict__ label_all, uint32_t* __restrict__ csize_all,
                                                     DetParams P) {
-  const int frame = blockIdx.z;
+  const int frame = (int)blockIdx.z + P.frame0;
   const size_t n = (size_t)P.W * P.H;
   uint32_t* label = label_all + (size_t)frame * n;
   uint32_t* csize = csize_all + (size_t)frame * n;

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   __shared__ uint32_t sbase;
   __shared__ unsigned long long tkey[PT_TB];
   __shared__ uint32_t tcnt[PT_TB], tslot[PT_TB], tbase[PT_TB];
-  const int frame = blockIdx.z;
+  const int frame = (int)blockIdx.z + P.frame0;
   const int W = P.W, H = P.H;
   const size_t npx = (size_t)W * H;
   const uint8_t* thr = thr_all + (size_t)frame * H * P.WS;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(1024) void k_cluster_select(const unsigned long lon
                                                          FrameCounters* __restrict__ counters, DetParams P) {
   __shared__ uint32_t wsum[16], wcnt[16];
   __shared__ uint32_t s_pbase, s_cbase;
-  const int frame = blockIdx.z;
+  const int frame = (int)blockIdx.z + P.frame0;
   const uint32_t slot = blockIdx.x * 1024 + threadIdx.x;
   const bool in_range = slot < P.hcap;
   const size_t hi = (size_t)frame * P.hcap + (in_range ? slot : 0);
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(1024) void k_cluster_select(const unsigned long lon
 __global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ stage_all, const uint32_t* __restrict__ rank_all,
                                                  const uint32_t* __restrict__ hoff_all, uint32_t* __restrict__ pts_all,
                                                  const FrameCounters* __restrict__ counters, DetParams P) {
-  const int frame = blockIdx.z;
+  const int frame = (int)blockIdx.z + P.frame0;
   uint32_t n = counters[frame].npoints_raw;
   if (n > P.pcap) n = P.pcap;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {

@@ -258,7 +258,7 @@ __device__ float quad_decode_dev(const DetParams& P, const FamilyDev& fam, const
 // one thread per quad
 __global__ __launch_bounds__(64) void k_decode(const FrameDesc* __restrict__ frames, const QuadRec* __restrict__ quads_all,
                                                DetRec* __restrict__ dets_all, FrameCounters* __restrict__ counters, DetParams P) {
-  const int frame = blockIdx.y;
+  const int frame = (int)blockIdx.y + P.frame0;
   uint32_t nq = counters[frame].nquads;
   if (nq > P.qcap) nq = P.qcap;
   const FrameDesc fd = frames[frame];
@@ -383,7 +383,7 @@ __device__ void pose_from_homography_dev(const double* H, double fx_in, double f
 __global__ __launch_bounds__(64) void k_reconcile(const FrameDesc* __restrict__ frames, const DetRec* __restrict__ dets_all,
                                                   DetRec* __restrict__ out_all, FrameCounters* __restrict__ counters,
                                                   uint16_t* __restrict__ order_all, DetParams P) {
-  const int frame = blockIdx.x;
+  const int frame = (int)blockIdx.x + P.frame0;
   uint32_t nd = counters[frame].ndets;
   if (nd > P.dcap) nd = P.dcap;
   const DetRec* dets = dets_all + (size_t)frame * P.dcap;

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64) void k_decode_wave(const FrameDesc* __restrict_
   __shared__ double s_C[2][3];
   __shared__ double s_values[144], s_sharp[64];
 
-  const int frame = blockIdx.y;
+  const int frame = (int)blockIdx.y + P.frame0;
   const int lane = threadIdx.x;
   uint32_t nq = counters[frame].nquads;
   if (nq > P.qcap) nq = P.qcap;

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 4 : 2)) void k_fit_quads(const Fra
   __shared__ U128 s_carry[6];
   __shared__ U128 s_wtot[(NW > 1 ? NW : 1) * 6];
 
-  const int frame = blockIdx.y;
+  const int frame = (int)blockIdx.y + P.frame0;
   const int tid = threadIdx.x;
   const FrameDesc fd = frames[frame];
   const uint8_t* gray = (P.decimate > 1) ? gray_all + (size_t)frame * P.H * P.WS : fd.img;

@@ -83,8 +83,9 @@ __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__
   const int per_xcd = (int)(gridDim.x >> 3);
   const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
   if (tile >= ntiles) return;
-  const int frame = tile / (gx * gy);
-  const int trem = tile - frame * (gx * gy);
+  const int lframe = tile / (gx * gy);
+  const int trem = tile - lframe * (gx * gy);
+  const int frame = lframe + P.frame0;
   const int bx = trem % gx, by = trem / gx;
   const FrameDesc fd = frames[frame];
   const bool aligned = ((((uintptr_t)fd.img) | (uintptr_t)fd.pitch) & 15) == 0;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__
 template <int DEC>
 __global__ __launch_bounds__(256) void k_threshold_leftover(const FrameDesc* __restrict__ frames, uint8_t* __restrict__ gray_all,
                                                             uint8_t* __restrict__ thr_all, DetParams P) {
-  const int frame = blockIdx.z;
+  const int frame = (int)blockIdx.z + P.frame0;
   const FrameDesc fd = frames[frame];
   const int nright = P.W - P.tw * 4;  // columns per row in the right strip
   const int nbot = P.H - P.th * 4;    // rows in the bottom strip
