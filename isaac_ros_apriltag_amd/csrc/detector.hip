@@ -125,6 +125,9 @@ struct amdAprilTagsDetector_st {
   bool profiling = false;
   bool fq_counters = false;  // per-phase cycle counters inside k_fit_quads (profiling level 2; perturbs timing)
   bool fq_attr_set = false;
+  // tuning overrides read once at creation (AMDAT_FQ_CLASSES, AMDAT_FQ_SERIAL, AMDAT_SPLIT)
+  const char* env_fq_classes = nullptr;
+  bool env_fq_serial = false, env_split = false;
   hipEvent_t ev[AMDAT_NUM_STAGES + 1] = {};
   float stage_ms[AMDAT_NUM_STAGES] = {};
   uint32_t last_n = 0;
@@ -253,6 +256,9 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   auto* D = new (std::nothrow) amdAprilTagsDetector_st();
   if (!D) return AMDAT_OUT_OF_MEMORY;
   D->cfg = cfg;
+  D->env_fq_classes = getenv("AMDAT_FQ_CLASSES");
+  D->env_fq_serial = getenv("AMDAT_FQ_SERIAL") != nullptr;
+  D->env_split = getenv("AMDAT_SPLIT") != nullptr;
   if (cfg.device >= 0) {
     if (hipSetDevice(cfg.device) != hipSuccess) { delete D; return AMDAT_HIP_ERROR; }
   }
@@ -473,7 +479,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
                          {256, 4096, 1024, 4096, clampu(2048u / n, 32u, 512u)},
                          {512, 8192, 4096, 8192, clampu(1024u / n, 16u, 256u)},
                          {512, 16384, 8192, 0x7FFFFFFF, clampu(512u / n, 8u, 256u)}};
-    if (const char* ov = getenv("AMDAT_FQ_CLASSES")) {  // tuning override: "nt:cap:gxbudget" x 5 (size bounds follow cap)
+    if (const char* ov = D->env_fq_classes) {  // tuning override: "nt:cap:gxbudget" x 5 (size bounds follow cap)
       int nt[NCLS], cap[NCLS], bud[NCLS];
       if (sscanf(ov, "%d:%d:%d,%d:%d:%d,%d:%d:%d,%d:%d:%d,%d:%d:%d", &nt[0], &cap[0], &bud[0], &nt[1], &cap[1], &bud[1], &nt[2],
                  &cap[2], &bud[2], &nt[3], &cap[3], &bud[3], &nt[4], &cap[4], &bud[4]) == 15) {
@@ -496,7 +502,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
     // The classes are independent (they only append to the quad list), so they run concurrently: class
     // 0 stays on the lane's stream, the others fork to auxiliary streams and join before decode.
     // Small-cluster waves fill the CUs that the one-workgroup-per-CU big-cluster class leaves mostly idle.
-    const bool fork = getenv("AMDAT_FQ_SERIAL") == nullptr;
+    const bool fork = !D->env_fq_serial;
     if (fork) HIP_TRY(hipEventRecord(D->ev_fork[lane], s));
     int nlaunched = 0;
     for (int c = 0; c < NCLS; c++) {
@@ -564,7 +570,7 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
   // with different bottlenecks overlap.  Measured SLOWER on MI355X (2.95k vs 3.30k frames/s at sigma 2,
   // 21k vs 26k noise-free): every kernel already fills the chip at 64 frames and halving its grid costs
   // more than the overlap returns, so the default is one lane.
-  const bool split = !prof && n >= 16 && getenv("AMDAT_SPLIT") != nullptr;
+  const bool split = !prof && n >= 16 && D->env_split;
   if (!split) {
     int rc = issue_pipeline(D, 0, 0, n, ostride, s, mark);
     if (rc) return rc;

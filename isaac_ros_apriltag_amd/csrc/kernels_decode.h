@@ -2,9 +2,8 @@
 // (the tail of the closed cuAprilTagsDetect call, reference
 // src/apriltag_node.cpp:491-493, whose outputs the node reads at :503-546).
 //
-// This file holds the scalar building blocks (projection, gray model, bilinear sample, code rotation),
-// a one-lane-per-quad kernel k_decode kept as the simple form of the stage, and the per-frame
-// reconcile/pose kernel.  The production launch is the one-wave-per-quad kernel in
+// This file holds the scalar building blocks (projection, gray model, bilinear sample, code rotation)
+// and the per-frame reconcile/pose kernel; the quad stage itself is the one-wave-per-quad kernel in
 // kernels_decode_wave.h.  Every floating-point statement is evaluated in the same order as the
 // sequential CPU definition so that ids, corners and poses come out bit-identical.  The code lookup is
 // a brute-force popcount scan over the family table (<= 587 codes x 4 rotations), not a hash table.
@@ -17,109 +16,6 @@ __device__ __forceinline__ void homography_project_dev(const double* H, double x
   const double zz = H[6] * x + H[7] * y + H[8];
   *ox = xx / zz;
   *oy = yy / zz;
-}
-
-__device__ void refine_edges_dev(const DetParams& P, const uint8_t* im, int w, int h, int pitch, QuadRec* quad) {
-  double lines[4][4];
-  for (int edge = 0; edge < 4; edge++) {
-    const int a = edge, b = (edge + 1) & 3;
-    double nx = (double)quad->p[b][1] - (double)quad->p[a][1];
-    double ny = -(double)quad->p[b][0] + (double)quad->p[a][0];
-    const double mag = __dsqrt_rn(nx * nx + ny * ny);
-    nx /= mag; ny /= mag;
-    if (quad->reversed_border) { nx = -nx; ny = -ny; }
-    int nsamples = (int)(mag / 8);
-    if (nsamples < 16) nsamples = 16;
-    double Mx = 0, My = 0, Mxx = 0, Mxy = 0, Myy = 0, N = 0;
-    const double range = P.decimate + 1;
-    const int steps = (int)(2 * range * 4) + 1;
-    for (int s = 0; s < nsamples; s++) {
-      const double alpha = (1.0 + s) / (nsamples + 1);
-      const double x0 = alpha * (double)quad->p[a][0] + (1 - alpha) * (double)quad->p[b][0];
-      const double y0 = alpha * (double)quad->p[a][1] + (1 - alpha) * (double)quad->p[b][1];
-      double Mn = 0, Mcount = 0;
-      for (int k = 0; k < steps; k++) {
-        const double n = -range + 0.25 * k;
-        const double grange = 1;
-        const int x1 = (int)(x0 + (n + grange) * nx);
-        const int y1 = (int)(y0 + (n + grange) * ny);
-        if (x1 < 0 || x1 >= w || y1 < 0 || y1 >= h) continue;
-        const int x2 = (int)(x0 + (n - grange) * nx);
-        const int y2 = (int)(y0 + (n - grange) * ny);
-        if (x2 < 0 || x2 >= w || y2 < 0 || y2 >= h) continue;
-        const int g1 = im[(size_t)y1 * pitch + x1];
-        const int g2 = im[(size_t)y2 * pitch + x2];
-        if (g1 < g2) continue;
-        const double weight = (double)((g2 - g1) * (g2 - g1));
-        Mn += weight * n;
-        Mcount += weight;
-      }
-      if (Mcount == 0) continue;
-      const double n0 = Mn / Mcount;
-      const double bestx = x0 + n0 * nx, besty = y0 + n0 * ny;
-      Mx += bestx; My += besty; Mxx += bestx * bestx; Mxy += bestx * besty; Myy += besty * besty; N++;
-    }
-    const double Ex = Mx / N, Ey = My / N;
-    const double Cxx = Mxx / N - Ex * Ex, Cxy = Mxy / N - Ex * Ey, Cyy = Myy / N - Ey * Ey;
-    const double disc = (Cxx - Cyy) * (Cxx - Cyy) + 4 * Cxy * Cxy;
-    const double eig = 0.5 * (Cxx + Cyy + (double)at_sqrtf_rn((float)disc));
-    const double nx1 = Cxx - eig, ny1 = Cxy, M1 = nx1 * nx1 + ny1 * ny1;
-    const double nx2 = Cxy, ny2 = Cyy - eig, M2 = nx2 * nx2 + ny2 * ny2;
-    double M;
-    if (M1 > M2) { nx = nx1; ny = ny1; M = M1; } else { nx = nx2; ny = ny2; M = M2; }
-    const double length = (double)at_sqrtf_rn((float)M);
-    if (fabs(length) < 1e-12) { nx = 0; ny = 0; } else { nx = nx / length; ny = ny / length; }
-    lines[edge][0] = Ex; lines[edge][1] = Ey; lines[edge][2] = nx; lines[edge][3] = ny;
-  }
-  for (int i = 0; i < 4; i++) {
-    const double A00 = lines[i][3], A01 = -lines[(i + 1) & 3][3];
-    const double A10 = -lines[i][2], A11 = lines[(i + 1) & 3][2];
-    const double B0 = -lines[i][0] + lines[(i + 1) & 3][0];
-    const double B1 = -lines[i][1] + lines[(i + 1) & 3][1];
-    const double det = A00 * A11 - A10 * A01;
-    if (fabs(det) > 0.001) {
-      const double W00 = A11 / det, W01 = -A01 / det;
-      const double L0 = W00 * B0 + W01 * B1;
-      quad->p[i][0] = (float)(lines[i][0] + L0 * A00);
-      quad->p[i][1] = (float)(lines[i][1] + L0 * A10);
-    }
-  }
-}
-
-__device__ int homography_compute_dev(const QuadRec* q, double* H) {
-  double A[72];
-  for (int i = 0; i < 4; i++) {
-    const double x = (i == 0 || i == 3) ? -1 : 1, y = (i == 0 || i == 1) ? -1 : 1;
-    const double u = (double)q->p[i][0], v = (double)q->p[i][1];
-    double* r0 = &A[(2 * i) * 9];
-    double* r1 = &A[(2 * i + 1) * 9];
-    r0[0] = x; r0[1] = y; r0[2] = 1; r0[3] = 0; r0[4] = 0; r0[5] = 0; r0[6] = -x * u; r0[7] = -y * u; r0[8] = u;
-    r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = x; r1[4] = y; r1[5] = 1; r1[6] = -x * v; r1[7] = -y * v; r1[8] = v;
-  }
-  for (int col = 0; col < 8; col++) {
-    double max_val = 0;
-    int max_idx = -1;
-    for (int row = col; row < 8; row++) {
-      const double val = fabs(A[row * 9 + col]);
-      if (val > max_val) { max_val = val; max_idx = row; }
-    }
-    if (max_val < 1e-10) return -1;
-    if (max_idx != col)
-      for (int i = col; i < 9; i++) { const double t = A[col * 9 + i]; A[col * 9 + i] = A[max_idx * 9 + i]; A[max_idx * 9 + i] = t; }
-    for (int i = col + 1; i < 8; i++) {
-      const double f = A[i * 9 + col] / A[col * 9 + col];
-      A[i * 9 + col] = 0;
-      for (int j = col + 1; j < 9; j++) A[i * 9 + j] -= f * A[col * 9 + j];
-    }
-  }
-  for (int col = 7; col >= 0; col--) {
-    double sum = 0;
-    for (int i = col + 1; i < 8; i++) sum += A[col * 9 + i] * A[i * 9 + 8];
-    A[col * 9 + 8] = (A[col * 9 + 8] - sum) / A[col * 9 + col];
-  }
-  for (int i = 0; i < 8; i++) H[i] = A[i * 9 + 8];
-  H[8] = 1;
-  return 0;
 }
 
 struct GrayModel { double A00, A01, A02, A11, A12, A22, B0, B1, B2, C0, C1, C2; };
@@ -171,128 +67,6 @@ __device__ __forceinline__ uint64_t rotate90_dev(uint64_t w, int d) {
       if ((w >> (nb - 1 - (sr * d + sc))) & 1) o |= 1ull << (nb - 1 - (r * d + c));
     }
   return o;
-}
-
-__device__ float quad_decode_dev(const DetParams& P, const FamilyDev& fam, const uint8_t* im, int w, int h, int pitch,
-                                 const double* H, int* id, int* hamming, int* rotation, int* found) {
-  const int wb = (int)fam.width_at_border, tw = (int)fam.total_width;
-  GrayModel whitemodel = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, blackmodel = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  *found = 0;
-  for (int pi = 0; pi < 8; pi++) {
-    // {x0, y0, dx, dy, is_white} of the 8 border sample lines
-    float p0, p1, p2, p3;
-    int is_white;
-    switch (pi) {
-      case 0: p0 = -0.5f; p1 = 0.5f; p2 = 0; p3 = 1; is_white = 1; break;
-      case 1: p0 = 0.5f; p1 = 0.5f; p2 = 0; p3 = 1; is_white = 0; break;
-      case 2: p0 = (float)wb + 0.5f; p1 = 0.5f; p2 = 0; p3 = 1; is_white = 1; break;
-      case 3: p0 = (float)wb - 0.5f; p1 = 0.5f; p2 = 0; p3 = 1; is_white = 0; break;
-      case 4: p0 = 0.5f; p1 = -0.5f; p2 = 1; p3 = 0; is_white = 1; break;
-      case 5: p0 = 0.5f; p1 = 0.5f; p2 = 1; p3 = 0; is_white = 0; break;
-      case 6: p0 = 0.5f; p1 = (float)wb + 0.5f; p2 = 1; p3 = 0; is_white = 1; break;
-      default: p0 = 0.5f; p1 = (float)wb - 0.5f; p2 = 1; p3 = 0; is_white = 0; break;
-    }
-    for (int i = 0; i < wb; i++) {
-      const double tagx01 = ((double)p0 + i * (double)p2) / wb;
-      const double tagy01 = ((double)p1 + i * (double)p3) / wb;
-      const double tagx = 2 * (tagx01 - 0.5), tagy = 2 * (tagy01 - 0.5);
-      double px, py;
-      homography_project_dev(H, tagx, tagy, &px, &py);
-      const int ix = (int)px, iy = (int)py;
-      if (ix < 0 || iy < 0 || ix >= w || iy >= h) continue;
-      const int v = im[(size_t)iy * pitch + ix];
-      if (is_white) graymodel_add_dev(whitemodel, tagx, tagy, v);
-      else graymodel_add_dev(blackmodel, tagx, tagy, v);
-    }
-  }
-  graymodel_solve_dev(whitemodel);
-  graymodel_solve_dev(blackmodel);
-  if ((graymodel_interp_dev(whitemodel, 0, 0) - graymodel_interp_dev(blackmodel, 0, 0) < 0) != (fam.reversed_border != 0))
-    return -1;
-
-  double values[12 * 12];
-  for (int i = 0; i < tw * tw; i++) values[i] = 0;
-  const int min_coord = (wb - tw) / 2;
-  const int d = (int)fam.d;
-  for (int i = 0; i < (int)fam.nbits; i++) {
-    const int bitx = 1 + i % d, bity = 1 + i / d;
-    const double tagx01 = (bitx + 0.5) / wb, tagy01 = (bity + 0.5) / wb;
-    const double tagx = 2 * (tagx01 - 0.5), tagy = 2 * (tagy01 - 0.5);
-    double px, py;
-    homography_project_dev(H, tagx, tagy, &px, &py);
-    const double v = value_for_pixel_dev(im, w, h, pitch, px, py);
-    if (v == -1) continue;
-    const double thresh = (graymodel_interp_dev(blackmodel, tagx, tagy) + graymodel_interp_dev(whitemodel, tagx, tagy)) / 2.0;
-    values[tw * (bity - min_coord) + bitx - min_coord] = v - thresh;
-  }
-  float black_score = 0, white_score = 0, black_count = 1, white_count = 1;
-  uint64_t rcode = 0;
-  for (int i = 0; i < (int)fam.nbits; i++) {
-    const int bitx = 1 + i % d, bity = 1 + i / d;
-    const int y = bity - min_coord, x = bitx - min_coord;
-    // sharpened value at (x,y): v + s * (4v - up - left - right - down), accumulated in kernel order
-    double s = 0;
-    if (y - 1 >= 0) s += values[(y - 1) * tw + x] * -1.0;
-    if (x - 1 >= 0) s += values[y * tw + x - 1] * -1.0;
-    s += values[y * tw + x] * 4.0;
-    if (x + 1 <= tw - 1) s += values[y * tw + x + 1] * -1.0;
-    if (y + 1 <= tw - 1) s += values[(y + 1) * tw + x] * -1.0;
-    const double v = values[y * tw + x] + P.decode_sharpening * s;
-    rcode <<= 1;
-    if (v > 0) { white_score = (float)((double)white_score + v); white_count++; rcode |= 1; }
-    else { black_score = (float)((double)black_score - v); black_count++; }
-  }
-  for (int r = 0; r < 4 && !*found; r++) {
-    int best = 1 << 30, bid = -1;
-    for (uint32_t i = 0; i < fam.ncodes; i++) {
-      const int hd = __popcll(rcode ^ fam.codes[i]);
-      if (hd < best) { best = hd; bid = (int)i; }
-    }
-    if (best <= P.max_hamming) { *id = bid; *hamming = best; *rotation = r; *found = 1; }
-    else rcode = rotate90_dev(rcode, d);
-  }
-  const float a = white_score / white_count, b = black_score / black_count;
-  return a < b ? a : b;
-}
-
-// one thread per quad
-__global__ __launch_bounds__(64) void k_decode(const FrameDesc* __restrict__ frames, const QuadRec* __restrict__ quads_all,
-                                               DetRec* __restrict__ dets_all, FrameCounters* __restrict__ counters, DetParams P) {
-  const int frame = (int)blockIdx.y + P.frame0;
-  uint32_t nq = counters[frame].nquads;
-  if (nq > P.qcap) nq = P.qcap;
-  const FrameDesc fd = frames[frame];
-  for (uint32_t qi = blockIdx.x * 64 + threadIdx.x; qi < nq; qi += gridDim.x * 64) {
-    QuadRec q = quads_all[(size_t)frame * P.qcap + qi];
-    if (P.refine_edges) refine_edges_dev(P, fd.img, P.W0, P.H0, (int)fd.pitch, &q);
-    double H[9];
-    if (homography_compute_dev(&q, H) != 0) continue;
-    for (int fi = 0; fi < P.nfam; fi++) {
-      if ((P.fam[fi].reversed_border != 0) != (q.reversed_border != 0)) continue;
-      int id = 0, hamming = 0, rotation = 0, found = 0;
-      const float margin = quad_decode_dev(P, P.fam[fi], fd.img, P.W0, P.H0, (int)fd.pitch, H, &id, &hamming, &rotation, &found);
-      if (!(margin >= 0 && found)) continue;
-      const uint32_t di = atomicAdd(&counters[frame].ndets, 1u);
-      if (di >= P.dcap) { atomicOr(&counters[frame].flags, 0x10u); continue; }
-      DetRec det;
-      det.family = fi; det.id = id; det.hamming = hamming; det.decision_margin = margin;
-      const double c = (rotation == 0) ? 1.0 : (rotation == 2) ? -1.0 : 0.0;
-      const double s = (rotation == 1) ? 1.0 : (rotation == 3) ? -1.0 : 0.0;
-      for (int r = 0; r < 3; r++) {
-        det.H[r * 3 + 0] = H[r * 3 + 0] * c + H[r * 3 + 1] * s;
-        det.H[r * 3 + 1] = H[r * 3 + 0] * -s + H[r * 3 + 1] * c;
-        det.H[r * 3 + 2] = H[r * 3 + 2];
-      }
-      homography_project_dev(det.H, 0, 0, &det.c[0], &det.c[1]);
-      for (int i = 0; i < 4; i++) {
-        const double tcx = (i == 1 || i == 2) ? 1 : -1, tcy = (i < 2) ? 1 : -1;
-        homography_project_dev(det.H, tcx, tcy, &det.p[i][0], &det.p[i][1]);
-      }
-      for (int i = 0; i < 9; i++) det.R[i] = 0;
-      det.t[0] = det.t[1] = det.t[2] = 0;
-      dets_all[(size_t)frame * P.dcap + di] = det;
-    }
-  }
 }
 
 // ---- S8 reconcile + S9 pose ---------------------------------------------------------------------

@@ -193,13 +193,6 @@ void ato_connected_components(const uint8_t* thr, int w, int h, uint32_t* label,
 /* ------------------------------------------------------------------------------------------- */
 typedef struct { uint64_t key; uint32_t pt; } kp_t;
 
-static __attribute__((unused)) int kp_cmp(const void* a, const void* b) {
-  const kp_t* x = (const kp_t*)a; const kp_t* y = (const kp_t*)b;
-  if (x->key != y->key) return x->key < y->key ? -1 : 1;
-  if (x->pt != y->pt) return x->pt < y->pt ? -1 : 1;
-  return 0;
-}
-
 static inline uint32_t pack_point(int x, int y, int gx, int gy) {
   /* x,y half-pixel units (< 2^14); gx,gy in {-255,0,255} -> code {0,1,2} */
   return ((uint32_t)x << 18) | ((uint32_t)y << 4) | ((uint32_t)(gx / 255 + 1) << 2) | (uint32_t)(gy / 255 + 1);
