@@ -168,6 +168,21 @@ int amdAprilTagsGetFrameFlags(amdAprilTagsHandle handle, uint32_t* flags, uint32
 int amdAprilTagsConvertToMono8(const void* src_dev, size_t src_pitch, const char* encoding, uint32_t width,
                                uint32_t height, uint8_t* dst_dev, size_t dst_pitch, amdAprilTagsStream stream);
 
+/* ---- front steps of the usual graph (camera -> rectify -> resize -> apriltag; reference README.md:16-29,
+ * launch/isaac_ros_apriltag_usb_cam.launch.py:43-63) on mono8 device images ------------------------- */
+/* Bilinear resize, pixel-centre aligned; source coordinates and weights are 1/2048 fixed point, so the
+ * result is exactly reproducible (oracle: ato_resize_mono8). */
+int amdAprilTagsResizeMono8(const uint8_t* src_dev, size_t src_pitch, uint32_t src_width, uint32_t src_height,
+                            uint8_t* dst_dev, size_t dst_pitch, uint32_t dst_width, uint32_t dst_height,
+                            amdAprilTagsStream stream);
+/* Undistortion of a plumb_bob image (sensor_msgs/CameraInfo K and D = k1,k2,p1,p2,k3) onto the pinhole
+ * camera K_new (row-major 3x3 each): every destination pixel is projected through the distortion model
+ * in double precision, the source position is quantised to 1/32 pixel and sampled bilinearly in integer
+ * arithmetic; pixels that map outside the source are 0 (oracle: ato_rectify_mono8). */
+int amdAprilTagsRectifyMono8(const uint8_t* src_dev, size_t src_pitch, uint8_t* dst_dev, size_t dst_pitch, uint32_t width,
+                             uint32_t height, const double* K9, const double* D5, const double* Knew9,
+                             amdAprilTagsStream stream);
+
 /* Device-memory helpers for hosts that do not link the HIP runtime themselves (the node shell copies
  * sensor_msgs/Image payloads with these).  Plain hipMalloc / hipFree / hipMemcpyAsync + sync. */
 int amdAprilTagsDeviceAlloc(void** dev_ptr, size_t bytes);

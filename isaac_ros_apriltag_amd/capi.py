@@ -59,7 +59,7 @@ EXPORTS = ["amdAprilTagsDefaultConfig", "amdCreateAprilTagsDetector", "amdCreate
            "amdAprilTagsFamilyInfo", "amdAprilTagsFamilyFromName", "amdAprilTagsStageName",
            "amdAprilTagsSetProfiling", "amdAprilTagsGetStageMs", "amdAprilTagsThresholdOnly",
            "amdAprilTagsDebugCopy", "amdAprilTagsDebugMath", "amdAprilTagsDeviceAlloc", "amdAprilTagsDeviceFree",
-           "amdAprilTagsCopyToDevice"]
+           "amdAprilTagsCopyToDevice", "amdAprilTagsResizeMono8", "amdAprilTagsRectifyMono8"]
 
 _lib = None
 
@@ -101,6 +101,10 @@ def lib():
     L.amdAprilTagsDeviceAlloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     L.amdAprilTagsDeviceFree.argtypes = [C.c_void_p]
     L.amdAprilTagsCopyToDevice.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, H]
+    L.amdAprilTagsResizeMono8.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32,
+                                          C.c_uint32, H]
+    L.amdAprilTagsRectifyMono8.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32,
+                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), H]
     L.amdAprilTagsDebugMath.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     for name in EXPORTS:
         fn = getattr(L, name)

@@ -21,6 +21,7 @@
 #include "kernels_cluster.h"
 #include "kernels_decode.h"
 #include "kernels_decode_wave.h"
+#include "kernels_frontend.h"
 #include "kernels_quad.h"
 #include "kernels_threshold.h"
 
@@ -710,6 +711,31 @@ int amdAprilTagsConvertToMono8(const void* src_dev, size_t src_pitch, const char
   } else {
     return AMDAT_UNSUPPORTED;
   }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));
+  return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsResizeMono8(const uint8_t* src_dev, size_t src_pitch, uint32_t sw, uint32_t sh, uint8_t* dst_dev, size_t dst_pitch,
+                            uint32_t dw, uint32_t dh, amdAprilTagsStream stream) {
+  if (!src_dev || !dst_dev || sw == 0 || sh == 0 || dw == 0 || dh == 0 || src_pitch < sw || dst_pitch < dw) return AMDAT_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_resize_mono8, dim3((dw + 63) / 64, (dh + 3) / 4), dim3(256), 0, s, src_dev, src_pitch, (int)sw, (int)sh, dst_dev,
+                     dst_pitch, (int)dw, (int)dh);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));
+  return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsRectifyMono8(const uint8_t* src_dev, size_t src_pitch, uint8_t* dst_dev, size_t dst_pitch, uint32_t width,
+                             uint32_t height, const double* K9, const double* D5, const double* Knew9, amdAprilTagsStream stream) {
+  if (!src_dev || !dst_dev || !K9 || !D5 || !Knew9 || width == 0 || height == 0 || src_pitch < width || dst_pitch < width)
+    return AMDAT_INVALID_ARGUMENT;
+  RectifyParams R = {K9[0], K9[4], K9[2], K9[5], D5[0], D5[1], D5[2], D5[3], D5[4], Knew9[0], Knew9[4], Knew9[2], Knew9[5]};
+  if (R.nfx == 0.0 || R.nfy == 0.0) return AMDAT_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_rectify_mono8, dim3((width + 63) / 64, (height + 3) / 4), dim3(256), 0, s, src_dev, src_pitch, dst_dev, dst_pitch,
+                     (int)width, (int)height, R);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));
   return AMDAT_SUCCESS;

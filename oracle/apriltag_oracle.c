@@ -1110,3 +1110,54 @@ void ato_dump_free(ato_dump_t* d) {
   free(d->dets);
   memset(d, 0, sizeof(*d));
 }
+
+/* ------------------------------------------------------------------------------------------- */
+/* front steps: resize and rectify (reference README.md:16-29; launch/..._usb_cam.launch.py:43-63) */
+/* ------------------------------------------------------------------------------------------- */
+void ato_resize_mono8(const uint8_t* src, int spitch, int sw, int sh, uint8_t* dst, int dpitch, int dw, int dh) {
+  for (int y = 0; y < dh; y++)
+    for (int x = 0; x < dw; x++) {
+      long long fx = ((long long)(2 * x + 1) * sw * 1024) / dw - 1024;
+      long long fy = ((long long)(2 * y + 1) * sh * 1024) / dh - 1024;
+      if (fx < 0) fx = 0;
+      if (fy < 0) fy = 0;
+      int x0 = (int)(fx >> 11), y0 = (int)(fy >> 11), wx = (int)(fx & 2047), wy = (int)(fy & 2047);
+      if (x0 >= sw - 1) { x0 = sw - 1; wx = 0; }
+      if (y0 >= sh - 1) { y0 = sh - 1; wy = 0; }
+      int x1 = x0 + 1 < sw ? x0 + 1 : sw - 1, y1 = y0 + 1 < sh ? y0 + 1 : sh - 1;
+      uint32_t p00 = src[(size_t)y0 * spitch + x0], p01 = src[(size_t)y0 * spitch + x1];
+      uint32_t p10 = src[(size_t)y1 * spitch + x0], p11 = src[(size_t)y1 * spitch + x1];
+      uint32_t top = p00 * (2048 - wx) + p01 * wx, bot = p10 * (2048 - wx) + p11 * wx;
+      uint64_t v = (uint64_t)top * (2048 - wy) + (uint64_t)bot * wy;
+      dst[(size_t)y * dpitch + x] = (uint8_t)((v + (1ull << 21)) >> 22);
+    }
+}
+
+void ato_rectify_mono8(const uint8_t* src, int spitch, uint8_t* dst, int dpitch, int w, int h, const double K[9],
+                       const double D[5], const double Knew[9]) {
+  double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+  double k1 = D[0], k2 = D[1], p1 = D[2], p2 = D[3], k3 = D[4];
+  double nfx = Knew[0], nfy = Knew[4], ncx = Knew[2], ncy = Knew[5];
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      double xn = ((double)x - ncx) / nfx, yn = ((double)y - ncy) / nfy;
+      double r2 = xn * xn + yn * yn;
+      double radial = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
+      double xd = xn * radial + (2.0 * p1 * xn * yn + p2 * (r2 + 2.0 * xn * xn));
+      double yd = yn * radial + (p1 * (r2 + 2.0 * yn * yn) + 2.0 * p2 * xn * yn);
+      double u = fx * xd + cx, v = fy * yd + cy;
+      uint8_t out = 0;
+      if (u >= 0.0 && v >= 0.0 && u <= (double)(w - 1) && v <= (double)(h - 1)) {
+        int fu = (int)(u * 32.0 + 0.5), fv = (int)(v * 32.0 + 0.5);
+        int x0 = fu >> 5, y0 = fv >> 5, wx = fu & 31, wy = fv & 31;
+        if (x0 >= w - 1) { x0 = w - 1; wx = 0; }
+        if (y0 >= h - 1) { y0 = h - 1; wy = 0; }
+        int x1 = x0 + 1 < w ? x0 + 1 : w - 1, y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+        uint32_t p00 = src[(size_t)y0 * spitch + x0], p01 = src[(size_t)y0 * spitch + x1];
+        uint32_t p10 = src[(size_t)y1 * spitch + x0], p11 = src[(size_t)y1 * spitch + x1];
+        uint32_t top = p00 * (32 - wx) + p01 * wx, bot = p10 * (32 - wx) + p11 * wx;
+        out = (uint8_t)((top * (32 - wy) + bot * wy + 512) >> 10);
+      }
+      dst[(size_t)y * dpitch + x] = out;
+    }
+}

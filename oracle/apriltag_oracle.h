@@ -107,6 +107,12 @@ int ato_detect(const ato_params_t* prm, const ato_family_t* fams, int nfam,
                ato_detection_t* out, int max_det, ato_dump_t* dump);
 void ato_dump_free(ato_dump_t* d);
 
+/* Front steps (resize / rectify of mono8 frames), same fixed-point definitions as the HIP kernels in
+ * isaac_ros_apriltag_amd/csrc/kernels_frontend.h. */
+void ato_resize_mono8(const uint8_t* src, int spitch, int sw, int sh, uint8_t* dst, int dpitch, int dw, int dh);
+void ato_rectify_mono8(const uint8_t* src, int spitch, uint8_t* dst, int dpitch, int w, int h, const double K[9],
+                       const double D[5], const double Knew[9]);
+
 /* Pose from a detection homography ("reference homography solve", AprilRobotics
  * estimate_pose_for_tag_homography). */
 void ato_pose_from_homography(const double H[9], double fx, double fy, double cx, double cy,

@@ -78,6 +78,9 @@ def lib():
         _lib.ato_connected_components.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _lib.ato_decimate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _lib.ato_resize_mono8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        _lib.ato_rectify_mono8.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib.ato_pose_from_homography.argtypes = [C.POINTER(C.c_double)] + [C.c_double] * 5 + \
             [C.POINTER(C.c_double), C.POINTER(C.c_double)]
     return _lib
@@ -139,6 +142,23 @@ def decimate(img, f):
     out = np.empty((1 + (h - 1) // f, 1 + (w - 1) // f), dtype=np.uint8)
     sw, sh = C.c_int(), C.c_int()
     lib().ato_decimate(img.ctypes.data, w, h, img.strides[0], f, out.ctypes.data, C.byref(sw), C.byref(sh))
+    return out
+
+
+def resize_mono8(img, dw, dh):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty((dh, dw), dtype=np.uint8)
+    lib().ato_resize_mono8(img.ctypes.data, img.strides[0], img.shape[1], img.shape[0], out.ctypes.data, dw, dw, dh)
+    return out
+
+
+def rectify_mono8(img, K, D, Knew):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty_like(img)
+    k = (C.c_double * 9)(*np.asarray(K, dtype=np.float64).reshape(-1))
+    d = (C.c_double * 5)(*np.asarray(D, dtype=np.float64).reshape(-1))
+    kn = (C.c_double * 9)(*np.asarray(Knew, dtype=np.float64).reshape(-1))
+    lib().ato_rectify_mono8(img.ctypes.data, img.strides[0], out.ctypes.data, out.strides[0], img.shape[1], img.shape[0], k, d, kn)
     return out
 
 

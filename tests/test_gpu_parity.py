@@ -335,3 +335,39 @@ def test_large_single_cluster_uses_global_sort_path(built):
     det.close()
     assert not errs, errs[:3]
     assert len(cl) == 1 and 16384 < cl["count"].max() <= 36000
+
+
+def test_front_steps_bit_exact(built):
+    """Resize and rectify kernels reproduce the oracle's bytes, and 4K -> resize -> detect equals the
+    oracle run on the resized frame (the chain the reference README recommends for 4K input)."""
+    L = capi.lib()
+    img, K, truth, size = synth.scene_c3()
+    src = torch.from_numpy(img).cuda()
+    dst = torch.empty((1080, 1920), dtype=torch.uint8, device="cuda")
+    assert L.amdAprilTagsResizeMono8(src.data_ptr(), 3840, 3840, 2160, dst.data_ptr(), 1920, 1920, 1080, None) == 0
+    ref = po.resize_mono8(img, 1920, 1080)
+    assert np.array_equal(dst.cpu().numpy(), ref)
+    Ks = np.array([[2000.0, 0, 960.0], [0, 2000.0, 540.0], [0, 0, 1]])
+    det = AprilTagDetector(1920, 1080, families=("synth36h11",), intrinsics=_k4(Ks), tag_size=size, max_batch=1)
+    g = det.detect_batch_ex(dst, max_dets=128)[0]
+    det.close()
+    o, _ = po.detect(ref, families=("synth36h11",), params=pu.oracle_params(Ks, 1, size))
+    assert not pu.compare_detections(g, o) and len(g) == 100
+    # odd sizes, up- and down-scaling
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 256, size=(203, 301), dtype=np.uint8)
+    ta = torch.from_numpy(a).cuda()
+    for (dw, dh) in ((301, 203), (97, 55), (640, 480), (1, 1)):
+        out = torch.empty((dh, dw), dtype=torch.uint8, device="cuda")
+        assert L.amdAprilTagsResizeMono8(ta.data_ptr(), 301, 301, 203, out.data_ptr(), dw, dw, dh, None) == 0
+        assert np.array_equal(out.cpu().numpy(), po.resize_mono8(a, dw, dh)), (dw, dh)
+    # rectify with a plumb_bob model
+    img1, K1, _ = synth.scene_c1()
+    D = [-0.25, 0.07, 0.001, -0.002, 0.01]
+    Kn = np.array([[480.0, 0, 330.0], [0, 470.0, 235.0], [0, 0, 1]])
+    t1 = torch.from_numpy(img1).cuda()
+    r = torch.empty_like(t1)
+    k = (C.c_double * 9)(*K1.reshape(-1)); d5 = (C.c_double * 5)(*D); kn = (C.c_double * 9)(*Kn.reshape(-1))
+    assert L.amdAprilTagsRectifyMono8(t1.data_ptr(), 640, r.data_ptr(), 640, 640, 480, k, d5, kn, None) == 0
+    assert np.array_equal(r.cpu().numpy(), po.rectify_mono8(img1, K1, D, Kn))
+    assert L.amdAprilTagsRectifyMono8(t1.data_ptr(), 640, r.data_ptr(), 640, 640, 480, k, d5, None, None) == 1

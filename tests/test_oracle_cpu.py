@@ -246,3 +246,20 @@ def test_pose_matches_truth_homography(built):
     H = synth.homography_from_pose(R, t, K, 0.22)
     R2, t2 = po.pose_from_homography(H, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 0.22)
     assert np.abs(R2 - R).max() < 1e-4 and np.abs(t2 - t).max() < 1e-4
+
+
+def test_front_steps_resize_and_rectify(built):
+    """Oracle definitions of the front steps: identity cases are exact, a 4K board resized to 1080p is
+    still fully detected, and rectifying with zero distortion onto the same camera is the identity."""
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, size=(37, 53), dtype=np.uint8)
+    assert np.array_equal(po.resize_mono8(a, 53, 37), a)
+    assert (po.resize_mono8(np.full((40, 60), 99, dtype=np.uint8), 17, 23) == 99).all()
+    img, K, truth, size = synth.scene_c3()
+    small = po.resize_mono8(img, 1920, 1080)
+    dets, _ = po.detect(small, families=("synth36h11",), params=po.default_params(fx=2000, fy=2000, cx=960, cy=540, tag_size=size))
+    assert sorted(d["id"] for d in dets) == list(range(100))
+    img1, K1, _ = synth.scene_c1()
+    assert np.array_equal(po.rectify_mono8(img1, K1, [0, 0, 0, 0, 0], K1), img1)
+    warped = po.rectify_mono8(img1, K1, [-0.25, 0.07, 0.001, -0.002, 0.0], K1)
+    assert (warped != img1).mean() > 0.001 and [d["id"] for d in po.detect(warped, params=_params(K1))[0]] == [0]
