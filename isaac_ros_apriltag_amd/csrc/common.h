@@ -27,7 +27,7 @@ struct FrameCounters {
   uint32_t ndets;         // raw detections before reconcile
   uint32_t flags;         // AMDAT_FLAG_*
   uint32_t nout;          // detections after reconcile
-  uint32_t pad;
+  uint32_t nroots;        // tile-local component roots (CC root list)
 };
 
 struct ClusterRec {

@@ -74,7 +74,7 @@ void init_families() {
 }
 
 const char* kStageNames[AMDAT_NUM_STAGES] = {"upload_clear", "threshold", "cc_local",  "cc_border",
-                                             "cc_flatten",   "points",    "cluster_select", "scatter",
+                                             "cc_sizes",   "points",    "cluster_select", "scatter",
                                              "fit_quads",    "decode",    "reconcile", "download"};
 
 uint32_t next_pow2(uint32_t v) {
@@ -99,6 +99,7 @@ struct amdAprilTagsDetector_st {
   uint8_t* d_thr = nullptr;
   uint32_t* d_label = nullptr;
   uint32_t* d_csize = nullptr;
+  uint32_t* d_roots = nullptr;
   unsigned long long* d_hkeys = nullptr;
   uint32_t* d_hcnt = nullptr;
   uint32_t* d_hoff = nullptr;
@@ -220,7 +221,7 @@ int amdAprilTagsFamilyFromName(const char* name) {
 const char* amdAprilTagsStageName(uint32_t stage) { return stage < AMDAT_NUM_STAGES ? kStageNames[stage] : ""; }
 
 static void free_all(amdAprilTagsDetector_st* D) {
-  hipFree(D->d_gray); hipFree(D->d_thr); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_hkeys);
+  hipFree(D->d_gray); hipFree(D->d_thr); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_roots); hipFree(D->d_hkeys);
   hipFree(D->d_hcnt); hipFree(D->d_hoff); hipFree(D->d_stage); hipFree(D->d_rank); hipFree(D->d_pts); hipFree(D->d_clusters);
   hipFree(D->d_keys); hipFree(D->d_lf); hipFree(D->d_errs_a); hipFree(D->d_errs_b); hipFree(D->d_quads);
   hipFree(D->d_fqprof);
@@ -311,6 +312,7 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   alloc((void**)&D->d_thr, B * (size_t)H * P.WS);
   alloc((void**)&D->d_label, B * (size_t)npx * 4);
   alloc((void**)&D->d_csize, B * (size_t)npx * 4);
+  alloc((void**)&D->d_roots, B * (size_t)npx * 4);
   alloc((void**)&D->d_hkeys, B * (size_t)P.hcap * 8);
   alloc((void**)&D->d_hcnt, B * (size_t)P.hcap * 4);
   alloc((void**)&D->d_hoff, B * (size_t)P.hcap * 4);
@@ -447,7 +449,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
   launch_threshold(D, P, n, s);
   mark();
   hipLaunchKernelGGL(k_cc_local, dim3((P.W + CC_T - 1) / CC_T, (P.H + CC_T - 1) / CC_T, n), dim3(256), 0, s, D->d_thr,
-                     D->d_label, D->d_csize, P);
+                     D->d_label, D->d_csize, D->d_roots, D->d_counters, P);
   mark();
   {
     const int nrows = (P.H - 1) / CC_T, ncols = (P.W - 1) / CC_T;
@@ -456,8 +458,12 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
       hipLaunchKernelGGL(k_cc_border, dim3((unsigned)((total + 255) / 256), 1, n), dim3(256), 0, s, D->d_thr, D->d_label, P);
   }
   mark();
-  hipLaunchKernelGGL(k_cc_flatten, dim3((unsigned)(((size_t)P.W * P.H + 255) / 256), 1, n), dim3(256), 0, s, D->d_label,
-                     D->d_csize, P);
+  {
+    unsigned gr = (unsigned)(((size_t)P.W * P.H / 16 + 255) / 256);
+    if (gr < 1) gr = 1;
+    if (gr > 1024) gr = 1024;
+    hipLaunchKernelGGL(k_cc_sizes, dim3(gr, 1, n), dim3(256), 0, s, D->d_label, D->d_csize, D->d_roots, D->d_counters, P);
+  }
   mark();
   hipLaunchKernelGGL(k_points, dim3((P.W + PT_TW - 1) / PT_TW, (P.H + PT_TH - 1) / PT_TH, n), dim3(256), 0, s, D->d_thr,
                      D->d_label, D->d_csize, D->d_hkeys, D->d_hcnt, D->d_stage, D->d_rank, D->d_counters, P);
@@ -782,7 +788,14 @@ int amdAprilTagsDebugCopy(amdAprilTagsHandle handle, uint32_t frame, amdAprilTag
       if (host_dst) memcpy(host_dst, tmp.data(), npx < capacity ? npx : capacity);
       return AMDAT_SUCCESS;
     }
-    case AMDAT_DBG_LABEL: src = handle->d_label + (size_t)frame * npx; sz = npx * 4; break;
+    case AMDAT_DBG_LABEL: {
+      DetParams Pf = P;
+      Pf.frame0 = (int)frame;
+      hipLaunchKernelGGL(k_cc_flatten, dim3((unsigned)((npx + 255) / 256), 1, 1), dim3(256), 0, 0, handle->d_label, Pf);
+      HIP_TRY(hipDeviceSynchronize());
+      src = handle->d_label + (size_t)frame * npx; sz = npx * 4;
+      break;
+    }
     case AMDAT_DBG_CSIZE: src = handle->d_csize + (size_t)frame * npx; sz = npx * 4; break;
     case AMDAT_DBG_CLUSTERS:
       src = handle->d_clusters + (size_t)frame * P.ccap;

@@ -7,10 +7,14 @@
 //
 //   k_cc_local   one 64x64 tile per 256-thread block, entirely in LDS: wave-ballot run labelling
 //                of each 64-pixel row (no atomics), lock-free atomicMin union of rows, flatten,
-//                per-run size counting; writes global labels (index of the tile-local root) and
-//                the local size at root pixels.
+//                per-run size counting; writes global labels (index of the tile-local root), the
+//                local size at root pixels, and appends the tile's roots to a per-frame root list.
 //   k_cc_border  unions across tile borders with global atomicMin (only first-overlap pixels).
-//   k_cc_flatten path compression to the final representative + size accumulation at it.
+//   k_cc_sizes   over the root list only: every tile-local root is pointed at its final representative
+//                and its pixel count is added there.  Pixels keep the index of their tile-local root, so
+//                a consumer reaches the representative with two loads (label[label[p]]) and the image-wide
+//                flatten pass (12 B/pixel of traffic) is not needed.
+//   k_cc_flatten only used on demand by the stage-inspection call (writes representatives per pixel).
 #pragma once
 #include "common.h"
 
@@ -54,9 +58,11 @@ __device__ __forceinline__ void glb_union(uint32_t* L, uint32_t a, uint32_t b) {
 }
 
 __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ thr_all, uint32_t* __restrict__ label_all,
-                                                  uint32_t* __restrict__ csize_all, DetParams P) {
+                                                  uint32_t* __restrict__ csize_all, uint32_t* __restrict__ roots_all,
+                                                  FrameCounters* __restrict__ counters, DetParams P) {
   __shared__ __attribute__((aligned(16))) uint8_t st[CC_T * CC_T];
   __shared__ uint32_t sl[CC_T * CC_T];
+  __shared__ uint32_t s_nroots, s_rbase;
   const int frame = (int)blockIdx.z + P.frame0;
   const int X0 = blockIdx.x * CC_T, Y0 = blockIdx.y * CC_T;
   const int W = P.W, H = P.H;
@@ -146,9 +152,20 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   }
   __syncthreads();
 
-  // ---- 4. write global labels (index of the local root) and local sizes at the roots -----------
+  // ---- 4. write global labels (index of the local root), local sizes at the roots, root list -------
   uint32_t* label = label_all + (size_t)frame * W * H;
   uint32_t* csize = csize_all + (size_t)frame * W * H;
+  uint32_t* roots = roots_all + (size_t)frame * W * H;
+  if (tid == 0) s_nroots = 0;
+  __syncthreads();
+  uint32_t myroots = 0;
+  for (int k = 0; k < 16; k++)
+    if (root[k] != AT_NO_LABEL && root[k] == (uint32_t)((wv * 16 + k) * CC_T + lane)) myroots++;
+  uint32_t rpos = myroots ? atomicAdd(&s_nroots, myroots) : 0;
+  __syncthreads();
+  if (tid == 0) s_rbase = s_nroots ? atomicAdd(&counters[frame].nroots, s_nroots) : 0;
+  __syncthreads();
+  rpos += s_rbase;
   if (gx < W) {
     for (int k = 0; k < 16; k++) {
       const int r = wv * 16 + k;
@@ -156,10 +173,10 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
       if (gy >= H) break;
       const uint32_t me = (uint32_t)(r * CC_T + lane);
       const size_t gi = (size_t)gy * W + gx;
-      if (root[k] == AT_NO_LABEL) { label[gi] = AT_NO_LABEL; csize[gi] = 0; continue; }
+      if (root[k] == AT_NO_LABEL) { label[gi] = AT_NO_LABEL; continue; }
       const uint32_t rr = root[k] / CC_T, rc = root[k] % CC_T;
       label[gi] = (uint32_t)((Y0 + rr) * W + X0 + rc);
-      csize[gi] = (root[k] == me) ? sl[me] : 0;
+      if (root[k] == me) { csize[gi] = sl[me]; roots[rpos++] = (uint32_t)gi; }
     }
   }
 }
@@ -218,19 +235,37 @@ __global__ __launch_bounds__(256) void k_cc_border(const uint8_t* __restrict__ t
   }
 }
 
-__global__ __launch_bounds__(256) void k_cc_flatten(uint32_t* __restrict__ label_all, uint32_t* __restrict__ csize_all,
-                                                    DetParams P) {
+// one thread per tile-local root of the frame
+__global__ __launch_bounds__(256) void k_cc_sizes(uint32_t* __restrict__ label_all, uint32_t* __restrict__ csize_all,
+                                                  const uint32_t* __restrict__ roots_all, const FrameCounters* __restrict__ counters,
+                                                  DetParams P) {
   const int frame = (int)blockIdx.z + P.frame0;
   const size_t n = (size_t)P.W * P.H;
   uint32_t* label = label_all + (size_t)frame * n;
   uint32_t* csize = csize_all + (size_t)frame * n;
+  const uint32_t* roots = roots_all + (size_t)frame * n;
+  const uint32_t nroots = counters[frame].nroots;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nroots; i += gridDim.x * 256) {
+    const uint32_t p = roots[i];
+    uint32_t r = p, q;
+    while ((q = glb_load(&label[r])) != r) r = q;
+    if (r != p) {
+      label[p] = r;  // every chain through p now ends in one more hop
+      atomicAdd(&csize[r], csize[p]);
+    }
+  }
+}
+
+// Stage inspection only: representative per pixel (label[label[p]] after k_cc_sizes; idempotent).
+__global__ __launch_bounds__(256) void k_cc_flatten(uint32_t* __restrict__ label_all, DetParams P) {
+  const int frame = (int)blockIdx.z + P.frame0;
+  const size_t n = (size_t)P.W * P.H;
+  uint32_t* label = label_all + (size_t)frame * n;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  uint32_t l = label[i];
+  const uint32_t l = label[i];
   if (l == AT_NO_LABEL) return;
-  uint32_t r = l, p;
-  while ((p = glb_load(&label[r])) != r) r = p;
+  uint32_t r = l, q;
+  while ((q = glb_load(&label[r])) != r) r = q;
   if (r != l) label[i] = r;
-  const uint32_t c = csize[i];
-  if (c != 0 && r != (uint32_t)i) atomicAdd(&csize[r], c);
 }

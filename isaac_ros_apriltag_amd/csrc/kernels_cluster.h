@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     if (gx >= 0 && gx < W && gy < H) {
       v = thr[(size_t)gy * P.WS + gx];
       if (v != 127) {
-        const uint32_t r = label[(size_t)gy * W + gx];
+        // pixel -> its tile-local root -> the representative (k_cc_sizes left every local root one hop away)
+        const uint32_t r = label[label[(size_t)gy * W + gx]];
         if ((int)csize[r] >= P.min_component_size) lab = r;
       }
     }
