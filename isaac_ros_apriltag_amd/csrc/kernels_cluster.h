@@ -87,20 +87,35 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   const int X0 = blockIdx.x * PT_TW, Y0 = blockIdx.y * PT_TH;
   const int tid = threadIdx.x;
 
-  for (int i = tid; i < PT_LH * PT_LW; i += 256) {
-    const int ly = i / PT_LW, lx = i % PT_LW;
-    const int gx = X0 + lx - 1, gy = Y0 + ly;
-    uint32_t v = 127, lab = AT_NO_LABEL;
-    if (gx >= 0 && gx < W && gy < H) {
-      v = thr[(size_t)gy * P.WS + gx];
-      if (v != 127) {
-        // pixel -> its tile-local root -> the representative (k_cc_sizes left every local root one hop away)
-        const uint32_t r = label[label[(size_t)gy * W + gx]];
-        if ((int)csize[r] >= P.min_component_size) lab = r;
+  {
+    // tile + halo: 17 x 66 = 1122 entries, up to 5 per thread.  The three dependent gathers per entry
+    // (pixel -> tile-local root -> representative -> its size) are issued stage by stage for all of a
+    // thread's entries, so their latencies overlap instead of adding up.
+    constexpr int NE = (PT_LH * PT_LW + 255) / 256;
+    uint32_t v[NE], l[NE], r[NE];
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+      const int i = tid + e * 256;
+      v[e] = 127; l[e] = AT_NO_LABEL; r[e] = AT_NO_LABEL;
+      if (i < PT_LH * PT_LW) {
+        const int ly = i / PT_LW, lx = i % PT_LW;
+        const int gx = X0 + lx - 1, gy = Y0 + ly;
+        if (gx >= 0 && gx < W && gy < H) {
+          v[e] = thr[(size_t)gy * P.WS + gx];
+          l[e] = label[(size_t)gy * W + gx];
+        }
       }
     }
-    sv[i] = (uint8_t)v;
-    slab[i] = lab;
+#pragma unroll
+    for (int e = 0; e < NE; e++)
+      if (v[e] != 127 && l[e] != AT_NO_LABEL) r[e] = label[l[e]];
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+      const int i = tid + e * 256;
+      uint32_t lab = AT_NO_LABEL;
+      if (r[e] != AT_NO_LABEL && (int)csize[r[e]] >= P.min_component_size) lab = r[e];
+      if (i < PT_LH * PT_LW) { sv[i] = (uint8_t)v[e]; slab[i] = lab; }
+    }
   }
   tkey[tid] = AT_EMPTY_KEY;
   tcnt[tid] = 0;
