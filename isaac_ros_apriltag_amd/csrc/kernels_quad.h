@@ -415,8 +415,11 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 4 : 2)) void k_fit_quads(const Fra
 
     // ---- windowed line-fit error, smoothing ------------------------------------------------------
     const int ksz = min(20, szd / 12);
-    double* ea = errs_a_all + (size_t)frame * P.pcap + cl.start;
-    double* eb = errs_b_all + (size_t)frame * P.pcap + cl.start;
+    // error arrays: the key array is dead after the moment terms, so the raw errors live there (LDS);
+    // the smoothed errors use the pair-table region while it is still free (clusters up to 1024 points),
+    // global scratch otherwise
+    double* ea = in_lds ? reinterpret_cast<double*>(skeys) : errs_a_all + (size_t)frame * P.pcap + cl.start;
+    double* eb = (in_lds && szd <= 1024) ? chunk : errs_b_all + (size_t)frame * P.pcap + cl.start;
     // (indices wrap with compare/subtract: integer division by a run-time value costs ~40 instructions)
     for (int i = tid; i < szd; i += NT) {
       double e;
