@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU (BASELINE.md protocol sweeps 1, 8, 64, 256)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct rendered frames per stream")
     ap.add_argument("--sigma", type=float, default=2.0)
     ap.add_argument("--decimate", type=int, default=1)
