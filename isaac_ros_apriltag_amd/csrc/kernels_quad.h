@@ -187,6 +187,70 @@ __device__ __forceinline__ void bitonic_sort_block(KeyPtr A, int n) {
   }
 }
 
+// Two network steps per pass: a thread owns a group of four elements that is closed under two
+// consecutive steps (flip + half-cleaner, or two half-cleaners), so every element is loaded and stored
+// once per two steps and the workgroup synchronises half as often.  Indices >= n behave as +infinity.
+template <int NT, typename KeyPtr>
+__device__ __forceinline__ void bitonic_sort_block2(KeyPtr A, int n) {
+  const unsigned long long INF = ~0ull;
+  int lpow = 0;
+  while ((1 << lpow) < n) lpow++;
+  const int half = (1 << lpow) >> 1, quarter = half >> 1;
+  auto ce = [](unsigned long long& lo, unsigned long long& hi) {
+    if (lo > hi) { const unsigned long long t = lo; lo = hi; hi = t; }
+  };
+  for (int lk = 1; lk <= lpow; lk++) {
+    int s = 0;  // step 0 = flip of blocks of 2^lk, step t >= 1 = half-cleaner of stride 2^(lk-1-t)
+    while (s < lk) {
+      if (s + 1 < lk) {
+        for (int g = threadIdx.x; g < quarter; g += NT) {
+          int x0, x1, x2, x3;
+          if (s == 0) {
+            const int lq = lk - 2, qm = (1 << lq) - 1;  // quarter block
+            const int blk = g >> lq, off = g & qm;
+            x0 = (blk << lk) + off; x1 = x0 + (1 << lq);
+            x3 = (blk << lk) + (1 << lk) - 1 - off; x2 = x3 - (1 << lq);
+          } else {
+            const int lj = lk - 1 - s;          // first stride 2^lj, second 2^(lj-1)
+            const int lh = lj - 1, hm = (1 << lh) - 1;
+            x0 = ((g >> lh) << (lj + 1)) + (g & hm);
+            x1 = x0 + (1 << lh); x2 = x0 + (1 << lj); x3 = x2 + (1 << lh);
+          }
+          if (x1 >= n && x2 >= n) continue;  // nothing but x0 is real: no exchange possible
+          unsigned long long v0 = A[x0];
+          unsigned long long v1 = x1 < n ? A[x1] : INF, v2 = x2 < n ? A[x2] : INF, v3 = x3 < n ? A[x3] : INF;
+          if (s == 0) { ce(v0, v3); ce(v1, v2); ce(v0, v1); ce(v2, v3); }
+          else { ce(v0, v2); ce(v1, v3); ce(v0, v1); ce(v2, v3); }
+          A[x0] = v0;
+          if (x1 < n) A[x1] = v1;
+          if (x2 < n) A[x2] = v2;
+          if (x3 < n) A[x3] = v3;
+        }
+        __syncthreads();
+        s += 2;
+      } else {
+        for (int i = threadIdx.x; i < half; i += NT) {
+          int a, b;
+          if (s == 0) {
+            const int lhk = lk - 1, hkm = (1 << lhk) - 1;
+            const int blk = i >> lhk, off = i & hkm;
+            a = (blk << lk) + off; b = (blk << lk) + (1 << lk) - 1 - off;
+          } else {
+            const int lj = lk - 1 - s, jm = (1 << lj) - 1;
+            a = ((i >> lj) << (lj + 1)) + (i & jm); b = a + (1 << lj);
+          }
+          if (b < n) {
+            const unsigned long long x = A[a], y = A[b];
+            if (x > y) { A[a] = y; A[b] = x; }
+          }
+        }
+        __syncthreads();
+        s += 1;
+      }
+    }
+  }
+}
+
 // lexicographic index of the 4-subsets of {0..9}: entry t = {m0,m1,m2,m3} packed 4 bits each
 __device__ __forceinline__ uint32_t combo_of(int t) {
   int c = 0;
@@ -304,7 +368,7 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 4 : 2)) void k_fit_quads(const Fra
       if (in_lds) skeys[i] = key; else gkeys[i] = key;
     }
     __syncthreads();
-    if (in_lds) bitonic_sort_block<NT>(skeys, sz); else bitonic_sort_block<NT>(gkeys, sz);
+    if (in_lds) bitonic_sort_block2<NT>(skeys, sz); else bitonic_sort_block2<NT>(gkeys, sz);
     // ---- remove duplicate points (same half-pixel location; adjacent after the sort) ----------------
     // chunk by chunk: a chunk is read, the block synchronises, then it is written at or below where it
     // was read, so no unread element is ever overwritten
