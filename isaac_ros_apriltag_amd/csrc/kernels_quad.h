@@ -187,66 +187,76 @@ __device__ __forceinline__ void bitonic_sort_block(KeyPtr A, int n) {
   }
 }
 
-// Two network steps per pass: a thread owns a group of four elements that is closed under two
-// consecutive steps (flip + half-cleaner, or two half-cleaners), so every element is loaded and stored
-// once per two steps and the workgroup synchronises half as often.  Indices >= n behave as +infinity.
-template <int NT, typename KeyPtr>
-__device__ __forceinline__ void bitonic_sort_block2(KeyPtr A, int n) {
-  const unsigned long long INF = ~0ull;
-  int lpow = 0;
-  while ((1 << lpow) < n) lpow++;
-  const int half = (1 << lpow) >> 1, quarter = half >> 1;
+// Up to three network steps per pass: a thread owns a group of 2^r elements that is closed under r
+// consecutive steps (a flip followed by half-cleaners, or half-cleaners only), so every element is
+// loaded and stored once per r steps and the workgroup synchronises a third as often.  Indices >= n
+// behave as +infinity and are never written.
+template <int R>
+__device__ __forceinline__ void bitonic_group(unsigned long long (&v)[8], bool flip_first) {
+  constexpr int M = 1 << R;
   auto ce = [](unsigned long long& lo, unsigned long long& hi) {
     if (lo > hi) { const unsigned long long t = lo; lo = hi; hi = t; }
   };
+  int first_stride = M >> 1;
+  if (flip_first) {
+#pragma unroll
+    for (int e = 0; e < M / 2; e++) ce(v[e], v[M - 1 - e]);
+    first_stride = M >> 2;
+  }
+#pragma unroll
+  for (int st = M >> 1; st >= 1; st >>= 1) {
+    if (st > first_stride) continue;
+#pragma unroll
+    for (int e = 0; e < M; e++)
+      if ((e & st) == 0) ce(v[e], v[e + st]);
+  }
+}
+
+template <int NT, int R, typename KeyPtr>
+__device__ __forceinline__ void bitonic_pass_r(KeyPtr A, int n, int lpow, int lk, int s) {
+  // steps s .. s+R-1 of merge level lk (step 0 = flip of 2^lk blocks, step t = half-cleaner of stride 2^(lk-1-t))
+  constexpr int M = 1 << R;
+  const unsigned long long INF = ~0ull;
+  const int ngroups = (1 << lpow) >> R;
+  // spacing of the group's elements: 2^lsp, where the last step's stride is 2^(lk-1-(s+R-1)) = 2^lsp
+  const int lsp = lk - s - R;
+  const int spm = (1 << lsp) - 1;
+  for (int g = threadIdx.x; g < ngroups; g += NT) {
+    int idx[M];
+    if (s == 0) {
+      // lower side ascending, upper side mirrored: positions 0..M/2-1 are x_e, M/2..M-1 are y_(M/2-1-e')
+      const int blk = g >> lsp, off = g & spm;
+      const int lo = (blk << lk) + off, hi = (blk << lk) + (1 << lk) - 1 - off;
+#pragma unroll
+      for (int e = 0; e < M / 2; e++) { idx[e] = lo + (e << lsp); idx[M - 1 - e] = hi - (e << lsp); }
+    } else {
+      const int base = ((g >> lsp) << (lsp + R)) + (g & spm);
+#pragma unroll
+      for (int e = 0; e < M; e++) idx[e] = base + (e << lsp);
+    }
+    if (idx[1] >= n) continue;  // at most one real element: nothing to exchange
+    unsigned long long v[8];
+#pragma unroll
+    for (int e = 0; e < M; e++) v[e] = idx[e] < n ? A[idx[e]] : INF;
+    bitonic_group<R>(v, s == 0);
+#pragma unroll
+    for (int e = 0; e < M; e++)
+      if (idx[e] < n) A[idx[e]] = v[e];
+  }
+  __syncthreads();
+}
+
+template <int NT, typename KeyPtr>
+__device__ __forceinline__ void bitonic_sort_block2(KeyPtr A, int n) {
+  int lpow = 0;
+  while ((1 << lpow) < n) lpow++;
   for (int lk = 1; lk <= lpow; lk++) {
-    int s = 0;  // step 0 = flip of blocks of 2^lk, step t >= 1 = half-cleaner of stride 2^(lk-1-t)
+    int s = 0;
     while (s < lk) {
-      if (s + 1 < lk) {
-        for (int g = threadIdx.x; g < quarter; g += NT) {
-          int x0, x1, x2, x3;
-          if (s == 0) {
-            const int lq = lk - 2, qm = (1 << lq) - 1;  // quarter block
-            const int blk = g >> lq, off = g & qm;
-            x0 = (blk << lk) + off; x1 = x0 + (1 << lq);
-            x3 = (blk << lk) + (1 << lk) - 1 - off; x2 = x3 - (1 << lq);
-          } else {
-            const int lj = lk - 1 - s;          // first stride 2^lj, second 2^(lj-1)
-            const int lh = lj - 1, hm = (1 << lh) - 1;
-            x0 = ((g >> lh) << (lj + 1)) + (g & hm);
-            x1 = x0 + (1 << lh); x2 = x0 + (1 << lj); x3 = x2 + (1 << lh);
-          }
-          if (x1 >= n && x2 >= n) continue;  // nothing but x0 is real: no exchange possible
-          unsigned long long v0 = A[x0];
-          unsigned long long v1 = x1 < n ? A[x1] : INF, v2 = x2 < n ? A[x2] : INF, v3 = x3 < n ? A[x3] : INF;
-          if (s == 0) { ce(v0, v3); ce(v1, v2); ce(v0, v1); ce(v2, v3); }
-          else { ce(v0, v2); ce(v1, v3); ce(v0, v1); ce(v2, v3); }
-          A[x0] = v0;
-          if (x1 < n) A[x1] = v1;
-          if (x2 < n) A[x2] = v2;
-          if (x3 < n) A[x3] = v3;
-        }
-        __syncthreads();
-        s += 2;
-      } else {
-        for (int i = threadIdx.x; i < half; i += NT) {
-          int a, b;
-          if (s == 0) {
-            const int lhk = lk - 1, hkm = (1 << lhk) - 1;
-            const int blk = i >> lhk, off = i & hkm;
-            a = (blk << lk) + off; b = (blk << lk) + (1 << lk) - 1 - off;
-          } else {
-            const int lj = lk - 1 - s, jm = (1 << lj) - 1;
-            a = ((i >> lj) << (lj + 1)) + (i & jm); b = a + (1 << lj);
-          }
-          if (b < n) {
-            const unsigned long long x = A[a], y = A[b];
-            if (x > y) { A[a] = y; A[b] = x; }
-          }
-        }
-        __syncthreads();
-        s += 1;
-      }
+      const int left = lk - s;
+      if (left >= 3) { bitonic_pass_r<NT, 3>(A, n, lpow, lk, s); s += 3; }
+      else if (left == 2) { bitonic_pass_r<NT, 2>(A, n, lpow, lk, s); s += 2; }
+      else { bitonic_pass_r<NT, 1>(A, n, lpow, lk, s); s += 1; }
     }
   }
 }
