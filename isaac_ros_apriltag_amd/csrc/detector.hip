@@ -419,7 +419,7 @@ static void fill_frames(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTa
 }
 
 static void launch_threshold(amdAprilTagsDetector_st* D, const DetParams& P, uint32_t n, hipStream_t s) {
-  const int gx = ((P.W + 3) / 4 + 127) / 128, gy = ((P.H + 3) / 4 + 7) / 8;
+  const int gx = ((P.W + 3) / 4 + TH_BTX - 1) / TH_BTX, gy = ((P.H + 3) / 4 + TH_BTY - 1) / TH_BTY;
   const unsigned ntiles = (unsigned)gx * gy * n;
   dim3 grid(8u * ((ntiles + 7u) / 8u));
   const bool leftover = (P.W % 4) || (P.H % 4);

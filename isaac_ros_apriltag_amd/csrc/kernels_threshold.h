@@ -3,15 +3,15 @@
 // cuAprilTagsDetect call (reference src/apriltag_node.cpp:491-493); semantics per SURVEY.md A.1/A.2.
 //
 // HBM-bound streaming kernel, 2 B/pixel algorithmic (1 read + 1 written):
-//   * a 256-thread block owns a 512 x 32 pixel region (128 x 8 tiles); every thread owns a
-//     16 x 4 pixel unit = 4 tiles and keeps its 64 pixels in registers (4 x 16-byte loads);
-//   * per-tile min/max go to LDS (u8, 10 x 132 incl. a one-tile halo ring), the 3x3 dilation reads
-//     two aligned dwords per halo row, the thresholded unit leaves as 4 x 16-byte stores;
+//   * a 256-thread block owns a 1024 x 32 pixel region (256 x 8 tiles); every thread owns two
+//     16 x 4 pixel units = 8 tiles and keeps its 128 pixels in registers (8 x 16-byte loads);
+//   * per-tile min/max go to LDS (u8, 10 x 260 incl. a one-tile halo ring), the 3x3 dilation reads
+//     two aligned dwords per halo row, the thresholded units leave as 8 x 16-byte stores;
 //   * the halo ring (2 tile rows + 2 tile columns) is recomputed from the image (L2 hits).
 #pragma once
 #include "common.h"
 
-#define TH_LDS_STRIDE 132  // bytes per LDS tile row (33 dwords)
+#define TH_LDS_STRIDE 260  // bytes per LDS tile row (65 dwords): 256 tiles + one halo tile each side
 
 // one working-image pixel through the decimating gather (slow path: halos, edges, unaligned input)
 template <int DEC>
@@ -73,6 +73,12 @@ __device__ __forceinline__ void th_minmax_word(uint32_t w, uint32_t& mn, uint32_
 // tiles (x fastest, then y, then frame), which keeps the halo rows a block re-reads from its vertical
 // neighbours in that XCD's own L2 instead of fetching them again over the fabric.  Placement is a speed
 // matter only: any block->tile bijection gives the same result.
+//
+// Block geometry: 256 threads as 64 (x) by 4 (y); a thread owns two vertically stacked 16x4-pixel units,
+// so a block covers 1024 x 32 pixels (256 x 8 tiles) and every wave-wide load is one contiguous 1 KiB
+// row segment.
+#define TH_BTX 256  // tiles per block in x
+#define TH_BTY 8    // tiles per block in y
 template <int DEC>
 __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__ frames, uint8_t* __restrict__ gray_all,
                                                    uint8_t* __restrict__ thr_all, int gx, int gy, int nframes, DetParams P) {
@@ -90,40 +96,46 @@ __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__
   const FrameDesc fd = frames[frame];
   const bool aligned = ((((uintptr_t)fd.img) | (uintptr_t)fd.pitch) & 15) == 0;
   const int tid = threadIdx.x;
-  const int tx32 = tid & 31, ty8 = tid >> 5;
-  const int TX0 = bx * 128, TY0 = by * 8;  // first tile of the block
+  const int tx64 = tid & 63, ty4 = tid >> 6;
+  const int TX0 = bx * TH_BTX, TY0 = by * TH_BTY;  // first tile of the block
   uint8_t* thr = thr_all + (size_t)frame * P.H * P.WS;
   uint8_t* gray = (DEC > 1) ? gray_all + (size_t)frame * P.H * P.WS : nullptr;
 
-  // ---- own unit: 16 x 4 pixels --------------------------------------------------------------
-  const int ux = (TX0 + 4 * tx32) * 4, uy = (TY0 + ty8) * 4;
-  uint32_t u[4][4];
+  // ---- own units: 2 x (16 x 4 pixels) ---------------------------------------------------------
+  const int ux = (TX0 + 4 * tx64) * 4;
+  uint32_t u[2][4][4];
 #pragma unroll
-  for (int r = 0; r < 4; r++) th_load16<DEC>(fd.img, fd.pitch, P.W0, P.H0, aligned, ux, uy + r, u[r]);
-  if (DEC > 1) {
+  for (int v = 0; v < 2; v++) {
+    const int uy = (TY0 + 2 * ty4 + v) * 4;
 #pragma unroll
-    for (int r = 0; r < 4; r++)
-      if (uy + r < P.H && ux < P.WS)
-        *reinterpret_cast<uint4*>(gray + (size_t)(uy + r) * P.WS + ux) = make_uint4(u[r][0], u[r][1], u[r][2], u[r][3]);
+    for (int r = 0; r < 4; r++) th_load16<DEC>(fd.img, fd.pitch, P.W0, P.H0, aligned, ux, uy + r, u[v][r]);
   }
-  {
-    const int tY = TY0 + ty8;
+#pragma unroll
+  for (int v = 0; v < 2; v++) {
+    const int lty = 2 * ty4 + v;
+    const int tY = TY0 + lty, uy = tY * 4;
+    if (DEC > 1) {
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (uy + r < P.H && ux < P.WS)
+          *reinterpret_cast<uint4*>(gray + (size_t)(uy + r) * P.WS + ux) = make_uint4(u[v][r][0], u[v][r][1], u[v][r][2], u[v][r][3]);
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const int tX = TX0 + 4 * tx32 + j;
+      const int tX = TX0 + 4 * tx64 + j;
       uint32_t mn = 255, mx = 0;
       if (tX < P.tw && tY < P.th) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) th_minmax_word(u[r][j], mn, mx);
+        for (int r = 0; r < 4; r++) th_minmax_word(u[v][r][j], mn, mx);
       }
-      smin[(ty8 + 1) * TH_LDS_STRIDE + 4 * tx32 + j + 1] = (uint8_t)mn;
-      smax[(ty8 + 1) * TH_LDS_STRIDE + 4 * tx32 + j + 1] = (uint8_t)mx;
+      smin[(lty + 1) * TH_LDS_STRIDE + 4 * tx64 + j + 1] = (uint8_t)mn;
+      smax[(lty + 1) * TH_LDS_STRIDE + 4 * tx64 + j + 1] = (uint8_t)mx;
     }
   }
   // ---- halo ring ----------------------------------------------------------------------------
-  if (tid < 64) {  // tile rows TY0-1 and TY0+8, 32 units each
-    const int side = tid >> 5, c = tid & 31;
-    const int tY = side ? TY0 + 8 : TY0 - 1;
+  if (tid < 128) {  // tile rows TY0-1 and TY0+8, 64 units each
+    const int side = tid >> 6, c = tid & 63;
+    const int tY = side ? TY0 + TH_BTY : TY0 - 1;
     const int lrow = side ? 9 : 0;
     uint32_t h[4][4];
     const bool rowok = tY >= 0 && tY < P.th;
@@ -142,10 +154,10 @@ __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__
       smin[lrow * TH_LDS_STRIDE + 4 * c + j + 1] = (uint8_t)mn;
       smax[lrow * TH_LDS_STRIDE + 4 * c + j + 1] = (uint8_t)mx;
     }
-  } else if (tid < 84) {  // tile columns TX0-1 and TX0+128, tile rows TY0-1 .. TY0+8
-    const int k = tid - 64;
+  } else if (tid < 148) {  // tile columns TX0-1 and TX0+256, tile rows TY0-1 .. TY0+8
+    const int k = tid - 128;
     const int side = k / 10, lrow = k % 10;
-    const int tX = side ? TX0 + 128 : TX0 - 1;
+    const int tX = side ? TX0 + TH_BTX : TX0 - 1;
     const int tY = TY0 - 1 + lrow;
     uint32_t mn = 255, mx = 0;
     if (tX >= 0 && tX < P.tw && tY >= 0 && tY < P.th) {
@@ -156,69 +168,73 @@ __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__
           mx = max(mx, v);
         }
     }
-    const int lcol = side ? 129 : 0;
+    const int lcol = side ? TH_BTX + 1 : 0;
     smin[lrow * TH_LDS_STRIDE + lcol] = (uint8_t)mn;
     smax[lrow * TH_LDS_STRIDE + lcol] = (uint8_t)mx;
   }
   __syncthreads();
 
   // ---- 3x3 dilation / erosion over tiles, then binarize --------------------------------------
-  // LDS columns 4*tx32 .. 4*tx32+5 hold tiles (first-1) .. (first+4): two aligned dwords per row.
-  uint32_t cmin[6], cmax[6];
+  // LDS columns 4*tx64 .. 4*tx64+5 hold tiles (first-1) .. (first+4): two aligned dwords per row.
 #pragma unroll
-  for (int c = 0; c < 6; c++) { cmin[c] = 255; cmax[c] = 0; }
+  for (int v = 0; v < 2; v++) {
+    const int lty = 2 * ty4 + v;
+    const int tY = TY0 + lty, uy = tY * 4;
+    if (tY >= P.th) continue;
+    uint32_t cmin[6], cmax[6];
 #pragma unroll
-  for (int dr = 0; dr < 3; dr++) {
-    const uint32_t* rmin = reinterpret_cast<const uint32_t*>(smin + (ty8 + dr) * TH_LDS_STRIDE + 4 * tx32);
-    const uint32_t* rmax = reinterpret_cast<const uint32_t*>(smax + (ty8 + dr) * TH_LDS_STRIDE + 4 * tx32);
-    uint32_t a0 = rmin[0], a1 = rmin[1], b0 = rmax[0], b1 = rmax[1];
+    for (int c = 0; c < 6; c++) { cmin[c] = 255; cmax[c] = 0; }
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-      cmin[c] = min(cmin[c], (a0 >> (8 * c)) & 0xFF);
-      cmax[c] = max(cmax[c], (b0 >> (8 * c)) & 0xFF);
+    for (int dr = 0; dr < 3; dr++) {
+      const uint32_t* rmin = reinterpret_cast<const uint32_t*>(smin + (lty + dr) * TH_LDS_STRIDE + 4 * tx64);
+      const uint32_t* rmax = reinterpret_cast<const uint32_t*>(smax + (lty + dr) * TH_LDS_STRIDE + 4 * tx64);
+      const uint32_t a0 = rmin[0], a1 = rmin[1], b0 = rmax[0], b1 = rmax[1];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        cmin[c] = min(cmin[c], (a0 >> (8 * c)) & 0xFF);
+        cmax[c] = max(cmax[c], (b0 >> (8 * c)) & 0xFF);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        cmin[4 + c] = min(cmin[4 + c], (a1 >> (8 * c)) & 0xFF);
+        cmax[4 + c] = max(cmax[4 + c], (b1 >> (8 * c)) & 0xFF);
+      }
     }
+    uint32_t o[4][4];
+    bool valid[4];
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-      cmin[4 + c] = min(cmin[4 + c], (a1 >> (8 * c)) & 0xFF);
-      cmax[4 + c] = max(cmax[4 + c], (b1 >> (8 * c)) & 0xFF);
+    for (int j = 0; j < 4; j++) {
+      const int tX = TX0 + 4 * tx64 + j;
+      valid[j] = tX < P.tw;
+      const uint32_t mn = min(min(cmin[j], cmin[j + 1]), cmin[j + 2]);
+      const uint32_t mx = max(max(cmax[j], cmax[j + 1]), cmax[j + 2]);
+      if ((int)(mx - mn) < P.min_white_black_diff) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[r][j] = 0x7F7F7F7Fu;
+      } else {
+        const uint32_t thresh = mn + (mx - mn) / 2;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const uint32_t w = u[v][r][j];
+          uint32_t ow = 0;
+#pragma unroll
+          for (int b = 0; b < 4; b++) ow |= (((w >> (8 * b)) & 0xFF) > thresh ? 0xFFu : 0u) << (8 * b);
+          o[r][j] = ow;
+        }
+      }
     }
-  }
-  const int tY = TY0 + ty8;
-  if (tY >= P.th) return;
-  uint32_t o[4][4];
-  bool valid[4];
+    if (valid[3]) {
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int tX = TX0 + 4 * tx32 + j;
-    valid[j] = tX < P.tw;
-    const uint32_t mn = min(min(cmin[j], cmin[j + 1]), cmin[j + 2]);
-    const uint32_t mx = max(max(cmax[j], cmax[j + 1]), cmax[j + 2]);
-    if ((int)(mx - mn) < P.min_white_black_diff) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) o[r][j] = 0x7F7F7F7Fu;
+      for (int r = 0; r < 4; r++)
+        *reinterpret_cast<uint4*>(thr + (size_t)(uy + r) * P.WS + ux) = make_uint4(o[r][0], o[r][1], o[r][2], o[r][3]);
     } else {
-      const uint32_t thresh = mn + (mx - mn) / 2;
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const uint32_t w = u[r][j];
-        uint32_t ow = 0;
+      for (int j = 0; j < 4; j++)
+        if (valid[j]) {
 #pragma unroll
-        for (int b = 0; b < 4; b++) ow |= (((w >> (8 * b)) & 0xFF) > thresh ? 0xFFu : 0u) << (8 * b);
-        o[r][j] = ow;
-      }
+          for (int r = 0; r < 4; r++) *reinterpret_cast<uint32_t*>(thr + (size_t)(uy + r) * P.WS + ux + 4 * j) = o[r][j];
+        }
     }
-  }
-  if (valid[3]) {
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-      *reinterpret_cast<uint4*>(thr + (size_t)(uy + r) * P.WS + ux) = make_uint4(o[r][0], o[r][1], o[r][2], o[r][3]);
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (valid[j]) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) *reinterpret_cast<uint32_t*>(thr + (size_t)(uy + r) * P.WS + ux + 4 * j) = o[r][j];
-      }
   }
 }
 
