@@ -371,3 +371,42 @@ def test_front_steps_bit_exact(built):
     assert L.amdAprilTagsRectifyMono8(t1.data_ptr(), 640, r.data_ptr(), 640, 640, 480, k, d5, kn, None) == 0
     assert np.array_equal(r.cpu().numpy(), po.rectify_mono8(img1, K1, D, Kn))
     assert L.amdAprilTagsRectifyMono8(t1.data_ptr(), 640, r.data_ptr(), 640, 640, 480, k, d5, None, None) == 1
+
+
+def test_random_scene_sweep(built):
+    """Seeded sweep over 48 random VGA scenes (1-4 tags of random family/id/pose, noise sigma 0-8,
+    decimate 1-2, one or two families enabled): detections bit-identical to the oracle on every one."""
+    rng = np.random.default_rng(20260927)
+    fams_all = ("tag36h11", "tag25h9", "tag16h5")
+    K = synth.default_K(640, 480)
+    dets_by_key = {}
+    total = 0
+    for case in range(48):
+        ntags = int(rng.integers(1, 5))
+        enabled = tuple(rng.choice(fams_all, size=int(rng.integers(1, 3)), replace=False))
+        tags = []
+        for t in range(ntags):
+            fam = str(rng.choice(fams_all))
+            ncodes = {"tag36h11": 27, "tag25h9": 35, "tag16h5": 30}[fam]
+            side = float(rng.uniform(40, 110))
+            cx, cy = float(rng.uniform(120, 520)), float(rng.uniform(100, 380))
+            R = synth.rot_xyz(float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-3.1, 3.1)))
+            z = K[0, 0] * 0.1 / side
+            tvec = np.array([(cx - 320) / K[0, 0] * z, (cy - 240) / K[1, 1] * z, z])
+            tags.append({"family": fam, "id": int(rng.integers(0, ncodes)), "H": synth.homography_from_pose(R, tvec, K, 0.1)})
+        sigma = float(rng.choice([0.0, 1.0, 2.0, 4.0, 8.0]))
+        dec = int(rng.choice([1, 2]))
+        img = synth.render(640, 480, tags, background=int(rng.integers(90, 200)), sigma=sigma, seed=1000 + case)
+        key = (enabled, dec)
+        if key not in dets_by_key:
+            dets_by_key[key] = AprilTagDetector(640, 480, families=enabled, decimate=dec, intrinsics=_k4(K), tag_size=0.1, max_batch=1)
+        det = dets_by_key[key]
+        g = det.detect_batch_ex(torch.from_numpy(img).cuda(), max_dets=64)[0]
+        o, _ = po.detect(img, families=enabled, params=pu.oracle_params(K, dec, 0.1))
+        errs = pu.compare_detections(g, o)
+        assert not errs, (case, enabled, dec, sigma, errs[:3])
+        assert det.frame_flags(1) == [0]
+        total += len(o)
+    for d in dets_by_key.values():
+        d.close()
+    assert total >= 30   # the sweep does exercise real detections
