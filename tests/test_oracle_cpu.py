@@ -263,3 +263,40 @@ def test_front_steps_resize_and_rectify(built):
     assert np.array_equal(po.rectify_mono8(img1, K1, [0, 0, 0, 0, 0], K1), img1)
     warped = po.rectify_mono8(img1, K1, [-0.25, 0.07, 0.001, -0.002, 0.0], K1)
     assert (warped != img1).mean() > 0.001 and [d["id"] for d in po.detect(warped, params=_params(K1))[0]] == [0]
+
+
+def test_random_scene_sweep_vs_ground_truth(built):
+    """The oracle against the renderer's ground truth over 40 random VGA scenes: every error-free
+    (hamming 0) tag36h11/tag25h9 detection is a rendered tag with corners within 1 px (2-bit-corrected
+    false positives from noise blobs are a known property of the small families and are tolerated), and
+    at least 85 % of the rendered tags are found."""
+    rng = np.random.default_rng(7)
+    K = synth.default_K(640, 480)
+    found = expected = 0
+    for case in range(40):
+        fam = ("tag36h11", "tag25h9")[case % 2]
+        ncodes = {"tag36h11": 27, "tag25h9": 35}[fam]
+        tags, truth = [], []
+        centers = [(170.0, 130.0), (470.0, 130.0), (170.0, 350.0), (470.0, 350.0)]
+        for t in range(int(rng.integers(1, 5))):
+            side = float(rng.uniform(50, 100))
+            cx, cy = centers[t][0] + float(rng.uniform(-25, 25)), centers[t][1] + float(rng.uniform(-20, 20))
+            R = synth.rot_xyz(float(rng.uniform(-0.45, 0.45)), float(rng.uniform(-0.45, 0.45)), float(rng.uniform(-3.1, 3.1)))
+            z = K[0, 0] * 0.1 / side
+            tvec = np.array([(cx - 320) / K[0, 0] * z, (cy - 240) / K[1, 1] * z, z])
+            H = synth.homography_from_pose(R, tvec, K, 0.1)
+            tid = int(rng.integers(0, ncodes))
+            tags.append({"family": fam, "id": tid, "H": H})
+            truth.append(synth.truth_from_H(fam, tid, H, R, tvec))
+        sigma = float(rng.choice([0.0, 1.0, 2.0, 4.0]))
+        img = synth.render(640, 480, tags, background=int(rng.integers(100, 190)), sigma=sigma, seed=500 + case)
+        dets, _ = po.detect(img, families=(fam,), params=_params(K, tag_size=0.1))
+        expected += len(truth)
+        for d in dets:
+            match = [t for t in truth if t["id"] == d["id"] and np.abs(t["p"] - d["p"]).max() < 1.0]
+            if not match and d["hamming"] > 0:
+                continue
+            assert match, (case, d["id"], d["hamming"])
+            assert np.abs(match[0]["t"] - d["t"]).max() < 0.05 * match[0]["t"][2] + 0.01
+            found += 1
+    assert found >= 0.85 * expected, (found, expected)
