@@ -301,7 +301,7 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   if (P.hcap < 256) P.hcap = 256;
   { uint32_t lg = 0; while ((1u << lg) < P.hcap) lg++; P.hshift = 64 - lg; }
   P.ccap = cfg.max_clusters ? cfg.max_clusters : (P.hcap < 65536 ? P.hcap : 65536);
-  P.qcap = cfg.max_quads ? cfg.max_quads : 8192;
+  P.qcap = cfg.max_quads ? cfg.max_quads : P.ccap;   // a quad needs its own kept cluster
   P.dcap = cfg.max_detections ? cfg.max_detections : 1024;
   if (P.dcap > 65535) P.dcap = 65535;
 

@@ -410,3 +410,31 @@ def test_random_scene_sweep(built):
     for d in dets_by_key.values():
         d.close()
     assert total >= 30   # the sweep does exercise real detections
+
+
+def test_adversarial_content_fuzz(built):
+    """300 seeded cases from tools/fuzz_gpu.py: checkerboards, stripes, gradients, rings, impulses, two-level
+    noise, rectangles and tag scenes at ragged sizes (4..300 px), odd pitches, decimate 1-4, one to three
+    families: every stage and every detection bit-identical to the oracle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_gpu", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_gpu.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    done, fails = fz.run_cases(300, seed=20260928, maxdim=300, out=lambda m: None)
+    assert done == 300 and not fails, fails[:3]
+
+
+def test_checkerboard_more_quads_than_the_old_fixed_capacity(built):
+    """A 1262x1162 checkerboard of 9-px cells fits ~20 000 quads (every cell is one); the default quad
+    capacity follows the cluster capacity, so nothing is dropped and no overflow flag is raised."""
+    yy, xx = np.mgrid[0:1162, 0:1262]
+    img = ((((yy // 9) + (xx // 9)) & 1) * 200 + 20).astype(np.uint8)
+    K = synth.default_K(1262, 1162)
+    det, g = _run(img, K, families=("tag16h5",))
+    errs, odets = pu.compare_stages(det, 0, img, ("tag16h5",), K, 1)
+    errs += pu.compare_detections(g, odets)
+    nq = len(det.debug(0, capi.DBG_QUADS))
+    det.close()
+    assert not errs, errs[:3]
+    assert nq > 8192

@@ -1,0 +1,152 @@
+"""GPU-vs-oracle fuzzer: adversarial frame content x ragged sizes x pitches x decimation x families.
+
+Run on the GPU box:  python tools/fuzz_gpu.py [--cases N] [--seed S]
+Every case compares every stage (gray, threshold, labels, sizes, clusters, points, quads) and the final
+detections bit-for-bit through the C ABI.  Prints one line per failing case and a summary; exit code 1 on
+any mismatch.  Test infrastructure (uses oracle/).
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+
+import torch  # noqa: E402
+
+from isaac_ros_apriltag_amd import synth  # noqa: E402
+from isaac_ros_apriltag_amd.detector import AprilTagDetector  # noqa: E402
+import parity_util as pu  # noqa: E402
+
+
+def gen_content(rng, h, w):
+    kind = rng.integers(0, 12)
+    yy, xx = np.mgrid[0:h, 0:w]
+    if kind == 0:    # checkerboard with random cell size 1..9
+        c = int(rng.integers(1, 10))
+        img = (((yy // c) + (xx // c)) & 1) * int(rng.integers(30, 255))
+    elif kind == 1:  # stripes (h or v) with random period and phase
+        p = int(rng.integers(2, 24))
+        a = xx if rng.integers(0, 2) else yy
+        img = ((a + int(rng.integers(0, p))) % p < p // 2) * 220 + 10
+    elif kind == 2:  # smooth gradient + faint noise (low contrast tiles -> 127)
+        img = (xx * 255.0 / max(w - 1, 1)) + rng.normal(0, 1.0, (h, w))
+    elif kind == 3:  # saturated blobs: random rectangles black/white on grey
+        img = np.full((h, w), 128.0)
+        for _ in range(int(rng.integers(1, 40))):
+            x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
+            x1, y1 = min(w, x0 + int(rng.integers(1, 80))), min(h, y0 + int(rng.integers(1, 80)))
+            img[y0:y1, x0:x1] = rng.choice([0, 255, 60, 200])
+    elif kind == 4:  # constant
+        img = np.full((h, w), float(rng.integers(0, 256)))
+    elif kind == 5:  # uniform noise
+        img = rng.integers(0, 256, (h, w)).astype(np.float64)
+    elif kind == 6:  # sparse impulses on flat background
+        img = np.full((h, w), 100.0)
+        m = rng.random((h, w)) < 0.02
+        img[m] = 255
+    elif kind == 7:  # diagonal lines
+        p = int(rng.integers(3, 17))
+        img = ((xx + yy * int(rng.integers(1, 4))) % p == 0) * 255.0
+    elif kind == 8:  # concentric rings (many nested components, long boundaries)
+        cx, cy = w / 2.0, h / 2.0
+        r = np.sqrt((xx - cx) ** 2 + (yy - cy) ** 2)
+        img = ((r / float(rng.integers(2, 12))).astype(np.int64) & 1) * 240.0 + 8
+    elif kind == 9:  # tags on a busy background
+        img = None
+    elif kind == 10:  # two-level noise: every pixel either 0 or 255
+        img = (rng.random((h, w)) < rng.uniform(0.2, 0.8)) * 255.0
+    else:            # big solid shapes with noisy edges (large clusters)
+        img = np.full((h, w), 40.0)
+        img[h // 6: 5 * h // 6, w // 6: 5 * w // 6] = 220
+        img += rng.normal(0, float(rng.uniform(0, 30)), (h, w))
+    return kind, img
+
+
+def tag_scene(rng, h, w, fams):
+    tags = []
+    n = int(rng.integers(1, 6))
+    K = synth.default_K(w, h)
+    for _ in range(n):
+        fam = fams[int(rng.integers(0, len(fams)))]
+        ncodes = len(synth.family_codes(fam)[0])
+        tid = int(rng.integers(0, ncodes))
+        side = float(rng.uniform(0.12, 0.5)) * min(w, h)
+        z = K[0, 0] * 0.22 / side
+        cxp, cyp = rng.uniform(0.2, 0.8) * w, rng.uniform(0.2, 0.8) * h
+        t = np.array([(cxp - K[0, 2]) * z / K[0, 0], (cyp - K[1, 2]) * z / K[1, 1], z])
+        R = synth.rot_xyz(*(np.deg2rad(rng.uniform(-45, 45, 2)).tolist() + [float(rng.uniform(-np.pi, np.pi))]))
+        H = synth.homography_from_pose(R, t, K, 0.22)
+        tags.append({"family": fam, "id": tid, "H": H})
+    img = synth.render(w, h, tags, background=int(rng.integers(60, 220)), sigma=float(rng.uniform(0, 6)),
+                       seed=int(rng.integers(0, 1 << 30)), ss=2)
+    return img
+
+
+def run_cases(cases, seed, maxdim=420, budget=1e9, out=print):
+    """Returns (cases run, list of failure strings)."""
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    fails = []
+    done = 0
+    for case in range(cases):
+        if time.time() - t0 > budget:
+            break
+        h = int(rng.integers(4, maxdim))
+        w = int(rng.integers(4, maxdim))
+        if rng.random() < 0.15:
+            w = int(rng.integers(4, 40))
+        if rng.random() < 0.15:
+            h = int(rng.integers(4, 40))
+        dec = int(rng.choice([1, 1, 1, 2, 2, 3, 4]))
+        if (w // dec) < 4 or (h // dec) < 4:
+            dec = 1
+        fams = [("tag36h11",), ("tag25h9",), ("tag16h5",), ("tag36h11", "tag25h9"), ("tag36h11", "tag25h9", "tag16h5")][
+            int(rng.integers(0, 5))]
+        kind, img = gen_content(rng, h, w)
+        if img is None:
+            img = tag_scene(rng, h, w, fams)
+        img = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+        pitch = w + int(rng.choice([0, 0, 1, 3, 13, 64]))
+        buf = np.zeros((h, pitch), dtype=np.uint8)
+        buf[:, :w] = img
+        buf[:, w:] = rng.integers(0, 256, (h, pitch - w), dtype=np.uint8)
+        K = synth.default_K(w, h)
+        try:
+            det = AprilTagDetector(w, h, intrinsics=(K[0, 0], K[1, 1], K[0, 2], K[1, 2]), families=fams, decimate=dec,
+                                   max_batch=1)
+        except Exception as e:  # noqa: BLE001
+            fails.append("case %d: create failed for %dx%d dec %d: %s" % (case, w, h, dec, e))
+            out(fails[-1])
+            continue
+        t = torch.from_numpy(buf).cuda()
+        g = det.detect_batch_ex([(t.data_ptr(), pitch)], max_dets=256)[0]
+        errs, odets = pu.compare_stages(det, 0, np.ascontiguousarray(img), fams, K, dec)
+        errs += pu.compare_detections(g, odets)
+        det.close()
+        done += 1
+        if errs:
+            fails.append("case %d FAIL kind %d %dx%d pitch %d dec %d fams %s: %s" % (case, kind, w, h, pitch, dec, fams,
+                                                                                  errs[:3]))
+            out(fails[-1])
+    return done, fails
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=150)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--maxdim", type=int, default=420)
+    ap.add_argument("--budget", type=float, default=1e9, help="seconds")
+    a = ap.parse_args()
+    t0 = time.time()
+    done, fails = run_cases(a.cases, a.seed, a.maxdim, a.budget, out=lambda m: print(m, flush=True))
+    print("fuzz: %d cases, %d failed, %.1f s" % (done, len(fails), time.time() - t0))
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
