@@ -484,7 +484,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
     FqClass cls[NCLS] = {{64, 256, 0, 256, clampu(32768u / n, 128u, 4096u)},
                          {128, 1024, 256, 1024, clampu(16384u / n, 64u, 2048u)},
                          {256, 4096, 1024, 4096, clampu(2048u / n, 32u, 512u)},
-                         {512, 8192, 4096, 8192, clampu(1024u / n, 16u, 256u)},
+                         {256, 8192, 4096, 8192, clampu(1024u / n, 16u, 256u)},
                          {512, 16384, 8192, 0x7FFFFFFF, clampu(512u / n, 8u, 256u)}};
     if (const char* ov = D->env_fq_classes) {  // tuning override: "nt:cap:gxbudget" x 5 (size bounds follow cap)
       int nt[NCLS], cap[NCLS], bud[NCLS];
