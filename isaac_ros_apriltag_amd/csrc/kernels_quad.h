@@ -1,56 +1,72 @@
 // kernels_quad.h -- S5 quad fitting (inside cuAprilTagsDetect, reference
-// src/apriltag_node.cpp:491-493).  One workgroup per cluster, four launch classes by cluster size
-// (one wave for <= 256 points, 256 threads up to 4096, 512 threads above) so that small clusters do
-// not pay for idle waves and the slope sort always runs in LDS (2 KB ... 128 KB of keys):
-//   bbox / gradient-dot by integer block reductions -> slope keys -> in-place bitonic sort in LDS ->
-//   weighted moment terms widened to 128-bit fixed point, where sums are exact, so the cumulative
-//   moments are a workgroup-wide parallel scan rounded once per prefix (bit-identical to the CPU
-//   definition in any order) -> windowed line-fit errors, 7-tap smoothing
-//   -> local maxima compacted into LDS, top-10 selection by 11 block arg-max rounds over that list ->
-//   all C(10,4) corner choices from a table of pairwise segment fits -> 4 line fits, intersections and
-//   the area/angle checks spread over 4 lanes.
+// src/apriltag_node.cpp:491-493).  One workgroup per cluster, five launch classes by cluster size
+// (one wave for <= 256 points ... 512 threads above 8192) so that small clusters do not pay for idle
+// waves and the slope sort always runs in LDS (2 KB ... 128 KB of keys):
+//   bbox / gradient-dot: seven DPP wave reductions, one barrier -> slope keys -> in-place bitonic sort
+//   in LDS -> one sweep that drops duplicate points, widens the weighted moment terms to 128-bit fixed
+//   point (sums are exact there), scans them across the workgroup (DPP wave scan, wave totals
+//   double-buffered: one barrier per chunk) and rounds every prefix once (bit-identical to the CPU
+//   definition in any order) -> windowed line-fit errors, 7-tap smoothing -> local maxima compacted into
+//   LDS -> wave 0 alone: top-10 selection by 11 arg-max rounds -> table of pairwise segment fits (all
+//   threads) -> wave 0 alone: best of the C(10,4) corner choices, 4 line fits, intersections and the
+//   area/angle checks.
+// Where the time goes (1080p sigma-2 frames, 256 per submission, 41.7 ms; measured by truncating the
+// kernel after each phase): cluster loop + bbox 3.8 ms, keys + sort 10.3, moment sweep 15.6 (gradient
+// gathers 2.6, rounding + 48 B/point store 5.4, terms + scans 7.6), errors + smoothing 4.4, maxima +
+// selection 4.3, pair table + corner choice + checks 3.4.
 #pragma once
 #include "common.h"
 
 
-template <int NW>
-__device__ __forceinline__ int block_reduce_min_i(int v, int* scratch) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-  if (NW == 1) return v;
-  if (lane_id() == 0) scratch[threadIdx.x >> 6] = v;
-  __syncthreads();
-  int r = scratch[0];
-#pragma unroll
-  for (int w = 1; w < NW; w++) r = min(r, scratch[w]);
-  __syncthreads();
-  return r;
+// ---- wave reductions on the DPP network (row_shr 1/2/4/8 inside each row of 16 lanes, then the row
+// broadcasts 15 and 31): after the six steps lane 63 holds the reduction of the whole wave.  For the
+// idempotent operations a lane without a source keeps its own value (old = v, bound_ctrl off).
+#define AT_DPP_STEPS(OP)          \
+  OP(0x111, 0xF) OP(0x112, 0xF) OP(0x114, 0xF) OP(0x118, 0xF) OP(0x142, 0xA) OP(0x143, 0xC)
+__device__ __forceinline__ int wave_min_i(int v) {
+#define OP(C, M) v = min(v, __builtin_amdgcn_update_dpp(v, v, C, M, 0xF, false));
+  AT_DPP_STEPS(OP)
+#undef OP
+  return __builtin_amdgcn_readlane(v, 63);
 }
-template <int NW>
-__device__ __forceinline__ int block_reduce_max_i(int v, int* scratch) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-  if (NW == 1) return v;
-  if (lane_id() == 0) scratch[threadIdx.x >> 6] = v;
-  __syncthreads();
-  int r = scratch[0];
-#pragma unroll
-  for (int w = 1; w < NW; w++) r = max(r, scratch[w]);
-  __syncthreads();
-  return r;
+__device__ __forceinline__ int wave_max_i(int v) {
+#define OP(C, M) v = max(v, __builtin_amdgcn_update_dpp(v, v, C, M, 0xF, false));
+  AT_DPP_STEPS(OP)
+#undef OP
+  return __builtin_amdgcn_readlane(v, 63);
 }
-template <int NW>
-__device__ __forceinline__ long long block_reduce_sum_ll(long long v, long long* scratch) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  if (NW == 1) return v;
-  if (lane_id() == 0) scratch[threadIdx.x >> 6] = v;
-  __syncthreads();
-  long long r = scratch[0];
-#pragma unroll
-  for (int w = 1; w < NW; w++) r += scratch[w];
-  __syncthreads();
-  return r;
+__device__ __forceinline__ long long wave_sum_ll(long long v) {
+#define OP(C, M)                                                                                         \
+  {                                                                                                      \
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, C, M, 0xF, true);      \
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((unsigned long long)v >> 32), C, M, 0xF, true); \
+    v += (long long)((unsigned long long)lo | ((unsigned long long)hi << 32));                           \
+  }
+  AT_DPP_STEPS(OP)
+#undef OP
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)v >> 32), 63);
+  return (long long)((unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+// max of an unsigned 64-bit key over the wave (used for arg-max with an order-preserving key)
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#define OP(C, M)                                                                                         \
+  {                                                                                                      \
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, C, M, 0xF, false);       \
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), C, M, 0xF, false); \
+    const unsigned long long o = (unsigned long long)lo | ((unsigned long long)hi << 32);                \
+    v = o > v ? o : v;                                                                                   \
+  }
+  AT_DPP_STEPS(OP)
+#undef OP
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+  return (unsigned long long)lo | ((unsigned long long)hi << 32);
+}
+// order-preserving map double -> u64 (total order of the finite values, -0 < +0)
+__device__ __forceinline__ unsigned long long double_sortable(double d) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
 // ---- exact 128-bit fixed-point sums of doubles (52 fractional bits) --------------------------------
@@ -88,31 +104,24 @@ __device__ __forceinline__ U128 exact_to_fixed(double t) {
   r.hi = m >> (64 - shift);
   return r;
 }
-// nearest-even rounding of v / 2^52 to double
+// nearest-even rounding of v / 2^52 to double, v < 2^127.  Branch-free: normalise so that the leading
+// one sits at bit 127, take the top 53 bits as the mantissa, the next bit as the half bit, the rest as
+// sticky.  (v == 0 maps to 0.)
 __device__ __forceinline__ double exact_from_fixed(U128 v) {
-  if (v.hi == 0 && v.lo < (1ull << 53)) return (double)(long long)v.lo * 0x1p-52;
-  const int p = v.hi ? 127 - __clzll((long long)v.hi) : 63 - __clzll((long long)v.lo);
-  int r = p - 52;  // 1 .. 75
-  unsigned long long mant, below;  // below: the r bits under the mantissa, top-aligned test done separately
-  bool halfbit, sticky;
-  if (r < 64) {
-    mant = (v.lo >> r) | (v.hi << (64 - r));
-    halfbit = (v.lo >> (r - 1)) & 1;
-    sticky = (v.lo & ((1ull << (r - 1)) - 1)) != 0;
-  } else if (r == 64) {
-    mant = v.hi;
-    halfbit = (v.lo >> 63) & 1;
-    sticky = (v.lo & ((1ull << 63) - 1)) != 0;
-  } else {
-    mant = v.hi >> (r - 64);
-    halfbit = (v.hi >> (r - 65)) & 1;
-    sticky = ((v.hi & ((1ull << (r - 65)) - 1)) != 0) || (v.lo != 0);
-  }
-  (void)below;
-  if (halfbit && (sticky || (mant & 1))) mant++;
-  if (mant >> 53) { mant >>= 1; r++; }
-  const unsigned long long bits = ((unsigned long long)(1023 + r) << 52) | (mant & ((1ull << 52) - 1));
-  return __longlong_as_double((long long)bits);
+  const bool hi0 = v.hi == 0;
+  const unsigned long long top = hi0 ? v.lo : v.hi;
+  const int lz = (int)__clzll((long long)top);          // 0..63 (64 when top == 0)
+  // n = v << (lz + (hi0 ? 64 : 0)), leading one at bit 127
+  const unsigned long long nh = hi0 ? (v.lo << lz) : ((v.hi << lz) | (lz ? (v.lo >> (64 - lz)) : 0ull));
+  const unsigned long long nl = hi0 ? 0ull : (v.lo << lz);
+  const int p = (hi0 ? 63 : 127) - lz;                  // position of the leading one
+  unsigned long long mant = nh >> 11;                   // 53 bits
+  const bool halfbit = (nh >> 10) & 1ull;
+  const bool sticky = ((nh & 0x3FFull) | nl) != 0ull;
+  mant += (halfbit && (sticky || (mant & 1ull))) ? 1ull : 0ull;
+  // a carry out of the mantissa (mant == 2^53) is absorbed by the exponent field arithmetic below
+  const unsigned long long bits = ((unsigned long long)(1023 - 52 + p - 1) << 52) + mant;
+  return top == 0 ? 0.0 : __longlong_as_double((long long)bits);
 }
 
 // Line fit over the cumulative moments lf[i*6 + {Mx,My,Mxx,Mxy,Myy,W}] of points i0..i1 (circular).
@@ -261,18 +270,19 @@ __device__ __forceinline__ void bitonic_sort_block2(KeyPtr A, int n) {
   }
 }
 
-// lexicographic index of the 4-subsets of {0..9}: entry t = {m0,m1,m2,m3} packed 4 bits each
-__device__ __forceinline__ uint32_t combo_of(int t) {
+// lexicographic list of the 4-subsets of {0..9}: entry t = {m0,m1,m2,m3} packed 4 bits each, built at
+// compile time (computing it in the kernel prologue cost ~2600 instructions per workgroup)
+struct ComboTable { uint16_t v[210]; };
+constexpr ComboTable make_combo_table() {
+  ComboTable t{};
   int c = 0;
   for (int m0 = 0; m0 < 7; m0++)
     for (int m1 = m0 + 1; m1 < 8; m1++)
       for (int m2 = m1 + 1; m2 < 9; m2++)
-        for (int m3 = m2 + 1; m3 < 10; m3++) {
-          if (c == t) return (uint32_t)(m0 | (m1 << 4) | (m2 << 8) | (m3 << 12));
-          c++;
-        }
-  return 0xFFFFu;
+        for (int m3 = m2 + 1; m3 < 10; m3++) t.v[c++] = (uint16_t)(m0 | (m1 << 4) | (m2 << 8) | (m3 << 12));
+  return t;
 }
+__device__ const ComboTable g_combo_table = make_combo_table();
 
 // Dynamic LDS layout: [0, 8*sort_cap) slope keys (later: maxima candidates) | 1024 doubles of pair-fit
 // tables.  Clusters with size in (size_lo, size_hi] are processed by this
@@ -294,10 +304,8 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 4 : 2)) void k_fit_quads(const Fra
   double* s_lines = chunk + 600;  // [4][4]
   double* s_lmse = chunk + 616;   // [4]
   constexpr int NW = NT / 64;
-  __shared__ long long sred_ll[NW];
-  __shared__ int sred_i[NW];
-  __shared__ double sred_d[NW];
-  __shared__ int sred_di[NW];
+  __shared__ long long s_dot[NW][3];
+  __shared__ int s_box[NW][4];
   __shared__ double s_remval[12];
   __shared__ int s_remidx[12];
   __shared__ int s_ncand;
@@ -305,10 +313,8 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 4 : 2)) void k_fit_quads(const Fra
   __shared__ int s_nkept;
   __shared__ uint16_t s_combo[210];
   __shared__ float s_corner[4][2];
-  __shared__ int s_ok;
-  __shared__ int s_idx4[4];
-  __shared__ U128 s_carry[6];
-  __shared__ U128 s_wtot[(NW > 1 ? NW : 1) * 6];
+  __shared__ U128 s_wtot[(NW > 1 ? 2 * NW : 1) * 6];   // [chunk parity][wave][moment]
+  __shared__ int s_wcnt[(NW > 1 ? 2 * NW : 1)];
 
   const int frame = (int)blockIdx.y + P.frame0;
   const int tid = threadIdx.x;
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 4 : 2)) void k_fit_quads(const Fra
   uint32_t ncl = counters[frame].nclusters;
   if (ncl > P.ccap) ncl = P.ccap;
 
-  for (int t = tid; t < 210; t += NT) s_combo[t] = (uint16_t)combo_of(t);
+  for (int t = tid; t < 210; t += NT) s_combo[t] = g_combo_table.v[t];
 
 #define FQ_TICK(slot)                                                                  \
   if (prof && tid == 0) {                                                              \
@@ -348,9 +354,24 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 4 : 2)) void k_fit_quads(const Fra
       sxg += (long long)x * gx + (long long)y * gy;
       sgx += gx; sgy += gy;
     }
-    xmin = block_reduce_min_i<NW>(xmin, sred_i); xmax = block_reduce_max_i<NW>(xmax, sred_i);
-    ymin = block_reduce_min_i<NW>(ymin, sred_i); ymax = block_reduce_max_i<NW>(ymax, sred_i);
-    sxg = block_reduce_sum_ll<NW>(sxg, sred_ll); sgx = block_reduce_sum_ll<NW>(sgx, sred_ll); sgy = block_reduce_sum_ll<NW>(sgy, sred_ll);
+    // seven reductions, one barrier: every wave reduces on the DPP network and parks its results
+    xmin = wave_min_i(xmin); xmax = wave_max_i(xmax); ymin = wave_min_i(ymin); ymax = wave_max_i(ymax);
+    sxg = wave_sum_ll(sxg); sgx = wave_sum_ll(sgx); sgy = wave_sum_ll(sgy);
+    if (NW > 1) {
+      const int wv = tid >> 6;
+      if (lane_id() == 0) {
+        s_box[wv][0] = xmin; s_box[wv][1] = xmax; s_box[wv][2] = ymin; s_box[wv][3] = ymax;
+        s_dot[wv][0] = sxg; s_dot[wv][1] = sgx; s_dot[wv][2] = sgy;
+      }
+      __syncthreads();
+      xmin = s_box[0][0]; xmax = s_box[0][1]; ymin = s_box[0][2]; ymax = s_box[0][3];
+      sxg = s_dot[0][0]; sgx = s_dot[0][1]; sgy = s_dot[0][2];
+#pragma unroll
+      for (int w = 1; w < NW; w++) {
+        xmin = min(xmin, s_box[w][0]); xmax = max(xmax, s_box[w][1]); ymin = min(ymin, s_box[w][2]); ymax = max(ymax, s_box[w][3]);
+        sxg += s_dot[w][0]; sgx += s_dot[w][1]; sgy += s_dot[w][2];
+      }
+    }
     if ((xmax - xmin) * (ymax - ymin) < P.min_tag_width) continue;
     const double cxd = (xmin + xmax) * 0.5 + 0.05118, cyd = (ymin + ymax) * 0.5 + -0.028581;
     const double dot = (double)sxg - cxd * (double)sgx - cyd * (double)sgy;
@@ -379,112 +400,117 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 4 : 2)) void k_fit_quads(const Fra
     }
     __syncthreads();
     if (in_lds) bitonic_sort_block2<NT>(skeys, sz); else bitonic_sort_block2<NT>(gkeys, sz);
-    // ---- remove duplicate points (same half-pixel location; adjacent after the sort) ----------------
-    // chunk by chunk: a chunk is read, the block synchronises, then it is written at or below where it
-    // was read, so no unread element is ever overwritten
+    FQ_TICK(2)
+
+    // ---- duplicate removal + weighted moment terms + exact cumulative sums, one sweep ---------------
+    // Duplicate points (same half-pixel location, adjacent after the sort) contribute nothing and get no
+    // output slot: the slot of a kept point is the running count of kept points, scanned together with
+    // the moments.  Each term (a double >= 1) is widened to value*2^52 in a 128-bit integer, where
+    // addition is exact and associative; the inclusive scan runs over the whole workgroup and every
+    // prefix is rounded to nearest-even double once -- the same definition the CPU oracle uses,
+    // independent of order.  Wave totals are double-buffered by chunk parity, so a chunk costs one
+    // barrier; the running carries live in registers (identical in every thread).
+    double* lf = lf_all + ((size_t)frame * P.pcap + cl.start) * 6;
+    int szd;
     {
-      if (tid == 0) s_ncand = 0;  // running output position
-      __syncthreads();
-      for (int base = 0; base < sz; base += NT) {
+      U128 carry[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) carry[j] = u128_zero();
+      int cnt_carry = 0;
+      int par = 0;
+      const int lane = lane_id(), wv = tid >> 6;
+      for (int base = 0; base < sz; base += NT, par ^= 1) {
         const int i = base + tid;
-        unsigned long long key = 0;
+        U128 v[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) v[j] = u128_zero();
         bool keep = false;
         if (i < sz) {
-          key = in_lds ? skeys[i] : gkeys[i];
+          const unsigned long long key = in_lds ? skeys[i] : gkeys[i];
           const unsigned long long prev = (i > 0) ? (in_lds ? skeys[i - 1] : gkeys[i - 1]) : ~key;
           keep = (i == 0) || ((key >> 4) != (prev >> 4));
+          if (keep) {
+            const int px = (int)((key >> 4) & 0x3FFF), py = (int)((key >> 18) & 0x3FFF);
+            const double x = px * .5 + 0.5, y = py * .5 + 0.5;
+            const int ix = (int)x, iy = (int)y;
+            double Wt = 1;
+            if (ix > 0 && ix + 1 < W && iy > 0 && iy + 1 < H) {
+              const int grad_x = (int)gray[(size_t)iy * gpitch + ix + 1] - (int)gray[(size_t)iy * gpitch + ix - 1];
+              const int grad_y = (int)gray[(size_t)(iy + 1) * gpitch + ix] - (int)gray[(size_t)(iy - 1) * gpitch + ix];
+              Wt = __dsqrt_rn((double)(grad_x * grad_x + grad_y * grad_y)) + 1;
+            }
+            v[0] = exact_to_fixed(Wt * x);
+            v[1] = exact_to_fixed(Wt * y);
+            v[2] = exact_to_fixed(Wt * x * x);
+            v[3] = exact_to_fixed(Wt * x * y);
+            v[4] = exact_to_fixed(Wt * y * y);
+            v[5] = exact_to_fixed(Wt);
+          }
         }
-        const unsigned long long m = __ballot(keep);
-        const int wv = tid >> 6, ln = lane_id();
-        if (NW > 1 && ln == 0) sred_i[wv] = (int)__popcll(m);
-        __syncthreads();
-        int off = s_ncand + (int)__popcll(m & ((1ull << ln) - 1ull));
-        if (NW > 1)
-          for (int w2 = 0; w2 < wv; w2++) off += sred_i[w2];
-        int tot = (int)__popcll(m);
-        if (NW > 1) { tot = 0; for (int w2 = 0; w2 < NW; w2++) tot += sred_i[w2]; }
-        if (keep) { if (in_lds) skeys[off] = key; else gkeys[off] = key; }
-        __syncthreads();
-        if (tid == 0) s_ncand += tot;
-        __syncthreads();
+        const unsigned long long kmask = __ballot(keep);
+        // wave-inclusive scan with DPP lane shifts: out-of-range sources read as zero, so no per-step
+        // select is needed
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          v[j] = u128_add(v[j], u128_dpp<0x111, 0xF>(v[j]));
+          v[j] = u128_add(v[j], u128_dpp<0x112, 0xF>(v[j]));
+          v[j] = u128_add(v[j], u128_dpp<0x114, 0xF>(v[j]));
+          v[j] = u128_add(v[j], u128_dpp<0x118, 0xF>(v[j]));
+          v[j] = u128_add(v[j], u128_dpp<0x142, 0xA>(v[j]));
+          v[j] = u128_add(v[j], u128_dpp<0x143, 0xC>(v[j]));
+        }
+        int pos = cnt_carry + (int)__popcll(kmask & ((1ull << lane) - 1ull));
+        if (NW > 1) {
+          if (lane == 63) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) s_wtot[(par * NW + wv) * 6 + j] = v[j];
+            s_wcnt[par * NW + wv] = (int)__popcll(kmask);
+          }
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < 6; j++) {
+            U128 run = carry[j], add = carry[j];
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+              if (w == wv) add = run;   // wave-uniform select
+              run = u128_add(run, s_wtot[(par * NW + w) * 6 + j]);
+            }
+            v[j] = u128_add(v[j], add);
+            carry[j] = run;
+          }
+          {
+            int run = cnt_carry, add = cnt_carry;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+              if (w == wv) add = run;
+              run += s_wcnt[par * NW + w];
+            }
+            pos += add - cnt_carry;
+            cnt_carry = run;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 6; j++) {
+            v[j] = u128_add(v[j], carry[j]);
+            U128 t;
+            t.lo = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v[j].lo, 63) |
+                   ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v[j].lo >> 32), 63) << 32);
+            t.hi = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v[j].hi, 63) |
+                   ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v[j].hi >> 32), 63) << 32);
+            carry[j] = t;
+          }
+          cnt_carry += (int)__popcll(kmask);
+        }
+        if (keep) {
+          double* o = lf + (size_t)pos * 6;
+#pragma unroll
+          for (int j = 0; j < 6; j++) o[j] = exact_from_fixed(v[j]);
+        }
       }
+      szd = cnt_carry;
     }
-    const int sz_all = sz;
-    (void)sz_all;
-    const int sz_dedup = s_ncand;
-    __syncthreads();
-    if (sz_dedup < 24) continue;
-    FQ_TICK(2)
-    const int szd = sz_dedup;
-
-    // ---- weighted moment terms, exact cumulative sums (parallel scan of 128-bit fixed point) -------
-    // Each term (a double >= 1) is widened to value*2^52 in a 128-bit integer, where addition is exact
-    // and associative; the inclusive scan runs over the whole workgroup and every prefix is rounded to
-    // nearest-even double once -- the same definition the CPU oracle uses, independent of order.
-    double* lf = lf_all + ((size_t)frame * P.pcap + cl.start) * 6;
-    if (tid < 6) s_carry[tid] = u128_zero();
-    __syncthreads();
-    for (int base = 0; base < szd; base += NT) {
-      const int i = base + tid;
-      U128 v[6];
-#pragma unroll
-      for (int j = 0; j < 6; j++) v[j] = u128_zero();
-      if (i < szd) {
-        const unsigned long long key = in_lds ? skeys[i] : gkeys[i];
-        const int px = (int)((key >> 4) & 0x3FFF), py = (int)((key >> 18) & 0x3FFF);
-        const double x = px * .5 + 0.5, y = py * .5 + 0.5;
-        const int ix = (int)x, iy = (int)y;
-        double Wt = 1;
-        if (ix > 0 && ix + 1 < W && iy > 0 && iy + 1 < H) {
-          const int grad_x = (int)gray[(size_t)iy * gpitch + ix + 1] - (int)gray[(size_t)iy * gpitch + ix - 1];
-          const int grad_y = (int)gray[(size_t)(iy + 1) * gpitch + ix] - (int)gray[(size_t)(iy - 1) * gpitch + ix];
-          Wt = __dsqrt_rn((double)(grad_x * grad_x + grad_y * grad_y)) + 1;
-        }
-        v[0] = exact_to_fixed(Wt * x);
-        v[1] = exact_to_fixed(Wt * y);
-        v[2] = exact_to_fixed(Wt * x * x);
-        v[3] = exact_to_fixed(Wt * x * y);
-        v[4] = exact_to_fixed(Wt * y * y);
-        v[5] = exact_to_fixed(Wt);
-      }
-      const int lane = lane_id(), wv = tid >> 6;
-      // wave-inclusive scan with DPP lane shifts (row_shr 1/2/4/8 inside each row of 16, then the row
-      // broadcasts 15 and 31): out-of-range sources read as zero, so no per-step select is needed
-#pragma unroll
-      for (int j = 0; j < 6; j++) {
-        v[j] = u128_add(v[j], u128_dpp<0x111, 0xF>(v[j]));
-        v[j] = u128_add(v[j], u128_dpp<0x112, 0xF>(v[j]));
-        v[j] = u128_add(v[j], u128_dpp<0x114, 0xF>(v[j]));
-        v[j] = u128_add(v[j], u128_dpp<0x118, 0xF>(v[j]));
-        v[j] = u128_add(v[j], u128_dpp<0x142, 0xA>(v[j]));
-        v[j] = u128_add(v[j], u128_dpp<0x143, 0xC>(v[j]));
-      }
-      if (NW > 1) {
-        if (lane == 63) {
-#pragma unroll
-          for (int j = 0; j < 6; j++) s_wtot[wv * 6 + j] = v[j];
-        }
-        __syncthreads();
-      }
-#pragma unroll
-      for (int j = 0; j < 6; j++) {
-        U128 add = s_carry[j];
-        if (NW > 1)
-          for (int w = 0; w < wv; w++) add = u128_add(add, s_wtot[w * 6 + j]);
-        v[j] = u128_add(v[j], add);
-      }
-      if (i < szd) {
-        double* o = lf + (size_t)i * 6;
-#pragma unroll
-        for (int j = 0; j < 6; j++) o[j] = exact_from_fixed(v[j]);
-      }
-      __syncthreads();
-      if (tid == NT - 1) {
-#pragma unroll
-        for (int j = 0; j < 6; j++) s_carry[j] = v[j];
-      }
-      __syncthreads();
-    }
+    __syncthreads();   // lf complete (read by other threads below); key array free
+    if (szd < 24) continue;
     FQ_TICK(4)
 
     // ---- windowed line-fit error, smoothing ------------------------------------------------------
@@ -502,7 +528,7 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 4 : 2)) void k_fit_quads(const Fra
       fit_line_dev(lf, szd, i0, i1, nullptr, &e, nullptr);
       ea[i] = e;
     }
-    if (tid == 0) { s_ncand = 0; s_nkept = 0; s_ok = 1; }
+    if (tid == 0) { s_ncand = 0; s_nkept = 0; }
     __syncthreads();
     {
       const float f0 = 0x1.6c0504p-7f, f1 = 0x1.152aaap-3f, f2 = 0x1.368b3p-1f;
@@ -538,57 +564,53 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 4 : 2)) void k_fit_quads(const Fra
     __syncthreads();
     const int nmaxima = s_ncand;
     if (nmaxima < 4) continue;
-    const bool select = nmaxima > P.max_nmaxima;
-    if (select) {
-      // remove the current largest (max_nmaxima + 1) times; the last removed value is the threshold
-      for (int round = 0; round <= P.max_nmaxima; round++) {
-        double bv = 0; int bi = -1;
-        for (int k = tid; k < nmaxima; k += NT) {
-          const double e = cand_val[k];
-          if (cand_idx[k] >= 0 && (bi < 0 || e > bv)) { bv = e; bi = k; }
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-          const double ov = __shfl_xor(bv, off, 64);
-          const int oi = __shfl_xor(bi, off, 64);
-          if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
-        }
-        if (lane_id() == 0) { sred_d[tid >> 6] = bv; sred_di[tid >> 6] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-          double v = 0; int ix = -1;
-          for (int w = 0; w < NW; w++) {
-            const double ov = sred_d[w]; const int oi = sred_di[w];
-            if (oi >= 0 && (ix < 0 || ov > v || (ov == v && oi < ix))) { v = ov; ix = oi; }
+    // Selection and ordering of at most max_nmaxima corners: wave 0 alone, no workgroup barriers inside.
+    // When there are more candidates, the current largest is removed (max_nmaxima + 1) times; the last
+    // removed value is the threshold (only the values matter, so ties may be broken arbitrarily).
+    if (tid < 64) {
+      const int lane = tid;
+      if (nmaxima > P.max_nmaxima) {
+        for (int round = 0; round <= P.max_nmaxima; round++) {
+          unsigned long long bk = 0; int bi = -1;
+          for (int k = lane; k < nmaxima; k += 64) {
+            if (cand_idx[k] >= 0) {
+              const unsigned long long kk = double_sortable(cand_val[k] + 0.0);
+              if (bi < 0 || kk > bk) { bk = kk; bi = k; }
+            }
           }
-          s_remval[round] = v;
-          s_remidx[round] = cand_idx[ix];
-          cand_idx[ix] = -1;  // removed
+          const unsigned long long mk = wave_max_u64(bi < 0 ? 0ull : bk);
+          const unsigned long long who = __ballot(bi >= 0 && bk == mk);
+          const int ix = __shfl(bi, (int)__ffsll((long long)who) - 1, 64);
+          if (lane == 0) {
+            s_remval[round] = cand_val[ix];
+            s_remidx[round] = cand_idx[ix];
+            cand_idx[ix] = -1;  // removed
+          }
+          __threadfence_block();
         }
-        __syncthreads();
+        if (lane == 0) {
+          const double thresh = s_remval[P.max_nmaxima];
+          int mm = 0;
+          for (int r = 0; r < P.max_nmaxima; r++)
+            if (s_remval[r] > thresh) s_maxidx[mm++] = s_remidx[r];
+          s_nkept = mm;
+        }
+      } else if (lane == 0) {
+        for (int k = 0; k < nmaxima; k++) s_maxidx[k] = cand_idx[k];
+        s_nkept = nmaxima;
       }
-      if (tid == 0) {
-        const double thresh = s_remval[P.max_nmaxima];
-        int m = 0;
-        for (int r = 0; r < P.max_nmaxima; r++)
-          if (s_remval[r] > thresh) s_maxidx[m++] = s_remidx[r];
-        s_nkept = m;
+      if (lane == 0) {  // ascending index order (<= 10 entries)
+        const int mm = s_nkept;
+        for (int a2 = 1; a2 < mm; a2++) {
+          const int v = s_maxidx[a2];
+          int b2 = a2 - 1;
+          while (b2 >= 0 && s_maxidx[b2] > v) { s_maxidx[b2 + 1] = s_maxidx[b2]; b2--; }
+          s_maxidx[b2 + 1] = v;
+        }
       }
-    } else if (tid == 0) {
-      for (int k = 0; k < nmaxima; k++) s_maxidx[k] = cand_idx[k];
-      s_nkept = nmaxima;
     }
     __syncthreads();
     const int m = s_nkept;
-    if (tid == 0) {  // ascending index order (<= 10 entries)
-      for (int a = 1; a < m; a++) {
-        const int v = s_maxidx[a];
-        int b = a - 1;
-        while (b >= 0 && s_maxidx[b] > v) { s_maxidx[b + 1] = s_maxidx[b]; b--; }
-        s_maxidx[b + 1] = v;
-      }
-    }
-    __syncthreads();
     if (m < 4) continue;
     FQ_TICK(6)
 
@@ -608,115 +630,109 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 4 : 2)) void k_fit_quads(const Fra
       }
     }
     __syncthreads();
-    double best_err = (double)HUGE_VALF;
-    int best_t = 1 << 30;
-    for (int t = tid; t < 210; t += NT) {
-      const uint32_t my_combo = s_combo[t];
-      const int q0 = my_combo & 15, q1 = (my_combo >> 4) & 15, q2 = (my_combo >> 8) & 15, q3 = (my_combo >> 12) & 15;
-      if (q3 < m) {
-        const double mse01 = s_fmse[q0 * 10 + q1], mse12 = s_fmse[q1 * 10 + q2], mse23 = s_fmse[q2 * 10 + q3];
-        const double mse30 = s_wmse[q0 * 10 + q3];
-        const double dotn = s_fnx[q0 * 10 + q1] * s_fnx[q1 * 10 + q2] + s_fny[q0 * 10 + q1] * s_fny[q1 * 10 + q2];
-        if (!(mse01 > P.max_line_fit_mse) && !(mse12 > P.max_line_fit_mse) && !(fabs(dotn) > P.cos_critical_rad) &&
-            !(mse23 > P.max_line_fit_mse) && !(mse30 > P.max_line_fit_mse)) {
-          const double e = s_ferr[q0 * 10 + q1] + s_ferr[q1 * 10 + q2] + s_ferr[q2 * 10 + q3] + s_werr[q0 * 10 + q3];
-          if (e < best_err) { best_err = e; best_t = t; }
-        }
-      }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double ov = __shfl_xor(best_err, off, 64);
-      const int ot = __shfl_xor(best_t, off, 64);
-      if (ov < best_err || (ov == best_err && ot < best_t)) { best_err = ov; best_t = ot; }
-    }
-    if (lane_id() == 0) { sred_d[tid >> 6] = best_err; sred_di[tid >> 6] = best_t; }
-    __syncthreads();
-    if (tid == 0) {
-      double be = sred_d[0]; int bt = sred_di[0];
-#pragma unroll
-      for (int w = 1; w < NW; w++)
-        if (sred_d[w] < be || (sred_d[w] == be && sred_di[w] < bt)) { be = sred_d[w]; bt = sred_di[w]; }
-      const bool ok = (be != (double)HUGE_VALF) && (be / szd < P.max_line_fit_mse);
-      s_ok = ok ? 1 : 0;
-      if (ok) {
-        const uint32_t cmb = s_combo[bt];
-        s_idx4[0] = s_maxidx[cmb & 15]; s_idx4[1] = s_maxidx[(cmb >> 4) & 15];
-        s_idx4[2] = s_maxidx[(cmb >> 8) & 15]; s_idx4[3] = s_maxidx[(cmb >> 12) & 15];
-      }
-    }
-    __syncthreads();
-    if (!s_ok) continue;
-    // four final line fits (lanes 0..3), then four intersections (lanes 0..3)
-    if (tid < 4) {
-      double ms;
-      fit_line_dev(lf, szd, s_idx4[tid], s_idx4[(tid + 1) & 3], s_lines + tid * 4, nullptr, &ms);
-      s_lmse[tid] = ms;
-    }
-    __syncthreads();
-    if (tid < 4) {
-      const int i = tid, j = (tid + 1) & 3;
-      bool ok = !(s_lmse[0] > P.max_line_fit_mse) && !(s_lmse[1] > P.max_line_fit_mse) &&
-                !(s_lmse[2] > P.max_line_fit_mse) && !(s_lmse[3] > P.max_line_fit_mse);
-      const double A00 = s_lines[i * 4 + 3], A01 = -s_lines[j * 4 + 3];
-      const double A10 = -s_lines[i * 4 + 2], A11 = s_lines[j * 4 + 2];
-      const double B0 = -s_lines[i * 4 + 0] + s_lines[j * 4 + 0];
-      const double B1 = -s_lines[i * 4 + 1] + s_lines[j * 4 + 1];
-      const double det = A00 * A11 - A10 * A01;
-      if (fabs(det) < 0.001) ok = false;
-      const double W00 = A11 / det, W01 = -A01 / det;
-      const double L0 = W00 * B0 + W01 * B1;
-      s_corner[i][0] = (float)(s_lines[i * 4 + 0] + L0 * A00);
-      s_corner[i][1] = (float)(s_lines[i * 4 + 1] + L0 * A10);
-      if (!ok) s_ok = 0;
-    }
-    __syncthreads();
-    if (tid == 0 && s_ok) {
-      bool ok = true;
-      const double p00 = s_corner[0][0], p01 = s_corner[0][1], p10 = s_corner[1][0], p11 = s_corner[1][1];
-      const double p20 = s_corner[2][0], p21 = s_corner[2][1], p30 = s_corner[3][0], p31 = s_corner[3][1];
-      {
-        // triangles (0,1,2) and (2,3,0), Heron
-        const double l0 = __dsqrt_rn((p10 - p00) * (p10 - p00) + (p11 - p01) * (p11 - p01));
-        const double l1 = __dsqrt_rn((p20 - p10) * (p20 - p10) + (p21 - p11) * (p21 - p11));
-        const double l2 = __dsqrt_rn((p00 - p20) * (p00 - p20) + (p01 - p21) * (p01 - p21));
-        const double pp = (l0 + l1 + l2) / 2;
-        double area = 0;
-        area += __dsqrt_rn(pp * (pp - l0) * (pp - l1) * (pp - l2));
-        const double k0 = __dsqrt_rn((p30 - p20) * (p30 - p20) + (p31 - p21) * (p31 - p21));
-        const double k1 = __dsqrt_rn((p00 - p30) * (p00 - p30) + (p01 - p31) * (p01 - p31));
-        const double k2 = __dsqrt_rn((p20 - p00) * (p20 - p00) + (p21 - p01) * (p21 - p01));
-        const double qq = (k0 + k1 + k2) / 2;
-        area += __dsqrt_rn(qq * (qq - k0) * (qq - k1) * (qq - k2));
-        if (area < 0.95 * P.min_tag_width * P.min_tag_width) ok = false;
-      }
-      const double px[4] = {p00, p10, p20, p30}, py[4] = {p01, p11, p21, p31};
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int i0 = i, i1 = (i + 1) & 3, i2 = (i + 2) & 3;
-        const double dx1 = px[i1] - px[i0], dy1 = py[i1] - py[i0];
-        const double dx2 = px[i2] - px[i1], dy2 = py[i2] - py[i1];
-        const double cos_dtheta = (dx1 * dx2 + dy1 * dy2) / __dsqrt_rn((dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2));
-        if ((cos_dtheta > P.cos_critical_rad || cos_dtheta < -P.cos_critical_rad) || dx1 * dy2 < dy1 * dx2) ok = false;
-      }
-      if (ok) {
-        QuadRec q;
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          float fx = s_corner[c][0], fy = s_corner[c][1];
-          if (P.decimate > 1) {
-            const double f = (double)(float)P.decimate;
-            fx = (float)(((double)fx - 0.5) * f + 0.5);
-            fy = (float)(((double)fy - 0.5) * f + 0.5);
+    // Everything below runs in wave 0 without workgroup barriers (the other waves go on to the barrier at
+    // the top of the cluster loop): best of the C(m,4) corner choices, four line fits, intersections, checks.
+    if (tid < 64) {
+      const int lane = tid;
+      double best_err = (double)HUGE_VALF;
+      int best_t = 1 << 30;
+      for (int t = lane; t < 210; t += 64) {
+        const uint32_t my_combo = s_combo[t];
+        const int q0 = my_combo & 15, q1 = (my_combo >> 4) & 15, q2 = (my_combo >> 8) & 15, q3 = (my_combo >> 12) & 15;
+        if (q3 < m) {
+          const double mse01 = s_fmse[q0 * 10 + q1], mse12 = s_fmse[q1 * 10 + q2], mse23 = s_fmse[q2 * 10 + q3];
+          const double mse30 = s_wmse[q0 * 10 + q3];
+          const double dotn = s_fnx[q0 * 10 + q1] * s_fnx[q1 * 10 + q2] + s_fny[q0 * 10 + q1] * s_fny[q1 * 10 + q2];
+          if (!(mse01 > P.max_line_fit_mse) && !(mse12 > P.max_line_fit_mse) && !(fabs(dotn) > P.cos_critical_rad) &&
+              !(mse23 > P.max_line_fit_mse) && !(mse30 > P.max_line_fit_mse)) {
+            const double e = s_ferr[q0 * 10 + q1] + s_ferr[q1 * 10 + q2] + s_ferr[q2 * 10 + q3] + s_werr[q0 * 10 + q3];
+            if (e < best_err) { best_err = e; best_t = t; }
           }
-          q.p[c][0] = fx; q.p[c][1] = fy;
         }
-        q.reversed_border = q_reversed;
-        q.pad = 0;
-        q.key = cl.key;
-        const uint32_t qi = atomicAdd(&counters[frame].nquads, 1u);
-        if (qi < P.qcap) quads_all[(size_t)frame * P.qcap + qi] = q;
-        else atomicOr(&counters[frame].flags, 0x8u);
+      }
+      // arg-min over the wave; equal errors resolve to the smaller combination index (the CPU loop order)
+      const unsigned long long mykey = ~double_sortable(best_err + 0.0);
+      const unsigned long long topkey = wave_max_u64(mykey);
+      const int bt = wave_min_i(mykey == topkey ? best_t : (1 << 30));
+      const double be = __longlong_as_double((long long)__shfl((long long)__double_as_longlong(best_err),
+                                                                 (int)__ffsll((long long)__ballot(mykey == topkey && best_t == bt)) - 1, 64));
+      const bool found = (bt != (1 << 30)) && (be != (double)HUGE_VALF) && (be / szd < P.max_line_fit_mse);
+      if (found) {
+        const uint32_t cmb = s_combo[bt];
+        const int sh = (lane & 3) * 4, sh1 = ((lane + 1) & 3) * 4;
+        // four final line fits (lanes 0..3), then four intersections (lanes 0..3)
+        if (lane < 4) {
+          double ms;
+          fit_line_dev(lf, szd, s_maxidx[(cmb >> sh) & 15], s_maxidx[(cmb >> sh1) & 15], s_lines + lane * 4, nullptr, &ms);
+          s_lmse[lane] = ms;
+        }
+        __threadfence_block();
+        bool okq = true;
+        if (lane < 4) {
+          const int i = lane, j = (lane + 1) & 3;
+          okq = !(s_lmse[0] > P.max_line_fit_mse) && !(s_lmse[1] > P.max_line_fit_mse) &&
+                !(s_lmse[2] > P.max_line_fit_mse) && !(s_lmse[3] > P.max_line_fit_mse);
+          const double A00 = s_lines[i * 4 + 3], A01 = -s_lines[j * 4 + 3];
+          const double A10 = -s_lines[i * 4 + 2], A11 = s_lines[j * 4 + 2];
+          const double B0 = -s_lines[i * 4 + 0] + s_lines[j * 4 + 0];
+          const double B1 = -s_lines[i * 4 + 1] + s_lines[j * 4 + 1];
+          const double det = A00 * A11 - A10 * A01;
+          if (fabs(det) < 0.001) okq = false;
+          const double W00 = A11 / det, W01 = -A01 / det;
+          const double L0 = W00 * B0 + W01 * B1;
+          s_corner[i][0] = (float)(s_lines[i * 4 + 0] + L0 * A00);
+          s_corner[i][1] = (float)(s_lines[i * 4 + 1] + L0 * A10);
+        }
+        __threadfence_block();
+        const bool all_ok = __ballot(!okq) == 0ull;
+        if (lane == 0 && all_ok) {
+          bool ok = true;
+          const double p00 = s_corner[0][0], p01 = s_corner[0][1], p10 = s_corner[1][0], p11 = s_corner[1][1];
+          const double p20 = s_corner[2][0], p21 = s_corner[2][1], p30 = s_corner[3][0], p31 = s_corner[3][1];
+          {
+            // triangles (0,1,2) and (2,3,0), Heron
+            const double l0 = __dsqrt_rn((p10 - p00) * (p10 - p00) + (p11 - p01) * (p11 - p01));
+            const double l1 = __dsqrt_rn((p20 - p10) * (p20 - p10) + (p21 - p11) * (p21 - p11));
+            const double l2 = __dsqrt_rn((p00 - p20) * (p00 - p20) + (p01 - p21) * (p01 - p21));
+            const double pp = (l0 + l1 + l2) / 2;
+            double area = 0;
+            area += __dsqrt_rn(pp * (pp - l0) * (pp - l1) * (pp - l2));
+            const double k0 = __dsqrt_rn((p30 - p20) * (p30 - p20) + (p31 - p21) * (p31 - p21));
+            const double k1 = __dsqrt_rn((p00 - p30) * (p00 - p30) + (p01 - p31) * (p01 - p31));
+            const double k2 = __dsqrt_rn((p20 - p00) * (p20 - p00) + (p21 - p01) * (p21 - p01));
+            const double qq = (k0 + k1 + k2) / 2;
+            area += __dsqrt_rn(qq * (qq - k0) * (qq - k1) * (qq - k2));
+            if (area < 0.95 * P.min_tag_width * P.min_tag_width) ok = false;
+          }
+          const double px[4] = {p00, p10, p20, p30}, py[4] = {p01, p11, p21, p31};
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int i0 = i, i1 = (i + 1) & 3, i2 = (i + 2) & 3;
+            const double dx1 = px[i1] - px[i0], dy1 = py[i1] - py[i0];
+            const double dx2 = px[i2] - px[i1], dy2 = py[i2] - py[i1];
+            const double cos_dtheta = (dx1 * dx2 + dy1 * dy2) / __dsqrt_rn((dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2));
+            if ((cos_dtheta > P.cos_critical_rad || cos_dtheta < -P.cos_critical_rad) || dx1 * dy2 < dy1 * dx2) ok = false;
+          }
+          if (ok) {
+            QuadRec q;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+              float fx = s_corner[c][0], fy = s_corner[c][1];
+              if (P.decimate > 1) {
+                const double f = (double)(float)P.decimate;
+                fx = (float)(((double)fx - 0.5) * f + 0.5);
+                fy = (float)(((double)fy - 0.5) * f + 0.5);
+              }
+              q.p[c][0] = fx; q.p[c][1] = fy;
+            }
+            q.reversed_border = q_reversed;
+            q.pad = 0;
+            q.key = cl.key;
+            const uint32_t qi = atomicAdd(&counters[frame].nquads, 1u);
+            if (qi < P.qcap) quads_all[(size_t)frame * P.qcap + qi] = q;
+            else atomicOr(&counters[frame].flags, 0x8u);
+          }
+        }
       }
     }
     FQ_TICK(7)
