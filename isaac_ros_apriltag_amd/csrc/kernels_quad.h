@@ -288,7 +288,14 @@ __device__ const ComboTable g_combo_table = make_combo_table();
 // tables.  Clusters with size in (size_lo, size_hi] are processed by this
 // launch; those above sort_cap (only possible in the last class) sort in global scratch.
 template <int NT>
-__global__ __launch_bounds__(NT, (NT <= 256 ? 4 : 2)) void k_fit_quads(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
+#ifndef FQ_WPE_64
+#define FQ_WPE_64 4
+#define FQ_WPE_128 4
+#define FQ_WPE_256 3
+#define FQ_WPE_512 2
+#endif
+// second launch-bound argument = minimum waves per SIMD the register allocation must allow
+__global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 : NT == 256 ? FQ_WPE_256 : FQ_WPE_512)) void k_fit_quads(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
                                                    const uint32_t* __restrict__ pts_all, const ClusterRec* __restrict__ clusters_all,
                                                    unsigned long long* __restrict__ keys_all, double* __restrict__ lf_all,
                                                    double* __restrict__ errs_a_all, double* __restrict__ errs_b_all,
@@ -477,6 +484,7 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 4 : 2)) void k_fit_quads(const Fra
             }
             v[j] = u128_add(v[j], add);
             carry[j] = run;
+            __builtin_amdgcn_sched_barrier(0);   // keep the NW loads of the next moment from being hoisted (register pressure)
           }
           {
             int run = cnt_carry, add = cnt_carry;
@@ -504,7 +512,7 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 4 : 2)) void k_fit_quads(const Fra
         if (keep) {
           double* o = lf + (size_t)pos * 6;
 #pragma unroll
-          for (int j = 0; j < 6; j++) o[j] = exact_from_fixed(v[j]);
+          for (int j = 0; j < 6; j++) { o[j] = exact_from_fixed(v[j]); __builtin_amdgcn_sched_barrier(0); }
         }
       }
       szd = cnt_carry;
