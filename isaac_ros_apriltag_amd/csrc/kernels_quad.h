@@ -322,6 +322,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
   __shared__ float s_corner[4][2];
   __shared__ U128 s_wtot[(NW > 1 ? 2 * NW : 1) * 6];   // [chunk parity][wave][moment]
   __shared__ int s_wcnt[(NW > 1 ? 2 * NW : 1)];
+  __shared__ U128 s_carry[12];   // [chunk parity][moment]: running totals up to the chunk
 
   const int frame = (int)blockIdx.y + P.frame0;
   const int tid = threadIdx.x;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     // addition is exact and associative; the inclusive scan runs over the whole workgroup and every
     // prefix is rounded to nearest-even double once -- the same definition the CPU oracle uses,
     // independent of order.  Wave totals are double-buffered by chunk parity, so a chunk costs one
-    // barrier; the running carries live in registers (identical in every thread).
+    // barrier; the running carries are double-buffered in LDS the same way (one wave: registers).
     double* lf = lf_all + ((size_t)frame * P.pcap + cl.start) * 6;
     int szd;
     {
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       int cnt_carry = 0;
       int par = 0;
       const int lane = lane_id(), wv = tid >> 6;
+      if (NW > 1 && tid < 6) s_carry[tid] = u128_zero();   // visible after the first chunk's barrier
       for (int base = 0; base < sz; base += NT, par ^= 1) {
         const int i = base + tid;
         U128 v[6];
@@ -476,15 +478,14 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
           __syncthreads();
 #pragma unroll
           for (int j = 0; j < 6; j++) {
-            U128 run = carry[j], add = carry[j];
+            U128 run = s_carry[par * 6 + j], add = run;
 #pragma unroll
             for (int w = 0; w < NW; w++) {
               if (w == wv) add = run;   // wave-uniform select
               run = u128_add(run, s_wtot[(par * NW + w) * 6 + j]);
             }
             v[j] = u128_add(v[j], add);
-            carry[j] = run;
-            __builtin_amdgcn_sched_barrier(0);   // keep the NW loads of the next moment from being hoisted (register pressure)
+            if (tid == 0) s_carry[(par ^ 1) * 6 + j] = run;   // read by the next chunk after its barrier
           }
           {
             int run = cnt_carry, add = cnt_carry;
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
         if (keep) {
           double* o = lf + (size_t)pos * 6;
 #pragma unroll
-          for (int j = 0; j < 6; j++) { o[j] = exact_from_fixed(v[j]); __builtin_amdgcn_sched_barrier(0); }
+          for (int j = 0; j < 6; j++) o[j] = exact_from_fixed(v[j]);
         }
       }
       szd = cnt_carry;
