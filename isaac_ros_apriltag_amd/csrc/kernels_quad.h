@@ -92,6 +92,28 @@ __device__ __forceinline__ U128 u128_dpp(U128 v) {
   r.hi = (unsigned long long)a2 | ((unsigned long long)a3 << 32);
   return r;
 }
+// 96-bit variant for the scan inside one wave: a term is < 2^88 (W < 2^9, x*y < 2^27, 52 fractional
+// bits), so the sum of 64 of them is < 2^94 and the top dword of the 128-bit form stays zero
+struct U96 { unsigned long long lo; uint32_t hi; };
+__device__ __forceinline__ U96 u96_add(U96 a, U96 b) {
+  U96 r;
+  r.lo = a.lo + b.lo;
+  r.hi = a.hi + b.hi + (r.lo < a.lo ? 1u : 0u);
+  return r;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ U96 u96_dpp(U96 v) {
+  uint32_t a0 = (uint32_t)v.lo, a1 = (uint32_t)(v.lo >> 32), a2 = v.hi;
+  a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a0, CTRL, ROW_MASK, 0xF, true);
+  a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a1, CTRL, ROW_MASK, 0xF, true);
+  a2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a2, CTRL, ROW_MASK, 0xF, true);
+  U96 r;
+  r.lo = (unsigned long long)a0 | ((unsigned long long)a1 << 32);
+  r.hi = a2;
+  return r;
+}
+__device__ __forceinline__ U96 u96_of(U128 v) { U96 r; r.lo = v.lo; r.hi = (uint32_t)v.hi; return r; }
+__device__ __forceinline__ U128 u128_of(U96 v) { U128 r; r.lo = v.lo; r.hi = (unsigned long long)v.hi; return r; }
 // value * 2^52 of a double >= 1 (every moment term is: W >= 1, x,y >= 1) and < 2^64
 __device__ __forceinline__ U128 exact_to_fixed(double t) {
   const unsigned long long bits = (unsigned long long)__double_as_longlong(t);
@@ -430,9 +452,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       if (NW > 1 && tid < 6) s_carry[tid] = u128_zero();   // visible after the first chunk's barrier
       for (int base = 0; base < sz; base += NT, par ^= 1) {
         const int i = base + tid;
-        U128 v[6];
+        U96 v[6];   // in-wave prefix (96 bits suffice inside a wave)
 #pragma unroll
-        for (int j = 0; j < 6; j++) v[j] = u128_zero();
+        for (int j = 0; j < 6; j++) { v[j].lo = 0; v[j].hi = 0; }
         bool keep = false;
         if (i < sz) {
           const unsigned long long key = in_lds ? skeys[i] : gkeys[i];
@@ -448,12 +470,12 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
               const int grad_y = (int)gray[(size_t)(iy + 1) * gpitch + ix] - (int)gray[(size_t)(iy - 1) * gpitch + ix];
               Wt = __dsqrt_rn((double)(grad_x * grad_x + grad_y * grad_y)) + 1;
             }
-            v[0] = exact_to_fixed(Wt * x);
-            v[1] = exact_to_fixed(Wt * y);
-            v[2] = exact_to_fixed(Wt * x * x);
-            v[3] = exact_to_fixed(Wt * x * y);
-            v[4] = exact_to_fixed(Wt * y * y);
-            v[5] = exact_to_fixed(Wt);
+            v[0] = u96_of(exact_to_fixed(Wt * x));
+            v[1] = u96_of(exact_to_fixed(Wt * y));
+            v[2] = u96_of(exact_to_fixed(Wt * x * x));
+            v[3] = u96_of(exact_to_fixed(Wt * x * y));
+            v[4] = u96_of(exact_to_fixed(Wt * y * y));
+            v[5] = u96_of(exact_to_fixed(Wt));
           }
         }
         const unsigned long long kmask = __ballot(keep);
@@ -461,18 +483,19 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
         // select is needed
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-          v[j] = u128_add(v[j], u128_dpp<0x111, 0xF>(v[j]));
-          v[j] = u128_add(v[j], u128_dpp<0x112, 0xF>(v[j]));
-          v[j] = u128_add(v[j], u128_dpp<0x114, 0xF>(v[j]));
-          v[j] = u128_add(v[j], u128_dpp<0x118, 0xF>(v[j]));
-          v[j] = u128_add(v[j], u128_dpp<0x142, 0xA>(v[j]));
-          v[j] = u128_add(v[j], u128_dpp<0x143, 0xC>(v[j]));
+          v[j] = u96_add(v[j], u96_dpp<0x111, 0xF>(v[j]));
+          v[j] = u96_add(v[j], u96_dpp<0x112, 0xF>(v[j]));
+          v[j] = u96_add(v[j], u96_dpp<0x114, 0xF>(v[j]));
+          v[j] = u96_add(v[j], u96_dpp<0x118, 0xF>(v[j]));
+          v[j] = u96_add(v[j], u96_dpp<0x142, 0xA>(v[j]));
+          v[j] = u96_add(v[j], u96_dpp<0x143, 0xC>(v[j]));
         }
         int pos = cnt_carry + (int)__popcll(kmask & ((1ull << lane) - 1ull));
+        U128 w[6];   // workgroup-wide prefix
         if (NW > 1) {
           if (lane == 63) {
 #pragma unroll
-            for (int j = 0; j < 6; j++) s_wtot[(par * NW + wv) * 6 + j] = v[j];
+            for (int j = 0; j < 6; j++) s_wtot[(par * NW + wv) * 6 + j] = u128_of(v[j]);
             s_wcnt[par * NW + wv] = (int)__popcll(kmask);
           }
           __syncthreads();
@@ -484,7 +507,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
               if (w == wv) add = run;   // wave-uniform select
               run = u128_add(run, s_wtot[(par * NW + w) * 6 + j]);
             }
-            v[j] = u128_add(v[j], add);
+            w[j] = u128_add(u128_of(v[j]), add);
             if (tid == 0) s_carry[(par ^ 1) * 6 + j] = run;   // read by the next chunk after its barrier
           }
           {
@@ -500,12 +523,12 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
         } else {
 #pragma unroll
           for (int j = 0; j < 6; j++) {
-            v[j] = u128_add(v[j], carry[j]);
+            w[j] = u128_add(u128_of(v[j]), carry[j]);
             U128 t;
-            t.lo = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v[j].lo, 63) |
-                   ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v[j].lo >> 32), 63) << 32);
-            t.hi = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v[j].hi, 63) |
-                   ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v[j].hi >> 32), 63) << 32);
+            t.lo = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w[j].lo, 63) |
+                   ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w[j].lo >> 32), 63) << 32);
+            t.hi = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w[j].hi, 63) |
+                   ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w[j].hi >> 32), 63) << 32);
             carry[j] = t;
           }
           cnt_carry += (int)__popcll(kmask);
@@ -513,7 +536,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
         if (keep) {
           double* o = lf + (size_t)pos * 6;
 #pragma unroll
-          for (int j = 0; j < 6; j++) o[j] = exact_from_fixed(v[j]);
+          for (int j = 0; j < 6; j++) o[j] = exact_from_fixed(w[j]);
         }
       }
       szd = cnt_carry;
