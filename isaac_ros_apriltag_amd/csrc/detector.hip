@@ -498,7 +498,10 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
         }
       }
     }
-    auto lds_bytes = [](const FqClass& c) { return (size_t)c.cap * 8 + (size_t)1024 * 8; };
+    auto lds_bytes = [](const FqClass& c) {
+      const size_t eb = (size_t)(c.cap < 1024 ? c.cap : 1024) * 8, tab = (size_t)FQ_TABLE_DOUBLES * 8;
+      return (size_t)c.cap * 8 + (eb > tab ? eb : tab);
+    };
     if (!D->fq_attr_set) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150000));
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150000));

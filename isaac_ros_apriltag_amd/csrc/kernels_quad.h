@@ -306,12 +306,13 @@ constexpr ComboTable make_combo_table() {
 }
 __device__ const ComboTable g_combo_table = make_combo_table();
 
-// Dynamic LDS layout: [0, 8*sort_cap) slope keys (later: maxima candidates) | 1024 doubles of pair-fit
-// tables.  Clusters with size in (size_lo, size_hi] are processed by this
+// Dynamic LDS layout: [0, 8*sort_cap) slope keys (later: maxima candidates) | FQ_TABLE_DOUBLES doubles of
+// pair-fit tables, or min(sort_cap, 1024) doubles of smoothed errors, whichever is larger.  Clusters with size in (size_lo, size_hi] are processed by this
 // launch; those above sort_cap (only possible in the last class) sort in global scratch.
 template <int NT>
+#define FQ_TABLE_DOUBLES 620   // six 10x10 pair tables, 4 lines x 4 parameters, 4 line mse
 #ifndef FQ_WPE_64
-#define FQ_WPE_64 4
+#define FQ_WPE_64 5
 #define FQ_WPE_128 4
 #define FQ_WPE_256 3
 #define FQ_WPE_512 2
@@ -651,9 +652,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       const int t = task % 100, a = t / 10, b = t % 10;
       if (a < b && b < m) {
         if (task < 100) {
-          double e, ms;
-          fit_line_dev(lf, szd, s_maxidx[a], s_maxidx[b], s_lines + 20 + task * 4, &e, &ms);  // params parked past s_lmse
-          s_ferr[t] = e; s_fmse[t] = ms; s_fnx[t] = s_lines[20 + task * 4 + 2]; s_fny[t] = s_lines[20 + task * 4 + 3];
+          double e, ms, lp[4];
+          fit_line_dev(lf, szd, s_maxidx[a], s_maxidx[b], lp, &e, &ms);
+          s_ferr[t] = e; s_fmse[t] = ms; s_fnx[t] = lp[2]; s_fny[t] = lp[3];
         } else {
           double e, ms;
           fit_line_dev(lf, szd, s_maxidx[b], s_maxidx[a], nullptr, &e, &ms);
