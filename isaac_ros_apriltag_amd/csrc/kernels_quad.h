@@ -305,12 +305,23 @@ constexpr ComboTable make_combo_table() {
   return t;
 }
 __device__ const ComboTable g_combo_table = make_combo_table();
+// the 45 index pairs a < b < 10 in triangular order, packed (a << 4) | b
+struct PairTable { uint8_t v[45]; };
+constexpr PairTable make_pair_table() {
+  PairTable t{};
+  int c = 0;
+  for (int a = 0; a < 9; a++)
+    for (int b = a + 1; b < 10; b++) t.v[c++] = (uint8_t)((a << 4) | b);
+  return t;
+}
+__device__ const PairTable g_pair_table = make_pair_table();
 
 // Dynamic LDS layout: [0, 8*sort_cap) slope keys (later: maxima candidates) | FQ_TABLE_DOUBLES doubles of
 // pair-fit tables, or min(sort_cap, 1024) doubles of smoothed errors, whichever is larger.  Clusters with size in (size_lo, size_hi] are processed by this
 // launch; those above sort_cap (only possible in the last class) sort in global scratch.
 template <int NT>
-#define FQ_TABLE_DOUBLES 620   // six 10x10 pair tables, 4 lines x 4 parameters, 4 line mse
+#define FQ_TABLE_DOUBLES 290   // six 45-entry pair tables, 4 lines x 4 parameters, 4 line mse
+#define FQ_PIDX(a, b) ((((a) * (19 - (a))) >> 1) + (b) - (a) - 1)   // a < b < 10 -> 0..44
 #ifndef FQ_WPE_64
 #define FQ_WPE_64 5
 #define FQ_WPE_128 4
@@ -329,10 +340,11 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
   unsigned long long* skeys = reinterpret_cast<unsigned long long*>(fq_smem);
   double* chunk = reinterpret_cast<double*>(fq_smem + (size_t)sort_cap * 8);
   // pair tables alias the chunk buffer (used after the cumulative sums are finished)
-  double* s_ferr = chunk; double* s_fmse = chunk + 100; double* s_fnx = chunk + 200; double* s_fny = chunk + 300;
-  double* s_werr = chunk + 400; double* s_wmse = chunk + 500;
-  double* s_lines = chunk + 600;  // [4][4]
-  double* s_lmse = chunk + 616;   // [4]
+  // six tables over the 45 index pairs a < b < 10 (triangular index FQ_PIDX)
+  double* s_ferr = chunk; double* s_fmse = chunk + 45; double* s_fnx = chunk + 90; double* s_fny = chunk + 135;
+  double* s_werr = chunk + 180; double* s_wmse = chunk + 225;
+  double* s_lines = chunk + 270;  // [4][4]
+  double* s_lmse = chunk + 286;   // [4]
   constexpr int NW = NT / 64;
   __shared__ long long s_dot[NW][3];
   __shared__ int s_box[NW][4];
@@ -648,10 +660,11 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     FQ_TICK(6)
 
     // ---- pairwise segment fits, then all corner quadruples ---------------------------------------
-    for (int task = tid; task < 200; task += NT) {
-      const int t = task % 100, a = t / 10, b = t % 10;
-      if (a < b && b < m) {
-        if (task < 100) {
+    for (int task = tid; task < 90; task += NT) {
+      const int t = task < 45 ? task : task - 45;
+      const int pr = g_pair_table.v[t], a = pr >> 4, b = pr & 15;   // a < b
+      if (b < m) {
+        if (task < 45) {
           double e, ms, lp[4];
           fit_line_dev(lf, szd, s_maxidx[a], s_maxidx[b], lp, &e, &ms);
           s_ferr[t] = e; s_fmse[t] = ms; s_fnx[t] = lp[2]; s_fny[t] = lp[3];
@@ -673,12 +686,13 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
         const uint32_t my_combo = s_combo[t];
         const int q0 = my_combo & 15, q1 = (my_combo >> 4) & 15, q2 = (my_combo >> 8) & 15, q3 = (my_combo >> 12) & 15;
         if (q3 < m) {
-          const double mse01 = s_fmse[q0 * 10 + q1], mse12 = s_fmse[q1 * 10 + q2], mse23 = s_fmse[q2 * 10 + q3];
-          const double mse30 = s_wmse[q0 * 10 + q3];
-          const double dotn = s_fnx[q0 * 10 + q1] * s_fnx[q1 * 10 + q2] + s_fny[q0 * 10 + q1] * s_fny[q1 * 10 + q2];
+          const int p01 = FQ_PIDX(q0, q1), p12 = FQ_PIDX(q1, q2), p23 = FQ_PIDX(q2, q3), p03 = FQ_PIDX(q0, q3);
+          const double mse01 = s_fmse[p01], mse12 = s_fmse[p12], mse23 = s_fmse[p23];
+          const double mse30 = s_wmse[p03];
+          const double dotn = s_fnx[p01] * s_fnx[p12] + s_fny[p01] * s_fny[p12];
           if (!(mse01 > P.max_line_fit_mse) && !(mse12 > P.max_line_fit_mse) && !(fabs(dotn) > P.cos_critical_rad) &&
               !(mse23 > P.max_line_fit_mse) && !(mse30 > P.max_line_fit_mse)) {
-            const double e = s_ferr[q0 * 10 + q1] + s_ferr[q1 * 10 + q2] + s_ferr[q2 * 10 + q3] + s_werr[q0 * 10 + q3];
+            const double e = s_ferr[p01] + s_ferr[p12] + s_ferr[p23] + s_werr[p03];
             if (e < best_err) { best_err = e; best_t = t; }
           }
         }
