@@ -614,7 +614,29 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     // removed value is the threshold (only the values matter, so ties may be broken arbitrarily).
     if (tid < 64) {
       const int lane = tid;
-      if (nmaxima > P.max_nmaxima) {
+      if (nmaxima > P.max_nmaxima && nmaxima <= 64) {
+        // one candidate per lane: rank every candidate among all of them (value descending, lane
+        // ascending for equal values); rank max_nmaxima holds the threshold value
+        const bool have = lane < nmaxima;
+        const unsigned long long myk = have ? double_sortable(cand_val[lane] + 0.0) : 0ull;
+        const int myi = have ? cand_idx[lane] : -1;
+        int rank = 0;
+        for (int l = 0; l < nmaxima; l++) {
+          const unsigned long long ok =
+              (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)myk, l) |
+              ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(myk >> 32), l) << 32);
+          rank += (ok > myk || (ok == myk && l < lane)) ? 1 : 0;
+        }
+        const unsigned long long tmask = __ballot(have && rank == P.max_nmaxima);
+        const int tl = (int)__ffsll((long long)tmask) - 1;
+        const unsigned long long tk = (unsigned long long)(uint32_t)__shfl((int)(uint32_t)myk, tl, 64) |
+                                      ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(myk >> 32), tl, 64) << 32);
+        const bool kept = have && rank < P.max_nmaxima && myk > tk;
+        const unsigned long long kmask = __ballot(kept);
+        if (kept) s_maxidx[__popcll(kmask & ((1ull << lane) - 1ull))] = myi;
+        if (lane == 0) s_nkept = (int)__popcll(kmask);
+        __threadfence_block();
+      } else if (nmaxima > P.max_nmaxima) {
         for (int round = 0; round <= P.max_nmaxima; round++) {
           unsigned long long bk = 0; int bi = -1;
           for (int k = lane; k < nmaxima; k += 64) {
