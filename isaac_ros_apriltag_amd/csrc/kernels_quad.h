@@ -422,6 +422,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     if (!P.reversed_border && q_reversed) continue;
     if (!P.normal_border && !q_reversed) continue;
     FQ_TICK(1)
+#if defined(FQ_STOP) && FQ_STOP == 1
+    if (P.max_nmaxima == 10) continue;
+#endif
 
     // ---- slope keys + sort -----------------------------------------------------------------------
     const float cx = (float)cxd, cy = (float)cyd;
@@ -444,6 +447,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     __syncthreads();
     if (in_lds) bitonic_sort_block2<NT>(skeys, sz); else bitonic_sort_block2<NT>(gkeys, sz);
     FQ_TICK(2)
+#if defined(FQ_STOP) && FQ_STOP == 2
+    if (P.max_nmaxima == 10) continue;
+#endif
 
     // ---- duplicate removal + weighted moment terms + exact cumulative sums, one sweep ---------------
     // Duplicate points (same half-pixel location, adjacent after the sort) contribute nothing and get no
@@ -557,6 +563,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     __syncthreads();   // lf complete (read by other threads below); key array free
     if (szd < 24) continue;
     FQ_TICK(4)
+#if defined(FQ_STOP) && FQ_STOP == 4
+    if (P.max_nmaxima == 10) continue;
+#endif
 
     // ---- windowed line-fit error, smoothing ------------------------------------------------------
     const int ksz = min(20, szd / 12);
@@ -593,6 +602,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     }
     __syncthreads();
     FQ_TICK(5)
+#if defined(FQ_STOP) && FQ_STOP == 5
+    if (P.max_nmaxima == 10) continue;
+#endif
 
     // ---- local maxima -> candidate list (values + indices) ------------------------------------------
     // list storage: the key array is free now (LDS), or the first error array (global) for huge clusters
@@ -680,6 +692,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     const int m = s_nkept;
     if (m < 4) continue;
     FQ_TICK(6)
+#if defined(FQ_STOP) && FQ_STOP == 6
+    if (P.max_nmaxima == 10) continue;
+#endif
 
     // ---- pairwise segment fits, then all corner quadruples ---------------------------------------
     for (int task = tid; task < 90; task += NT) {
