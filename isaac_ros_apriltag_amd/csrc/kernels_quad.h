@@ -186,37 +186,23 @@ __device__ __forceinline__ void fit_line_dev(const double* lf, int sz, int i0, i
   if (mse) *mse = eig_small;
 }
 
-template <int NT, typename KeyPtr>
-__device__ __forceinline__ void bitonic_sort_block(KeyPtr A, int n) {
-  // all-ascending bitonic network; indices >= n act as +infinity and are never touched.
-  // All strides are powers of two: index arithmetic is shifts and masks only.
-  int lpow = 0;
-  while ((1 << lpow) < n) lpow++;
-  const int half = (1 << lpow) >> 1;
-  for (int lk = 1; lk <= lpow; lk++) {          // merge block size k = 2^lk
-    const int lhk = lk - 1, hkm = (1 << lhk) - 1;
-    for (int i = threadIdx.x; i < half; i += NT) {
-      const int blk = i >> lhk, off = i & hkm;
-      const int a = (blk << lk) + off, b = (blk << lk) + (1 << lk) - 1 - off;
-      if (b < n) {
-        unsigned long long x = A[a], y = A[b];
-        if (x > y) { A[a] = y; A[b] = x; }
-      }
-    }
-    __syncthreads();
-    for (int lj = lk - 2; lj >= 0; lj--) {      // half-cleaners with stride j = 2^lj
-      const int jm = (1 << lj) - 1;
-      for (int i = threadIdx.x; i < half; i += NT) {
-        const int a = ((i >> lj) << (lj + 1)) + (i & jm), b = a + (1 << lj);
-        if (b < n) {
-          unsigned long long x = A[a], y = A[b];
-          if (x > y) { A[a] = y; A[b] = x; }
-        }
-      }
-      __syncthreads();
-    }
-  }
+// Sort keys are stored so that their order as IEEE doubles equals the wanted unsigned order: a
+// compare-exchange is then v_min_f64 + v_max_f64 (two instructions instead of a 64-bit compare and four
+// selects).  u >= 2^63 -> positive double with the same lower 63 bits; u < 2^63 -> ~u, a negative double
+// whose magnitude falls as u grows.  The upper word of u is float_sortable(slope) <= 0xFF800000 and
+// >= 0x387FFFFF (+ bias), so no encoded key has an all-ones exponent (no NaN, no infinity); +infinity is
+// the pad.
+// A bias of 2^20 on the upper word keeps the slope +0.0 (upper word 0x80000000) away from the denormal
+// doubles, so the result does not depend on the denormal mode of the min/max instructions.
+#define AT_KEY_BIAS 0x0010000000000000ull
+__device__ __forceinline__ unsigned long long key_enc(unsigned long long u) {
+  u += AT_KEY_BIAS;
+  return (u >> 63) ? (u ^ 0x8000000000000000ull) : ~u;
 }
+__device__ __forceinline__ unsigned long long key_dec(unsigned long long k) {
+  return ((k >> 63) ? ~k : (k | 0x8000000000000000ull)) - AT_KEY_BIAS;
+}
+#define AT_KEY_PAD 0x7FF0000000000000ull
 
 // Up to three network steps per pass: a thread owns a group of 2^r elements that is closed under r
 // consecutive steps (a flip followed by half-cleaners, or half-cleaners only), so every element is
@@ -226,7 +212,12 @@ template <int R>
 __device__ __forceinline__ void bitonic_group(unsigned long long (&v)[8], bool flip_first) {
   constexpr int M = 1 << R;
   auto ce = [](unsigned long long& lo, unsigned long long& hi) {
-    if (lo > hi) { const unsigned long long t = lo; lo = hi; hi = t; }
+    const double a = __longlong_as_double((long long)lo), b = __longlong_as_double((long long)hi);
+    double mn, mx;
+    asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(a), "v"(b));
+    lo = (unsigned long long)__double_as_longlong(mn);
+    hi = (unsigned long long)__double_as_longlong(mx);
   };
   int first_stride = M >> 1;
   if (flip_first) {
@@ -247,7 +238,7 @@ template <int NT, int R, typename KeyPtr>
 __device__ __forceinline__ void bitonic_pass_r(KeyPtr A, int n, int lpow, int lk, int s) {
   // steps s .. s+R-1 of merge level lk (step 0 = flip of 2^lk blocks, step t = half-cleaner of stride 2^(lk-1-t))
   constexpr int M = 1 << R;
-  const unsigned long long INF = ~0ull;
+  const unsigned long long INF = AT_KEY_PAD;
   const int ngroups = (1 << lpow) >> R;
   // spacing of the group's elements: 2^lsp, where the last step's stride is 2^(lk-1-(s+R-1)) = 2^lsp
   const int lsp = lk - s - R;
@@ -440,8 +431,8 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       if (dy < 0) { dy = -dy; dx = -dx; }
       if (dx < 0) { float tmp = dx; dx = dy; dy = -tmp; }
       const float slope = quadrant + __fdiv_rn(dy, dx);
-      const unsigned long long key = ((unsigned long long)float_sortable(slope) << 32) | ((unsigned long long)y << 18) |
-                                     ((unsigned long long)x << 4) | (unsigned long long)(p & 15u);
+      const unsigned long long key = key_enc(((unsigned long long)float_sortable(slope) << 32) | ((unsigned long long)y << 18) |
+                                             ((unsigned long long)x << 4) | (unsigned long long)(p & 15u));
       if (in_lds) skeys[i] = key; else gkeys[i] = key;
     }
     __syncthreads();
@@ -476,8 +467,8 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
         for (int j = 0; j < 6; j++) { v[j].lo = 0; v[j].hi = 0; }
         bool keep = false;
         if (i < sz) {
-          const unsigned long long key = in_lds ? skeys[i] : gkeys[i];
-          const unsigned long long prev = (i > 0) ? (in_lds ? skeys[i - 1] : gkeys[i - 1]) : ~key;
+          const unsigned long long key = key_dec(in_lds ? skeys[i] : gkeys[i]);
+          const unsigned long long prev = (i > 0) ? key_dec(in_lds ? skeys[i - 1] : gkeys[i - 1]) : ~key;
           keep = (i == 0) || ((key >> 4) != (prev >> 4));
           if (keep) {
             const int px = (int)((key >> 4) & 0x3FFF), py = (int)((key >> 18) & 0x3FFF);
