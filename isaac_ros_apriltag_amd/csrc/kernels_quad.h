@@ -268,11 +268,53 @@ __device__ __forceinline__ void bitonic_pass_r(KeyPtr A, int n, int lpow, int lk
   __syncthreads();
 }
 
+// merge levels 1..3 in one pass: every thread sorts 8 consecutive elements in registers
+template <int NT, typename KeyPtr>
+__device__ __forceinline__ void bitonic_first8(KeyPtr A, int n, int lpow) {
+  auto ce = [](unsigned long long& lo, unsigned long long& hi) {
+    const double a = __longlong_as_double((long long)lo), b = __longlong_as_double((long long)hi);
+    double mn, mx;
+    asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(a), "v"(b));
+    lo = (unsigned long long)__double_as_longlong(mn);
+    hi = (unsigned long long)__double_as_longlong(mx);
+  };
+  const int ngroups = (1 << lpow) >> 3;
+  for (int g = threadIdx.x; g < ngroups; g += NT) {
+    const int base = g << 3;
+    if (base + 1 >= n) continue;
+    unsigned long long v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = base + e < n ? A[base + e] : AT_KEY_PAD;
+#pragma unroll
+    for (int lk = 1; lk <= 3; lk++) {
+      const int k = 1 << lk;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {   // flip inside blocks of k
+        const int off = e & (k - 1);
+        if (off < k / 2) ce(v[e], v[(e & ~(k - 1)) + k - 1 - off]);
+      }
+#pragma unroll
+      for (int st = k >> 2; st >= 1; st >>= 1) {
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+          if ((e & st) == 0) ce(v[e], v[e + st]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++)
+      if (base + e < n) A[base + e] = v[e];
+  }
+  __syncthreads();
+}
+
 template <int NT, typename KeyPtr>
 __device__ __forceinline__ void bitonic_sort_block2(KeyPtr A, int n) {
   int lpow = 0;
   while ((1 << lpow) < n) lpow++;
-  for (int lk = 1; lk <= lpow; lk++) {
+  int lk0 = 1;
+  if (lpow >= 3) { bitonic_first8<NT>(A, n, lpow); lk0 = 4; }
+  for (int lk = lk0; lk <= lpow; lk++) {
     int s = 0;
     while (s < lk) {
       const int left = lk - s;
