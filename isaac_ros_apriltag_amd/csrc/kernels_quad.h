@@ -72,6 +72,12 @@ __device__ __forceinline__ unsigned long long double_sortable(double d) {
 // ---- exact 128-bit fixed-point sums of doubles (52 fractional bits) --------------------------------
 struct U128 { unsigned long long lo, hi; };
 __device__ __forceinline__ U128 u128_zero() { U128 r; r.lo = 0; r.hi = 0; return r; }
+__device__ __forceinline__ U128 u128_sub(U128 a, U128 b) {
+  U128 r;
+  r.lo = a.lo - b.lo;
+  r.hi = a.hi - b.hi - (a.lo < b.lo ? 1ull : 0ull);
+  return r;
+}
 __device__ __forceinline__ U128 u128_add(U128 a, U128 b) {
   U128 r;
   r.lo = a.lo + b.lo;
@@ -353,6 +359,9 @@ __device__ const PairTable g_pair_table = make_pair_table();
 // pair-fit tables, or min(sort_cap, 1024) doubles of smoothed errors, whichever is larger.  Clusters with size in (size_lo, size_hi] are processed by this
 // launch; those above sort_cap (only possible in the last class) sort in global scratch.
 template <int NT>
+#ifndef FQ_EPT
+#define FQ_EPT(NT) ((NT) >= 256 ? 2 : 1)   // elements per lane in the moment sweep
+#endif
 #define FQ_TABLE_DOUBLES 290   // six 45-entry pair tables, 4 lines x 4 parameters, 4 line mse
 #define FQ_PIDX(a, b) ((((a) * (19 - (a))) >> 1) + (b) - (a) - 1)   // a < b < 10 -> 0..44
 #ifndef FQ_WPE_64
@@ -495,42 +504,66 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     double* lf = lf_all + ((size_t)frame * P.pcap + cl.start) * 6;
     int szd;
     {
+      // EPT consecutive elements per lane: the DPP scan, the barrier and the carry traffic are paid once
+      // per EPT elements; the lane's own elements are separated again after the scan by subtraction
+      constexpr int EPT = FQ_EPT(NT);
       U128 carry[6];
 #pragma unroll
       for (int j = 0; j < 6; j++) carry[j] = u128_zero();
       int cnt_carry = 0;
       int par = 0;
       const int lane = lane_id(), wv = tid >> 6;
+      const unsigned long long lt_mask = (1ull << lane) - 1ull;
       if (NW > 1 && tid < 6) s_carry[tid] = u128_zero();   // visible after the first chunk's barrier
-      for (int base = 0; base < sz; base += NT, par ^= 1) {
-        const int i = base + tid;
-        U96 v[6];   // in-wave prefix (96 bits suffice inside a wave)
+      for (int base = 0; base < sz; base += NT * EPT, par ^= 1) {
+        U96 v[6];          // sum of the lane's elements, then the in-wave inclusive prefix (96 bits suffice)
+        U96 t1[6];         // terms of the lane's second element (EPT == 2)
 #pragma unroll
-        for (int j = 0; j < 6; j++) { v[j].lo = 0; v[j].hi = 0; }
-        bool keep = false;
-        if (i < sz) {
-          const unsigned long long key = key_dec(in_lds ? skeys[i] : gkeys[i]);
-          const unsigned long long prev = (i > 0) ? key_dec(in_lds ? skeys[i - 1] : gkeys[i - 1]) : ~key;
-          keep = (i == 0) || ((key >> 4) != (prev >> 4));
-          if (keep) {
-            const int px = (int)((key >> 4) & 0x3FFF), py = (int)((key >> 18) & 0x3FFF);
-            const double x = px * .5 + 0.5, y = py * .5 + 0.5;
-            const int ix = (int)x, iy = (int)y;
-            double Wt = 1;
-            if (ix > 0 && ix + 1 < W && iy > 0 && iy + 1 < H) {
-              const int grad_x = (int)gray[(size_t)iy * gpitch + ix + 1] - (int)gray[(size_t)iy * gpitch + ix - 1];
-              const int grad_y = (int)gray[(size_t)(iy + 1) * gpitch + ix] - (int)gray[(size_t)(iy - 1) * gpitch + ix];
-              Wt = __dsqrt_rn((double)(grad_x * grad_x + grad_y * grad_y)) + 1;
+        for (int j = 0; j < 6; j++) { v[j].lo = 0; v[j].hi = 0; t1[j].lo = 0; t1[j].hi = 0; }
+        bool keep[EPT];
+        unsigned long long prev_key = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+          const int i = base + tid * EPT + e;
+          keep[e] = false;
+          if (i < sz) {
+            const unsigned long long key = key_dec(in_lds ? skeys[i] : gkeys[i]);
+            const unsigned long long prev = (e > 0) ? prev_key : ((i > 0) ? key_dec(in_lds ? skeys[i - 1] : gkeys[i - 1]) : ~key);
+            prev_key = key;
+            keep[e] = (i == 0) || ((key >> 4) != (prev >> 4));
+            if (keep[e]) {
+              const int px = (int)((key >> 4) & 0x3FFF), py = (int)((key >> 18) & 0x3FFF);
+              const double x = px * .5 + 0.5, y = py * .5 + 0.5;
+              const int ix = (int)x, iy = (int)y;
+              double Wt = 1;
+              if (ix > 0 && ix + 1 < W && iy > 0 && iy + 1 < H) {
+                const int grad_x = (int)gray[(size_t)iy * gpitch + ix + 1] - (int)gray[(size_t)iy * gpitch + ix - 1];
+                const int grad_y = (int)gray[(size_t)(iy + 1) * gpitch + ix] - (int)gray[(size_t)(iy - 1) * gpitch + ix];
+                Wt = __dsqrt_rn((double)(grad_x * grad_x + grad_y * grad_y)) + 1;
+              }
+              U96 t[6];
+              t[0] = u96_of(exact_to_fixed(Wt * x));
+              t[1] = u96_of(exact_to_fixed(Wt * y));
+              t[2] = u96_of(exact_to_fixed(Wt * x * x));
+              t[3] = u96_of(exact_to_fixed(Wt * x * y));
+              t[4] = u96_of(exact_to_fixed(Wt * y * y));
+              t[5] = u96_of(exact_to_fixed(Wt));
+#pragma unroll
+              for (int j = 0; j < 6; j++) {
+                v[j] = u96_add(v[j], t[j]);
+                if (e == 1) t1[j] = t[j];
+              }
             }
-            v[0] = u96_of(exact_to_fixed(Wt * x));
-            v[1] = u96_of(exact_to_fixed(Wt * y));
-            v[2] = u96_of(exact_to_fixed(Wt * x * x));
-            v[3] = u96_of(exact_to_fixed(Wt * x * y));
-            v[4] = u96_of(exact_to_fixed(Wt * y * y));
-            v[5] = u96_of(exact_to_fixed(Wt));
           }
         }
-        const unsigned long long kmask = __ballot(keep);
+        unsigned long long kmask[EPT];
+        int before = 0, wcount = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+          kmask[e] = __ballot(keep[e]);
+          before += (int)__popcll(kmask[e] & lt_mask);
+          wcount += (int)__popcll(kmask[e]);
+        }
         // wave-inclusive scan with DPP lane shifts: out-of-range sources read as zero, so no per-step
         // select is needed
 #pragma unroll
@@ -542,22 +575,22 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
           v[j] = u96_add(v[j], u96_dpp<0x142, 0xA>(v[j]));
           v[j] = u96_add(v[j], u96_dpp<0x143, 0xC>(v[j]));
         }
-        int pos = cnt_carry + (int)__popcll(kmask & ((1ull << lane) - 1ull));
-        U128 w[6];   // workgroup-wide prefix
+        int pos = cnt_carry + before;   // slot of the lane's first kept element
+        U128 w[6];   // workgroup-wide prefix including the lane's last element
         if (NW > 1) {
           if (lane == 63) {
 #pragma unroll
             for (int j = 0; j < 6; j++) s_wtot[(par * NW + wv) * 6 + j] = u128_of(v[j]);
-            s_wcnt[par * NW + wv] = (int)__popcll(kmask);
+            s_wcnt[par * NW + wv] = wcount;
           }
           __syncthreads();
 #pragma unroll
           for (int j = 0; j < 6; j++) {
             U128 run = s_carry[par * 6 + j], add = run;
 #pragma unroll
-            for (int w = 0; w < NW; w++) {
-              if (w == wv) add = run;   // wave-uniform select
-              run = u128_add(run, s_wtot[(par * NW + w) * 6 + j]);
+            for (int w2 = 0; w2 < NW; w2++) {
+              if (w2 == wv) add = run;   // wave-uniform select
+              run = u128_add(run, s_wtot[(par * NW + w2) * 6 + j]);
             }
             w[j] = u128_add(u128_of(v[j]), add);
             if (tid == 0) s_carry[(par ^ 1) * 6 + j] = run;   // read by the next chunk after its barrier
@@ -565,9 +598,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
           {
             int run = cnt_carry, add = cnt_carry;
 #pragma unroll
-            for (int w = 0; w < NW; w++) {
-              if (w == wv) add = run;
-              run += s_wcnt[par * NW + w];
+            for (int w2 = 0; w2 < NW; w2++) {
+              if (w2 == wv) add = run;
+              run += s_wcnt[par * NW + w2];
             }
             pos += add - cnt_carry;
             cnt_carry = run;
@@ -583,9 +616,21 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
                    ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w[j].hi >> 32), 63) << 32);
             carry[j] = t;
           }
-          cnt_carry += (int)__popcll(kmask);
+          cnt_carry += wcount;
         }
-        if (keep) {
+        if (EPT == 2) {
+          // second element: prefix w; first element: w minus the second element's terms
+          if (keep[1]) {
+            double* o = lf + (size_t)(pos + (keep[0] ? 1 : 0)) * 6;
+#pragma unroll
+            for (int j = 0; j < 6; j++) o[j] = exact_from_fixed(w[j]);
+          }
+          if (keep[0]) {
+            double* o = lf + (size_t)pos * 6;
+#pragma unroll
+            for (int j = 0; j < 6; j++) o[j] = exact_from_fixed(u128_sub(w[j], u128_of(t1[j])));
+          }
+        } else if (keep[0]) {
           double* o = lf + (size_t)pos * 6;
 #pragma unroll
           for (int j = 0; j < 6; j++) o[j] = exact_from_fixed(w[j]);
