@@ -509,20 +509,27 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150000));
       D->fq_attr_set = true;
     }
-    // The classes are independent (they only append to the quad list), so they run concurrently: class
-    // 0 stays on the lane's stream, the others fork to auxiliary streams and join before decode.
-    // Small-cluster waves fill the CUs that the one-workgroup-per-CU big-cluster class leaves mostly idle.
+    // The classes are independent (they only append to the quad list), so they run concurrently.  The
+    // runtime multiplexes streams onto four hardware queues, and two streams on one queue serialise
+    // (measured: the largest class started only when another one had finished), so exactly four streams
+    // are used and the launches go out longest first: class 4 | class 2 | class 1 then 3 | class 0 on
+    // the lane's own stream.  Small-cluster waves fill the CUs that the one-workgroup-per-CU big-cluster
+    // class leaves mostly idle.
     const bool fork = !D->env_fq_serial;
     if (fork) HIP_TRY(hipEventRecord(D->ev_fork[lane], s));
-    int nlaunched = 0;
-    for (int c = 0; c < NCLS; c++) {
-      if (P.max_cluster_points <= cls[c].lo) break;
+    static const int order[NCLS] = {4, 2, 1, 3, 0};
+    static const int smap[NCLS] = {-1, 2, 1, 2, 0};   // class -> auxiliary stream (-1: the lane's stream)
+    bool used[3] = {false, false, false};
+    for (int oi = 0; oi < NCLS; oi++) {
+      const int c = order[oi];
+      if (P.max_cluster_points <= cls[c].lo) continue;
       const dim3 grid(cls[c].gx, n);
       const size_t lds = lds_bytes(cls[c]);
       hipStream_t sc = s;
-      if (fork && c > 0) {
-        sc = D->aux_stream[lane][(c - 1) & 3];
-        HIP_TRY(hipStreamWaitEvent(sc, D->ev_fork[lane], 0));
+      if (fork && smap[c] >= 0) {
+        sc = D->aux_stream[lane][smap[c]];
+        if (!used[smap[c]]) HIP_TRY(hipStreamWaitEvent(sc, D->ev_fork[lane], 0));
+        used[smap[c]] = true;
       }
 #define FQ_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_keys, D->d_lf, D->d_errs_a, D->d_errs_b, D->d_quads, \
                 D->d_counters, ((D->fq_counters && D->d_fqprof) ? D->d_fqprof + 8 * c : nullptr), cls[c].cap, cls[c].lo, cls[c].hi, P
@@ -531,12 +538,12 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
       else if (cls[c].nt == 256) hipLaunchKernelGGL(k_fit_quads<256>, grid, dim3(256), lds, sc, FQ_ARGS);
       else hipLaunchKernelGGL(k_fit_quads<512>, grid, dim3(512), lds, sc, FQ_ARGS);
 #undef FQ_ARGS
-      nlaunched = c + 1;
     }
     if (fork) {
-      for (int c = 1; c < nlaunched; c++) {
-        HIP_TRY(hipEventRecord(D->ev_join[lane][(c - 1) & 3], D->aux_stream[lane][(c - 1) & 3]));
-        HIP_TRY(hipStreamWaitEvent(s, D->ev_join[lane][(c - 1) & 3], 0));
+      for (int a = 0; a < 3; a++) {
+        if (!used[a]) continue;
+        HIP_TRY(hipEventRecord(D->ev_join[lane][a], D->aux_stream[lane][a]));
+        HIP_TRY(hipStreamWaitEvent(s, D->ev_join[lane][a], 0));
       }
     }
   }
