@@ -6,7 +6,7 @@ from isaac_ros_apriltag_amd import synth
 from isaac_ros_apriltag_amd.detector import AprilTagDetector
 for sigma in (0.0, 2.0):
     frames = np.stack([synth.scene_c2(seed=1234 + i, sigma=sigma)[0] for i in range(4)])
-    for B in (1, 64):
+    for B in (1, 8, 16, 64):
         t = torch.from_numpy(frames).cuda().repeat((B + 3) // 4, 1, 1)[:B].contiguous()
         det = AprilTagDetector(1920, 1080, max_batch=B)
         prep = det.prepare(t)
