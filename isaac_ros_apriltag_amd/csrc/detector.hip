@@ -144,7 +144,8 @@ __global__ void k_debug_math(int op, uint32_t n, const double* a, const double* 
   if (op == 0) out[i] = __dsqrt_rn(a[i]);
   else if (op == 1) out[i] = a[i] / b[i];
   else if (op == 2) out[i] = (double)at_sqrtf_rn((float)a[i]);
-  else out[i] = (double)__fdiv_rn((float)a[i], (float)b[i]);
+  else if (op == 3) out[i] = (double)__fdiv_rn((float)a[i], (float)b[i]);
+  else out[i] = div_by(a[i], b[i], shared_recip(b[i]));   // the line fit's shared-reciprocal division
 }
 
 // colour -> mono8 with the fixed-point BT.601 weights cv_bridge/OpenCV use for the reference's mono8

@@ -152,6 +152,24 @@ __device__ __forceinline__ double exact_from_fixed(U128 v) {
   return top == 0 ? 0.0 : __longlong_as_double((long long)bits);
 }
 
+// n / d with the reciprocal refinement hoisted: shared_recip is v_rcp_f64 + two Newton steps (the
+// operations the compiler's f64 division expands to), div_by is quotient, exact residual, correction.
+// Correctly rounded -- bit-identical to n / d -- for operands that need no v_div_scale rescaling; the
+// line fit uses it with 1 <= d < 2^40 and |n| < 2^70 (checked on the device by the IEEE test, op 4).
+__device__ __forceinline__ double shared_recip(double d) {
+  double r0;
+  asm("v_rcp_f64 %0, %1" : "=v"(r0) : "v"(d));
+  const double e0 = __builtin_fma(-d, r0, 1.0);
+  const double r1 = __builtin_fma(e0, r0, r0);
+  const double e1 = __builtin_fma(-d, r1, 1.0);
+  return __builtin_fma(e1, r1, r1);
+}
+__device__ __forceinline__ double div_by(double n, double d, double r) {
+  const double q = n * r;
+  const double e = __builtin_fma(-d, q, n);
+  return __builtin_fma(e, r, q);
+}
+
 // Line fit over the cumulative moments lf[i*6 + {Mx,My,Mxx,Mxy,Myy,W}] of points i0..i1 (circular).
 __device__ __forceinline__ void fit_line_dev(const double* lf, int sz, int i0, int i1, double* lineparm, double* err,
                                              double* mse) {
@@ -172,8 +190,11 @@ __device__ __forceinline__ void fit_line_dev(const double* lf, int sz, int i0, i
     Mx += b[0]; My += b[1]; Mxx += b[2]; Mxy += b[3]; Myy += b[4]; W += b[5];
     N = sz - i0 + i1 + 1;
   }
-  const double Ex = Mx / W, Ey = My / W;
-  const double Cxx = Mxx / W - Ex * Ex, Cxy = Mxy / W - Ex * Ey, Cyy = Myy / W - Ey * Ey;
+  // Five IEEE divisions by the same W share one reciprocal refinement (shared_recip / div_by)
+  const double rW = shared_recip(W);
+  auto divW = [W, rW](double n) { return div_by(n, W, rW); };
+  const double Ex = divW(Mx), Ey = divW(My);
+  const double Cxx = divW(Mxx) - Ex * Ex, Cxy = divW(Mxy) - Ex * Ey, Cyy = divW(Myy) - Ey * Ey;
   const double disc = (Cxx - Cyy) * (Cxx - Cyy) + 4 * Cxy * Cxy;
   const float rootf = at_sqrtf_rn((float)disc);
   const double eig_small = 0.5 * (Cxx + Cyy - (double)rootf);

@@ -44,6 +44,16 @@ def test_device_arithmetic_is_ieee(built):
     af, bf = a.astype(np.float32), b.astype(np.float32)
     assert np.array_equal(capi.debug_math(2, a, b), np.sqrt(af).astype(np.float64))
     assert np.array_equal(capi.debug_math(3, a, b), (af / bf).astype(np.float64))
+    # the line fit's shared-reciprocal division in its operand range: weights 1 <= W < 2^40 (plus mantissas
+    # of all ones / a single one, where reciprocal rounding is hardest), numerators up to 2^70 of either sign
+    W = np.concatenate([1 + rng.random(300000) * 10 ** rng.uniform(0, 12, 300000),
+                        np.ldexp(2 - 2.0 ** -52, rng.integers(0, 40, 50000)), np.ldexp(1 + 2.0 ** -52, rng.integers(0, 40, 50000)),
+                        np.ldexp(1.0, rng.integers(0, 40, 20000))])
+    W = W[W < 2.0 ** 40]
+    nmr = rng.standard_normal(W.size) * 10 ** rng.uniform(-3, 21, W.size)
+    nmr[::7] = W[::7] * np.rint(rng.standard_normal(W[::7].size) * 1000)          # exact quotients
+    nmr[3::11] = W[3::11] * (np.rint(rng.standard_normal(W[3::11].size) * 1e6) + 0.5) * 2.0 ** -30   # near ties
+    assert np.array_equal(capi.debug_math(4, nmr, W), nmr / W)
 
 
 @pytest.mark.parametrize("name,scene,families,decimate", [
