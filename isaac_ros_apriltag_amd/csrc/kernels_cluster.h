@@ -124,8 +124,12 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   const int lx = tid & 63;
   const int gx = X0 + lx;
   const int DX[4] = {1, 0, -1, 1}, DY[4] = {0, 1, 1, 1};
-  // pass 1: count per pair in the block table
+  // pass 1: count per pair in the block table; every emitting (pixel, direction) of this thread is
+  // remembered as a bit of emask plus the byte index of its table entry (0xFF: the table was full), so
+  // that pass 2 does not walk the neighbourhood again
   uint32_t cnt = 0;
+  uint32_t emask = 0;
+  uint32_t eidx[4] = {0, 0, 0, 0};
   {
     uint64_t last_key = AT_EMPTY_KEY;
     int last_e = -1;
@@ -150,7 +154,9 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
         if (r1 == AT_NO_LABEL || v0 + (int)sv[n] != 255) continue;
         const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
         if (key != last_key) { last_key = key; last_e = ltab_insert(tkey, key); }
-        if (last_e >= 0) atomicAdd(&tcnt[last_e], 1u);
+        if (last_e >= 0 && last_e < 255) atomicAdd(&tcnt[last_e], 1u);
+        emask |= 1u << (k * 4 + d);
+        eidx[k] |= (uint32_t)((last_e >= 0 && last_e < 255) ? last_e : 255) << (8 * d);
         cnt++;
       }
     }
@@ -179,52 +185,37 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   if (base + total > P.pcap) {
     if (tid == 0) atomicOr(&counters[frame].flags, 0x1u);
   }
-  // pass 2: emit {slot, point} and the rank inside the cluster
+  // pass 2: emit {slot, point} and the rank inside the cluster for the remembered emitters
   uint2* stage = stage_all + (size_t)frame * P.pcap;
   uint32_t* rank = rank_all + (size_t)frame * P.pcap;
-  uint64_t last_key = AT_EMPTY_KEY;
-  int last_e = -1;
-  uint32_t last_slot = AT_INVALID_SLOT;
   uint32_t pos = base + off;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
+  while (emask) {
+    const int sidx = __ffs((int)emask) - 1;
+    emask &= emask - 1;
+    const int k = sidx >> 2, d = sidx & 3;
     const int ly = (tid >> 6) + 4 * k;
     const int gy = Y0 + ly;
-    if (gx < 1 || gx > W - 2 || gy < 1 || gy > H - 2) continue;
     const int c = ly * PT_LW + lx + 1;
-    const uint32_t r0 = slab[c];
-    if (r0 == AT_NO_LABEL) continue;
-    const int v0 = sv[c];
-    const bool left_emits = gx - 1 >= 1 && slab[c - 1] != AT_NO_LABEL && slab[c + PT_LW] != AT_NO_LABEL &&
-                            (int)sv[c - 1] + (int)sv[c + PT_LW] == 255;
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-      if (d == 2 && left_emits) continue;
-      const int n = c + DY[d] * PT_LW + DX[d];
-      const uint32_t r1 = slab[n];
-      const int v1 = sv[n];
-      if (r1 == AT_NO_LABEL || v0 + v1 != 255) continue;
+    const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
+    const int n = c + ddy * PT_LW + ddx;
+    const int v0 = sv[c], v1 = sv[n];
+    const uint32_t e = (eidx[k] >> (8 * d)) & 255u;
+    uint32_t slot, rk = 0;
+    if (e != 255u) {
+      slot = tslot[e];
+      if (slot != AT_INVALID_SLOT) rk = tbase[e] + atomicAdd(&tcnt[e], 1u);
+    } else {  // block table was full: this pair goes straight to the frame table
+      const uint32_t r0 = slab[c], r1 = slab[n];
       const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
-      if (key != last_key) {
-        last_key = key;
-        last_e = ltab_find(tkey, key);
-        if (last_e >= 0) last_slot = tslot[last_e];
-        else {  // block table was full: this pair goes straight to the frame table
-          last_slot = hash_insert(hkeys, P.hcap, P.hshift, key);
-          if (last_slot == AT_INVALID_SLOT) atomicOr(&counters[frame].flags, 0x2u);
-        }
-      }
-      uint32_t rk = 0;
-      if (last_slot != AT_INVALID_SLOT) {
-        if (last_e >= 0) rk = tbase[last_e] + atomicAdd(&tcnt[last_e], 1u);
-        else rk = atomicAdd(&hcnt[last_slot], 1u);
-      }
-      if (pos < P.pcap) {
-        stage[pos] = make_uint2(last_slot, pack_point(2 * gx + DX[d], 2 * gy + DY[d], DX[d] * (v1 - v0), DY[d] * (v1 - v0)));
-        rank[pos] = rk;
-      }
-      pos++;
+      slot = hash_insert(hkeys, P.hcap, P.hshift, key);
+      if (slot == AT_INVALID_SLOT) atomicOr(&counters[frame].flags, 0x2u);
+      else rk = atomicAdd(&hcnt[slot], 1u);
     }
+    if (pos < P.pcap) {
+      stage[pos] = make_uint2(slot, pack_point(2 * gx + ddx, 2 * gy + ddy, ddx * (v1 - v0), ddy * (v1 - v0)));
+      rank[pos] = rk;
+    }
+    pos++;
   }
 }
 
