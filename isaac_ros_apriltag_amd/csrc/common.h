@@ -97,10 +97,11 @@ __device__ __forceinline__ uint32_t float_sortable(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// Correctly rounded float sqrt: HIP's __fsqrt_rn lowers to the native (approximate) instruction on
-// gfx950 (measured: not bit-exact against IEEE).  sqrt in double followed by one rounding to float
-// is exact because 53 >= 2*24 + 2 (double rounding is innocuous for sqrt at that width).
-__device__ __forceinline__ float at_sqrtf_rn(float x) { return (float)__dsqrt_rn((double)x); }
+// Correctly rounded float sqrt.  HIP's __fsqrt_rn lowers to the native (approximate) instruction on
+// gfx950 (measured: not bit-exact against IEEE), while plain sqrtf under this build's flags (no fast
+// math; correctly-rounded f32 divide/sqrt is the HIP default) expands to v_sqrt_f32 plus the fix-up steps
+// and is exact (amdAprilTagsDebugMath op 2 checks it on the device against IEEE on 200 000 operands).
+__device__ __forceinline__ float at_sqrtf_rn(float x) { return sqrtf(x); }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
