@@ -487,6 +487,10 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
                          {256, 4096, 1024, 4096, clampu(2048u / n, 32u, 512u)},
                          {256, 8192, 4096, 8192, clampu(1024u / n, 16u, 256u)},
                          {512, 16384, 8192, 0x7FFFFFFF, clampu(512u / n, 8u, 256u)}};
+    // the largest cluster a frame can hold is max_cluster_points = 3(2W+2H): when that is at most 18432
+    // points (1080p: 18000) the last class keeps all of them in LDS (144 KB of keys + the table region
+    // still fit the 160 KB of a CU) instead of sorting the rare >16384-point cluster in global scratch
+    if (P.max_cluster_points > 16384 && P.max_cluster_points <= 18432) cls[4].cap = (P.max_cluster_points + 63) & ~63;
     if (const char* ov = D->env_fq_classes) {  // tuning override: "nt:cap:gxbudget" x 5 (size bounds follow cap)
       int nt[NCLS], cap[NCLS], bud[NCLS];
       if (sscanf(ov, "%d:%d:%d,%d:%d:%d,%d:%d:%d,%d:%d:%d,%d:%d:%d", &nt[0], &cap[0], &bud[0], &nt[1], &cap[1], &bud[1], &nt[2],
@@ -504,7 +508,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
       return (size_t)c.cap * 8 + (eb > tab ? eb : tab);
     };
     if (!D->fq_attr_set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150000));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 157000));
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150000));
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 150000));
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150000));
