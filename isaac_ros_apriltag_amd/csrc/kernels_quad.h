@@ -418,8 +418,10 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
   __shared__ int s_nkept;
   __shared__ uint16_t s_combo[210];
   __shared__ float s_corner[4][2];
-  __shared__ U128 s_wtot[(NW > 1 ? 2 * NW : 1) * 6];   // [chunk parity][wave][moment]
-  __shared__ int s_wcnt[(NW > 1 ? 2 * NW : 1)];
+  __shared__ U128 s_wtot[NW * 6];   // [wave][moment]: wave totals of the current chunk
+  __shared__ U128 s_woff[NW * 6];   // [wave][moment]: offset every lane of the wave adds
+  __shared__ int s_wcnt[NW];
+  __shared__ int s_coff[NW + 1];    // kept-point offsets per wave, [NW] = chunk total
   __shared__ U128 s_carry[12];   // [chunk parity][moment]: running totals up to the chunk
 
   const int frame = (int)blockIdx.y + P.frame0;
@@ -599,33 +601,33 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
         int pos = cnt_carry + before;   // slot of the lane's first kept element
         U128 w[6];   // workgroup-wide prefix including the lane's last element
         if (NW > 1) {
+          // two-level combine: the wave totals go to LDS, NW*6 threads turn them into per-wave offsets
+          // (running total of the previous chunks + the waves before), everybody adds its wave's offset.
+          // Per-thread work and register use do not grow with the number of waves.
           if (lane == 63) {
 #pragma unroll
-            for (int j = 0; j < 6; j++) s_wtot[(par * NW + wv) * 6 + j] = u128_of(v[j]);
-            s_wcnt[par * NW + wv] = wcount;
+            for (int j = 0; j < 6; j++) s_wtot[wv * 6 + j] = u128_of(v[j]);
+            s_wcnt[wv] = wcount;
+          }
+          __syncthreads();
+          if (tid < NW * 6) {
+            const int ww = tid / 6, j = tid - ww * 6;
+            U128 run = s_carry[par * 6 + j];
+            for (int w2 = 0; w2 < ww; w2++) run = u128_add(run, s_wtot[w2 * 6 + j]);
+            s_woff[tid] = run;
+            if (ww == NW - 1) s_carry[(par ^ 1) * 6 + j] = u128_add(run, s_wtot[ww * 6 + j]);
+          } else if (tid < NW * 7) {
+            const int ww = tid - NW * 6;
+            int run = 0;
+            for (int w2 = 0; w2 < ww; w2++) run += s_wcnt[w2];
+            s_coff[ww] = run;
+            if (ww == NW - 1) s_coff[NW] = run + s_wcnt[ww];
           }
           __syncthreads();
 #pragma unroll
-          for (int j = 0; j < 6; j++) {
-            U128 run = s_carry[par * 6 + j], add = run;
-#pragma unroll
-            for (int w2 = 0; w2 < NW; w2++) {
-              if (w2 == wv) add = run;   // wave-uniform select
-              run = u128_add(run, s_wtot[(par * NW + w2) * 6 + j]);
-            }
-            w[j] = u128_add(u128_of(v[j]), add);
-            if (tid == 0) s_carry[(par ^ 1) * 6 + j] = run;   // read by the next chunk after its barrier
-          }
-          {
-            int run = cnt_carry, add = cnt_carry;
-#pragma unroll
-            for (int w2 = 0; w2 < NW; w2++) {
-              if (w2 == wv) add = run;
-              run += s_wcnt[par * NW + w2];
-            }
-            pos += add - cnt_carry;
-            cnt_carry = run;
-          }
+          for (int j = 0; j < 6; j++) w[j] = u128_add(u128_of(v[j]), s_woff[wv * 6 + j]);
+          pos += s_coff[wv];
+          cnt_carry += s_coff[NW];
         } else {
 #pragma unroll
           for (int j = 0; j < 6; j++) {
