@@ -503,8 +503,10 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
         }
       }
     }
+    // keys | table region; the smoothed errors of clusters up to 1024 points share the table region, so
+    // only classes that can see such clusters pay for 1024 doubles there
     auto lds_bytes = [](const FqClass& c) {
-      const size_t eb = (size_t)(c.cap < 1024 ? c.cap : 1024) * 8, tab = (size_t)FQ_TABLE_DOUBLES * 8;
+      const size_t eb = c.lo >= 1024 ? 0 : (size_t)(c.cap < 1024 ? c.cap : 1024) * 8, tab = (size_t)FQ_TABLE_DOUBLES * 8;
       return (size_t)c.cap * 8 + (eb > tab ? eb : tab);
     };
     if (!D->fq_attr_set) {

@@ -388,7 +388,7 @@ template <int NT>
 #ifndef FQ_WPE_64
 #define FQ_WPE_64 5
 #define FQ_WPE_128 4
-#define FQ_WPE_256 3
+#define FQ_WPE_256 4
 #define FQ_WPE_512 2
 #endif
 // second launch-bound argument = minimum waves per SIMD the register allocation must allow
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     // the smoothed errors use the pair-table region while it is still free (clusters up to 1024 points),
     // global scratch otherwise
     double* ea = in_lds ? reinterpret_cast<double*>(skeys) : errs_a_all + (size_t)frame * P.pcap + cl.start;
-    double* eb = (in_lds && szd <= 1024) ? chunk : errs_b_all + (size_t)frame * P.pcap + cl.start;
+    double* eb = (in_lds && szd <= 1024 && size_lo < 1024) ? chunk : errs_b_all + (size_t)frame * P.pcap + cl.start;
     // (indices wrap with compare/subtract: integer division by a run-time value costs ~40 instructions)
     for (int i = tid; i < szd; i += NT) {
       double e;
