@@ -711,12 +711,25 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     // list storage: the key array is free now (LDS), or the first error array (global) for huge clusters
     double* cand_val = in_lds ? reinterpret_cast<double*>(skeys) : ea;
     int* cand_idx = in_lds ? reinterpret_cast<int*>(skeys + (sort_cap >> 1)) : reinterpret_cast<int*>(ea + (szd >> 1) + 1);
-    for (int i = tid; i < szd; i += NT) {
-      const double e = eb[i];
-      if (e > eb[i + 1 < szd ? i + 1 : 0] && e > eb[i > 0 ? i - 1 : szd - 1]) {
-        const int k = atomicAdd(&s_ncand, 1);
-        cand_val[k] = e;
-        cand_idx[k] = i;
+    // one LDS atomic per wave and iteration (the lanes' slots come from a ballot), not one per maximum
+    for (int base = 0; base < szd; base += NT) {
+      const int i = base + tid;
+      double e = 0;
+      bool is_max = false;
+      if (i < szd) {
+        e = eb[i];
+        is_max = e > eb[i + 1 < szd ? i + 1 : 0] && e > eb[i > 0 ? i - 1 : szd - 1];
+      }
+      const unsigned long long mm = __ballot(is_max);
+      if (mm) {
+        int kbase = 0;
+        if (lane_id() == 0) kbase = atomicAdd(&s_ncand, (int)__popcll(mm));
+        kbase = __builtin_amdgcn_readfirstlane(kbase);
+        if (is_max) {
+          const int k = kbase + (int)__popcll(mm & ((1ull << lane_id()) - 1ull));
+          cand_val[k] = e;
+          cand_idx[k] = i;
+        }
       }
     }
     __syncthreads();
