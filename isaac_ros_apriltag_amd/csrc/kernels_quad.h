@@ -1,19 +1,19 @@
 // kernels_quad.h -- S5 quad fitting (inside cuAprilTagsDetect, reference
 // src/apriltag_node.cpp:491-493).  One workgroup per cluster, five launch classes by cluster size
 // (one wave for <= 256 points ... 512 threads above 8192) so that small clusters do not pay for idle
-// waves and the slope sort always runs in LDS (2 KB ... 128 KB of keys):
-//   bbox / gradient-dot: seven DPP wave reductions, one barrier -> slope keys -> in-place bitonic sort
-//   in LDS -> one sweep that drops duplicate points, widens the weighted moment terms to 128-bit fixed
-//   point (sums are exact there), scans them across the workgroup (DPP wave scan, wave totals
-//   double-buffered: one barrier per chunk) and rounds every prefix once (bit-identical to the CPU
-//   definition in any order) -> windowed line-fit errors, 7-tap smoothing -> local maxima compacted into
-//   LDS -> wave 0 alone: top-10 selection by 11 arg-max rounds -> table of pairwise segment fits (all
-//   threads) -> wave 0 alone: best of the C(10,4) corner choices, 4 line fits, intersections and the
-//   area/angle checks.
-// Where the time goes (1080p sigma-2 frames, 256 per submission, 41.7 ms; measured by truncating the
-// kernel after each phase): cluster loop + bbox 3.8 ms, keys + sort 10.3, moment sweep 15.6 (gradient
-// gathers 2.6, rounding + 48 B/point store 5.4, terms + scans 7.6), errors + smoothing 4.4, maxima +
-// selection 4.3, pair table + corner choice + checks 3.4.
+// waves and the slope sort always runs in LDS (2 KB ... 144 KB of keys):
+//   bbox / gradient-dot: seven DPP wave reductions, one barrier -> slope keys, stored so that their order
+//   as IEEE doubles is the wanted order -> bitonic sort in LDS (first three levels in registers, then up
+//   to three network steps per pass, compare-exchange = v_min_f64 + v_max_f64) -> one sweep that drops
+//   duplicate points, widens the weighted moment terms to fixed point (sums are exact there), scans them
+//   (DPP wave scan, 96 bits inside a wave; wave totals combined in two levels through LDS) and rounds
+//   every prefix once (bit-identical to the CPU definition in any order) -> windowed line-fit errors,
+//   7-tap smoothing -> local maxima compacted into LDS -> wave 0 alone: top-10 selection (rank among
+//   <= 64 candidates, else 11 arg-max rounds) -> table of the 45 pairwise segment fits (all threads) ->
+//   wave 0 alone: best of the C(10,4) corner choices, 4 line fits, intersections, area/angle checks.
+// Where the time goes (1080p sigma-2 frames, 256 per submission, 27.6 ms; measured by truncating the
+// kernel after each phase, -DFQ_STOP=n): cluster loop + bbox 3.7 ms, keys + sort 6.8, moment sweep 9.0,
+// errors + smoothing 2.5, maxima + selection 3.3, pair table + corner choice + checks 2.3.
 #pragma once
 #include "common.h"
 
