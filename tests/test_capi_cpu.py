@@ -86,3 +86,19 @@ def test_register_custom_family():
     assert capi.family_info("mini16")["codes"] == [0x231b, 0x2ea5, 0x346a]
     assert L.amdAprilTagsRegisterFamily(0, b"x", 4, codes, 3) == 1   # built-in slots are read-only
     assert L.amdAprilTagsStageName(1) == b"threshold"
+
+
+def test_c99_example_compiles_and_links(tmp_path):
+    """examples/detect_one.c is a plain C99 host of the C ABI (no C++, no HIP headers): it must compile with
+    -pedantic -Werror against include/apriltag_amd.h and link against the in-tree library."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "isaac_ros_apriltag_amd")
+    exe = str(tmp_path / "detect_one")
+    assert shutil.which("gcc")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "detect_one.c"), "-L", libdir, "-lapriltag_amd",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr

@@ -448,3 +448,22 @@ def test_checkerboard_more_quads_than_the_old_fixed_capacity(built):
     det.close()
     assert not errs, errs[:3]
     assert nq > 8192
+
+
+def test_c99_example_runs(built, tmp_path):
+    """The plain-C example host (examples/detect_one.c) detects the config-1 tag from a PGM file."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "isaac_ros_apriltag_amd")
+    exe = str(tmp_path / "detect_one")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "detect_one.c"),
+                           "-L", libdir, "-lapriltag_amd", "-Wl,-rpath," + libdir, "-o", exe])
+    img, K, truth = synth.scene_c1()
+    pgm = tmp_path / "c1.pgm"
+    with open(pgm, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(np.ascontiguousarray(img).tobytes())
+    r = subprocess.run([exe, str(pgm), "0.22", str(K[0, 0]), str(K[1, 1]), str(K[0, 2]), str(K[1, 2])],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "1 detection(s)" in r.stdout and r.stdout.startswith("id 0 ")
