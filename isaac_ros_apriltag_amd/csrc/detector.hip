@@ -503,12 +503,8 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
         }
       }
     }
-    // keys | table region; the smoothed errors of clusters up to 1024 points share the table region, so
-    // only classes that can see such clusters pay for 1024 doubles there
-    auto lds_bytes = [](const FqClass& c) {
-      const size_t eb = c.lo >= 1024 ? 0 : (size_t)(c.cap < 1024 ? c.cap : 1024) * 8, tab = (size_t)FQ_TABLE_DOUBLES * 8;
-      return (size_t)c.cap * 8 + (eb > tab ? eb : tab);
-    };
+    // keys | pair-table region
+    auto lds_bytes = [](const FqClass& c) { return (size_t)c.cap * 8 + (size_t)FQ_TABLE_DOUBLES * 8; };
     if (!D->fq_attr_set) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 157000));
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150000));

@@ -376,18 +376,19 @@ constexpr PairTable make_pair_table() {
 }
 __device__ const PairTable g_pair_table = make_pair_table();
 
-// Dynamic LDS layout: [0, 8*sort_cap) slope keys (later: maxima candidates) | FQ_TABLE_DOUBLES doubles of
-// pair-fit tables, or min(sort_cap, 1024) doubles of smoothed errors, whichever is larger.  Clusters with size in (size_lo, size_hi] are processed by this
+// Dynamic LDS layout: [0, 8*sort_cap) slope keys (later: raw/smoothed errors, then maxima candidates) |
+// FQ_TABLE_DOUBLES doubles of pair-fit tables.  Clusters with size in (size_lo, size_hi] are processed by this
 // launch; those above sort_cap (only possible in the last class) sort in global scratch.
 template <int NT>
 #ifndef FQ_EPT
 #define FQ_EPT(NT) ((NT) >= 256 ? 2 : 1)   // elements per lane in the moment sweep
 #endif
+#define FQ_SMOOTH_REGS 16      // smoothed errors per thread kept in registers (clusters up to 16 x threads)
 #define FQ_TABLE_DOUBLES 290   // six 45-entry pair tables, 4 lines x 4 parameters, 4 line mse
 #define FQ_PIDX(a, b) ((((a) * (19 - (a))) >> 1) + (b) - (a) - 1)   // a < b < 10 -> 0..44
 #ifndef FQ_WPE_64
 #define FQ_WPE_64 5
-#define FQ_WPE_128 4
+#define FQ_WPE_128 5
 #define FQ_WPE_256 4
 #define FQ_WPE_512 2
 #endif
@@ -670,11 +671,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
 
     // ---- windowed line-fit error, smoothing ------------------------------------------------------
     const int ksz = min(20, szd / 12);
-    // error arrays: the key array is dead after the moment terms, so the raw errors live there (LDS);
-    // the smoothed errors use the pair-table region while it is still free (clusters up to 1024 points),
-    // global scratch otherwise
+    // raw errors: the key array is dead after the moment terms, so they live there (LDS); global scratch
+    // for clusters that do not fit it
     double* ea = in_lds ? reinterpret_cast<double*>(skeys) : errs_a_all + (size_t)frame * P.pcap + cl.start;
-    double* eb = (in_lds && szd <= 1024 && size_lo < 1024) ? chunk : errs_b_all + (size_t)frame * P.pcap + cl.start;
     // (indices wrap with compare/subtract: integer division by a run-time value costs ~40 instructions)
     for (int i = tid; i < szd; i += NT) {
       double e;
@@ -685,11 +684,73 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     }
     if (tid == 0) { s_ncand = 0; s_nkept = 0; }
     __syncthreads();
-    {
-      const float f0 = 0x1.6c0504p-7f, f1 = 0x1.152aaap-3f, f2 = 0x1.368b3p-1f;
-      const double F0 = (double)f0, F1 = (double)f1, F2 = (double)f2;
+    const float f0 = 0x1.6c0504p-7f, f1 = 0x1.152aaap-3f, f2 = 0x1.368b3p-1f;
+    const double F0 = (double)f0, F1 = (double)f1, F2 = (double)f2;
+    auto wrap = [szd](int k) { return k < 0 ? k + szd : (k >= szd ? k - szd : k); };
+    double* cand_val = in_lds ? reinterpret_cast<double*>(skeys) : ea;
+    int* cand_idx = in_lds ? reinterpret_cast<int*>(skeys + (sort_cap >> 1)) : reinterpret_cast<int*>(ea + (szd >> 1) + 1);
+    if (in_lds && szd <= FQ_SMOOTH_REGS * NT) {
+      // Up to FQ_SMOOTH_REGS points per thread: the smoothed errors are formed in registers, written back
+      // over the raw ones, compared with their neighbours, and only then does the same LDS array take the
+      // candidate list -- no second error array (LDS or global) at all.  The pointers below are derived
+      // from the LDS array directly (not from the LDS-or-global selects above), so the compiler emits
+      // ds_ instructions with LDS alignment rules instead of flat accesses it may widen to 16 bytes.
+      double* const le = reinterpret_cast<double*>(skeys);
+      double* const lcv = reinterpret_cast<double*>(skeys);
+      int* const lci = reinterpret_cast<int*>(skeys + (sort_cap >> 1));
+      double acc[FQ_SMOOTH_REGS];
+#pragma unroll
+      for (int it = 0; it < FQ_SMOOTH_REGS; it++) {
+        const int i = tid + it * NT;
+        acc[it] = 0;
+        if (i < szd) {
+          double a2 = 0;
+          a2 += le[wrap(i - 3)] * F0;
+          a2 += le[wrap(i - 2)] * F1;
+          a2 += le[wrap(i - 1)] * F2;
+          a2 += le[i] * 1.0;
+          a2 += le[wrap(i + 1)] * F2;
+          a2 += le[wrap(i + 2)] * F1;
+          a2 += le[wrap(i + 3)] * F0;
+          acc[it] = a2;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < FQ_SMOOTH_REGS; it++) {
+        const int i = tid + it * NT;
+        if (i < szd) le[i] = acc[it];
+      }
+      __syncthreads();
+      uint32_t mx = 0;
+#pragma unroll
+      for (int it = 0; it < FQ_SMOOTH_REGS; it++) {
+        const int i = tid + it * NT;
+        if (i < szd) {
+          const double e = acc[it];
+          if (e > le[i + 1 < szd ? i + 1 : 0] && e > le[i > 0 ? i - 1 : szd - 1]) mx |= 1u << it;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < FQ_SMOOTH_REGS; it++) {
+        if (it * NT >= szd) break;
+        const bool is_max = (mx >> it) & 1u;
+        const unsigned long long mm = __ballot(is_max);
+        if (mm) {
+          int kbase = 0;
+          if (lane_id() == 0) kbase = atomicAdd(&s_ncand, (int)__popcll(mm));
+          kbase = __builtin_amdgcn_readfirstlane(kbase);
+          if (is_max) {
+            const int k = kbase + (int)__popcll(mm & ((1ull << lane_id()) - 1ull));
+            lcv[k] = acc[it];
+            lci[k] = tid + it * NT;
+          }
+        }
+      }
+    } else {
+      double* eb = errs_b_all + (size_t)frame * P.pcap + cl.start;
       for (int i = tid; i < szd; i += NT) {
-        auto wrap = [szd](int k) { return k < 0 ? k + szd : (k >= szd ? k - szd : k); };
         double acc = 0;
         acc += ea[wrap(i - 3)] * F0;
         acc += ea[wrap(i - 2)] * F1;
@@ -700,38 +761,32 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
         acc += ea[wrap(i + 3)] * F0;
         eb[i] = acc;
       }
+      __syncthreads();
+      for (int base = 0; base < szd; base += NT) {
+        const int i = base + tid;
+        double e = 0;
+        bool is_max = false;
+        if (i < szd) {
+          e = eb[i];
+          is_max = e > eb[i + 1 < szd ? i + 1 : 0] && e > eb[i > 0 ? i - 1 : szd - 1];
+        }
+        const unsigned long long mm = __ballot(is_max);
+        if (mm) {
+          int kbase = 0;
+          if (lane_id() == 0) kbase = atomicAdd(&s_ncand, (int)__popcll(mm));
+          kbase = __builtin_amdgcn_readfirstlane(kbase);
+          if (is_max) {
+            const int k = kbase + (int)__popcll(mm & ((1ull << lane_id()) - 1ull));
+            cand_val[k] = e;
+            cand_idx[k] = i;
+          }
+        }
+      }
     }
-    __syncthreads();
     FQ_TICK(5)
 #if defined(FQ_STOP) && FQ_STOP == 5
     if (P.max_nmaxima == 10) continue;
 #endif
-
-    // ---- local maxima -> candidate list (values + indices) ------------------------------------------
-    // list storage: the key array is free now (LDS), or the first error array (global) for huge clusters
-    double* cand_val = in_lds ? reinterpret_cast<double*>(skeys) : ea;
-    int* cand_idx = in_lds ? reinterpret_cast<int*>(skeys + (sort_cap >> 1)) : reinterpret_cast<int*>(ea + (szd >> 1) + 1);
-    // one LDS atomic per wave and iteration (the lanes' slots come from a ballot), not one per maximum
-    for (int base = 0; base < szd; base += NT) {
-      const int i = base + tid;
-      double e = 0;
-      bool is_max = false;
-      if (i < szd) {
-        e = eb[i];
-        is_max = e > eb[i + 1 < szd ? i + 1 : 0] && e > eb[i > 0 ? i - 1 : szd - 1];
-      }
-      const unsigned long long mm = __ballot(is_max);
-      if (mm) {
-        int kbase = 0;
-        if (lane_id() == 0) kbase = atomicAdd(&s_ncand, (int)__popcll(mm));
-        kbase = __builtin_amdgcn_readfirstlane(kbase);
-        if (is_max) {
-          const int k = kbase + (int)__popcll(mm & ((1ull << lane_id()) - 1ull));
-          cand_val[k] = e;
-          cand_idx[k] = i;
-        }
-      }
-    }
     __syncthreads();
     const int nmaxima = s_ncand;
     if (nmaxima < 4) continue;

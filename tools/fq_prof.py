@@ -12,7 +12,7 @@ det.set_profiling(2)
 det.detect_batch_ex(t)
 print({k: round(v, 3) for k, v in det.stage_ms().items()})
 pa = det.debug(0, 8).view(np.uint64)[:40].astype(np.float64).reshape(5, 8)
-names = ["loop/sync", "bbox+dot", "keys+sort", "-", "dedup+terms+prefix", "errs+smooth", "maxima+select", "pairs+combos+final"]
+names = ["loop/sync", "bbox+dot", "keys+sort", "-", "dedup+terms+prefix", "errs+smooth+maxima", "select", "pairs+combos+final"]
 for c in range(5):
     p = pa[c]
     print("class %d total %.3e cycles: " % (c, p.sum()) + ", ".join("%s %.0f%%" % (n, 100 * v / max(p.sum(), 1)) for n, v in zip(names, p) if n != "-"))
