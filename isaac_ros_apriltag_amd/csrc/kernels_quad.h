@@ -383,6 +383,7 @@ template <int NT>
 #ifndef FQ_EPT
 #define FQ_EPT(NT) ((NT) >= 256 ? 2 : 1)   // elements per lane in the moment sweep
 #endif
+#define FQ_SEL_REGS 8          // maxima candidates per lane held in registers during the top-10 selection
 #define FQ_SMOOTH_REGS 16      // smoothed errors per thread kept in registers (clusters up to 16 x threads)
 #define FQ_TABLE_DOUBLES 290   // six 45-entry pair tables, 4 lines x 4 parameters, 4 line mse
 #define FQ_PIDX(a, b) ((((a) * (19 - (a))) >> 1) + (b) - (a) - 1)   // a < b < 10 -> 0..44
@@ -815,6 +816,41 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
         const bool kept = have && rank < P.max_nmaxima && myk > tk;
         const unsigned long long kmask = __ballot(kept);
         if (kept) s_maxidx[__popcll(kmask & ((1ull << lane) - 1ull))] = myi;
+        if (lane == 0) s_nkept = (int)__popcll(kmask);
+        __threadfence_block();
+      } else if (nmaxima > P.max_nmaxima && nmaxima <= 64 * FQ_SEL_REGS && P.max_nmaxima < 12) {
+        // up to FQ_SEL_REGS candidates per lane, held in registers as order-preserving keys (0 = empty:
+        // no finite double maps to 0): the arg-max rounds touch no memory until the winners are known
+        unsigned long long key[FQ_SEL_REGS];
+#pragma unroll
+        for (int r = 0; r < FQ_SEL_REGS; r++) {
+          const int k = lane + 64 * r;
+          key[r] = (k < nmaxima) ? double_sortable(cand_val[k] + 0.0) : 0ull;
+        }
+        unsigned long long rem_key = 0;   // lane r (< 12) keeps the key and candidate index of round r
+        int rem_k = 0;
+        for (int round = 0; round <= P.max_nmaxima; round++) {
+          unsigned long long bk = 0; int br = 0;
+#pragma unroll
+          for (int r = 0; r < FQ_SEL_REGS; r++)
+            if (key[r] > bk) { bk = key[r]; br = r; }
+          const unsigned long long mk = wave_max_u64(bk);
+          const unsigned long long who = __ballot(bk == mk && bk != 0ull);
+          const int src = (int)__ffsll((long long)who) - 1;
+          const int wr = __shfl(br, src, 64);
+          if (lane == src) {
+#pragma unroll
+            for (int r = 0; r < FQ_SEL_REGS; r++)
+              if (r == wr) key[r] = 0ull;   // removed
+          }
+          if (lane == round) { rem_key = mk; rem_k = src + 64 * wr; }
+        }
+        // threshold = key of the last round; keep the earlier winners that are strictly larger
+        const unsigned long long tk = (unsigned long long)(uint32_t)__shfl((int)(uint32_t)rem_key, P.max_nmaxima, 64) |
+                                      ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(rem_key >> 32), P.max_nmaxima, 64) << 32);
+        const bool kept = lane < P.max_nmaxima && rem_key > tk;
+        const unsigned long long kmask = __ballot(kept);
+        if (kept) s_maxidx[__popcll(kmask & ((1ull << lane) - 1ull))] = cand_idx[rem_k];
         if (lane == 0) s_nkept = (int)__popcll(kmask);
         __threadfence_block();
       } else if (nmaxima > P.max_nmaxima) {
