@@ -515,12 +515,12 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
     // The classes are independent (they only append to the quad list), so they run concurrently.  The
     // runtime multiplexes streams onto four hardware queues, and two streams on one queue serialise
     // (measured: the largest class started only when another one had finished), so exactly four streams
-    // are used and the launches go out longest first: class 4 | class 2 | class 1 then 3 | class 0 on
-    // the lane's own stream.  Small-cluster waves fill the CUs that the one-workgroup-per-CU big-cluster
-    // class leaves mostly idle.
+    // are used: class 4 | class 2 | class 3 then 1 | class 0 on the lane's own stream (large-LDS classes
+    // first: the saturating small-cluster class then runs last, next to the tail of class 4, instead of
+    // leaving two low-occupancy classes alone at the end).
     const bool fork = !D->env_fq_serial;
     if (fork) HIP_TRY(hipEventRecord(D->ev_fork[lane], s));
-    static const int order[NCLS] = {4, 2, 1, 3, 0};
+    static const int order[NCLS] = {4, 2, 3, 1, 0};
     static const int smap[NCLS] = {-1, 2, 1, 2, 0};   // class -> auxiliary stream (-1: the lane's stream)
     bool used[3] = {false, false, false};
     for (int oi = 0; oi < NCLS; oi++) {
