@@ -16,6 +16,18 @@ def main():
     for n, cnt, tot, avg, mn, mx in rows:
         short = n.split("(")[0][:70]
         lines.append("| %s | %d | %.3f | %.2f | %.2f | %.2f | %.1f |" % (short, cnt, tot / 1e6, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total))
+    # the roofline kernel is launched in two shapes by bench.py (160-frame threshold-only launches for the
+    # roofline figure, 256-frame launches inside the pipeline): list them separately so that the average
+    # of the roofline launches can be compared with bench.py's roofline.avg_launch_ms
+    if "grid_x" in cols:
+        rows2 = c.execute("select %s, grid_x, grid_y, grid_z, count(*), avg(end-start), min(end-start), max(end-start) from kernels "
+                          "where %s like '%%k_threshold%%' group by %s, grid_x, grid_y, grid_z order by 1, 2" %
+                          (name_col, name_col, name_col)).fetchall()
+        if rows2:
+            lines += ["", "Threshold launches by grid (work-items):", "", "| kernel | grid | calls | avg us | min us | max us |",
+                      "|---|---|---|---|---|---|"]
+            for n, gx, gy, gz, cnt, avg, mn, mx in rows2:
+                lines.append("| %s | %s x %s x %s | %d | %.2f | %.2f | %.2f |" % (n.split("(")[0][:40], gx, gy, gz, cnt, avg / 1e3, mn / 1e3, mx / 1e3))
     out = "\n".join(lines)
     print(out)
     if len(sys.argv) > 2:
