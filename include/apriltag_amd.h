@@ -59,10 +59,10 @@ typedef enum {
 #define AMDAT_FLAG_DETS_OVERFLOW 0x10u     /* detection list full */
 
 typedef enum {
-  AMDAT_TAG36H11 = 0,   /* ids 0..26 built in (see include/apriltag_amd_families.h) */
-  AMDAT_TAG25H9 = 1,
-  AMDAT_TAG16H5 = 2,
-  AMDAT_SYNTH36H11 = 3, /* stand-in 36-bit family, NOT the published tag36h11 table */
+  AMDAT_TAG36H11 = 0,   /* 587 codes (include/apriltag_amd_families.h states the provenance of every table) */
+  AMDAT_TAG25H9 = 1,    /* 35 codes */
+  AMDAT_TAG16H5 = 2,    /* 30 codes */
+  AMDAT_TAG36H10 = 3,   /* 2320 codes */
   AMDAT_CUSTOM0 = 4,    /* slots filled by amdAprilTagsRegisterFamily */
   AMDAT_CUSTOM1 = 5,
   AMDAT_ENUM_SIZE = 6
@@ -126,12 +126,14 @@ typedef struct {
   uint32_t max_hamming;        /* 2 */
   float decode_sharpening;     /* 0.25 */
   /* capacities per frame; 0 = defaults derived from the image size */
-  uint32_t max_points;         /* boundary points */
+  uint32_t max_points;         /* boundary points; default 1.25 per working pixel (hard bound: 2 per pixel) */
   uint32_t hash_slots;         /* power of two */
   uint32_t max_clusters;
   uint32_t max_quads;
   uint32_t max_detections;
   int32_t device;              /* HIP device ordinal, -1 = current */
+  float skew;                  /* K[0][1] of the pinhole matrix; 0 on the cuAprilTags-shaped path, the VPI path of
+                                * the reference passes it with its 2x3 intrinsics (src/apriltag_node.cpp:215-225) */
 } amdAprilTagsConfig_t;
 
 void amdAprilTagsDefaultConfig(amdAprilTagsConfig_t* cfg, uint32_t width, uint32_t height);
@@ -159,6 +161,9 @@ int amdAprilTagsDetectBatchEx(amdAprilTagsHandle handle, uint32_t n, const amdAp
                               const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics,
                               amdAprilTagsDetectionEx_t* dets_out, uint32_t* num_dets, uint32_t max_dets,
                               amdAprilTagsStream stream);
+
+/* Device memory the handle owns, in bytes. */
+int amdAprilTagsGetDeviceBytes(amdAprilTagsHandle handle, size_t* bytes);
 
 /* Status bits of the frames of the last submission (n values). */
 int amdAprilTagsGetFrameFlags(amdAprilTagsHandle handle, uint32_t* flags, uint32_t n);

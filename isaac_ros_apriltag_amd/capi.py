@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libapriltag_amd.so")
 
 NUM_STAGES = 12
-FAMILY_ENUM = {"tag36h11": 0, "tag25h9": 1, "tag16h5": 2, "synth36h11": 3}
+FAMILY_ENUM = {"tag36h11": 0, "tag25h9": 1, "tag16h5": 2, "tag36h10": 3}
 (DBG_GRAY, DBG_THRESH, DBG_LABEL, DBG_CSIZE, DBG_CLUSTERS, DBG_POINTS, DBG_QUADS, DBG_COUNTS) = range(8)
 
 STATUS = {0: "AMDAT_SUCCESS", 1: "AMDAT_INVALID_ARGUMENT", 2: "AMDAT_UNSUPPORTED", 3: "AMDAT_HIP_ERROR",
@@ -49,7 +49,7 @@ class Config(C.Structure):
                 ("tag_size", C.c_float), ("max_batch", C.c_uint32), ("refine_edges", C.c_uint32),
                 ("max_hamming", C.c_uint32), ("decode_sharpening", C.c_float), ("max_points", C.c_uint32),
                 ("hash_slots", C.c_uint32), ("max_clusters", C.c_uint32), ("max_quads", C.c_uint32),
-                ("max_detections", C.c_uint32), ("device", C.c_int32)]
+                ("max_detections", C.c_uint32), ("device", C.c_int32), ("skew", C.c_float)]
 
 
 # every symbol include/apriltag_amd.h declares
@@ -59,7 +59,8 @@ EXPORTS = ["amdAprilTagsDefaultConfig", "amdCreateAprilTagsDetector", "amdCreate
            "amdAprilTagsFamilyInfo", "amdAprilTagsFamilyFromName", "amdAprilTagsStageName",
            "amdAprilTagsSetProfiling", "amdAprilTagsGetStageMs", "amdAprilTagsThresholdOnly",
            "amdAprilTagsDebugCopy", "amdAprilTagsDebugMath", "amdAprilTagsDeviceAlloc", "amdAprilTagsDeviceFree",
-           "amdAprilTagsCopyToDevice", "amdAprilTagsResizeMono8", "amdAprilTagsRectifyMono8"]
+           "amdAprilTagsCopyToDevice", "amdAprilTagsResizeMono8", "amdAprilTagsRectifyMono8",
+           "amdAprilTagsGetDeviceBytes"]
 
 _lib = None
 
@@ -105,6 +106,7 @@ def lib():
                                           C.c_uint32, H]
     L.amdAprilTagsRectifyMono8.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32,
                                            C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), H]
+    L.amdAprilTagsGetDeviceBytes.argtypes = [H, C.POINTER(C.c_size_t)]
     L.amdAprilTagsDebugMath.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     for name in EXPORTS:
         fn = getattr(L, name)

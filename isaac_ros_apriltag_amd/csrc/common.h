@@ -16,6 +16,7 @@ struct FrameDesc {
   uint32_t pitch;
   uint32_t pad;
   double fx, fy, cx, cy;
+  double skew;
 };
 
 // Per-frame counters (one struct per batch slot), zeroed at the start of every submission.

@@ -57,7 +57,7 @@ std::mutex g_fam_mutex;
 void init_families() {
   g_families[AMDAT_TAG36H11].name = "tag36h11";
   g_families[AMDAT_TAG36H11].d = 6;
-  g_families[AMDAT_TAG36H11].ncodes = APRILTAG_AMD_TAG36H11_VALIDATED;
+  g_families[AMDAT_TAG36H11].ncodes = APRILTAG_AMD_TAG36H11_NCODES;
   g_families[AMDAT_TAG36H11].codes = apriltag_amd_tag36h11_codes;
   g_families[AMDAT_TAG25H9].name = "tag25h9";
   g_families[AMDAT_TAG25H9].d = 5;
@@ -67,15 +67,31 @@ void init_families() {
   g_families[AMDAT_TAG16H5].d = 4;
   g_families[AMDAT_TAG16H5].ncodes = APRILTAG_AMD_TAG16H5_NCODES;
   g_families[AMDAT_TAG16H5].codes = apriltag_amd_tag16h5_codes;
-  g_families[AMDAT_SYNTH36H11].name = "synth36h11";
-  g_families[AMDAT_SYNTH36H11].d = 6;
-  g_families[AMDAT_SYNTH36H11].ncodes = APRILTAG_AMD_SYNTH36H11_NCODES;
-  g_families[AMDAT_SYNTH36H11].codes = apriltag_amd_synth36h11_codes;
+#ifdef APRILTAG_AMD_TAG36H10_NCODES
+  g_families[AMDAT_TAG36H10].name = "tag36h10";
+  g_families[AMDAT_TAG36H10].d = 6;
+  g_families[AMDAT_TAG36H10].ncodes = APRILTAG_AMD_TAG36H10_NCODES;
+  g_families[AMDAT_TAG36H10].codes = apriltag_amd_tag36h10_codes;
+#endif
 }
 
 const char* kStageNames[AMDAT_NUM_STAGES] = {"upload_clear", "threshold", "cc_local",  "cc_border",
                                              "cc_sizes",   "points",    "cluster_select", "scatter",
                                              "fit_quads",    "decode",    "reconcile", "download"};
+
+// Makes `device` current for the scope of one C-ABI call and restores the caller's device afterwards, so
+// that a multi-GPU host (one handle per device in one process) never finds its current device changed.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) ok = hipSetDevice(device) == hipSuccess; else prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 uint32_t next_pow2(uint32_t v) {
   uint32_t p = 1;
@@ -84,16 +100,26 @@ uint32_t next_pow2(uint32_t v) {
 }
 }  // namespace
 
+// One size class of the quad fit: workgroup size, LDS key capacity, cluster sizes (lo, hi], persistent grid,
+// scratch slot size (points) and its slice of the work array.
+struct FqClass {
+  int nt, sort_cap, lo, hi;
+  unsigned grid;
+  int slot_cap;
+  int pop;                                // clusters taken from the work list per atomic
+  double* d_lf = nullptr;                 // grid x slot_cap x 6 doubles
+};
+
 struct amdAprilTagsDetector_st {
   amdAprilTagsConfig_t cfg;
   DetParams P;
   int device = 0;
+  int num_cus = 256;
+  size_t device_bytes = 0;
   hipStream_t own_stream = nullptr;
-  // Inside a lane the size classes of the quad fit fork to auxiliary streams and join before decode.
-  // A second lane exists for the opt-in half-batch experiment (AMDAT_SPLIT, see run_batch).
-  hipStream_t lane_stream = nullptr;  // main stream of lane 1 (lane 0 uses the submission stream)
-  hipStream_t aux_stream[2][4] = {};
-  hipEvent_t ev_fork[2] = {}, ev_join[2][4] = {}, ev_lane_begin = nullptr, ev_lane_end = nullptr;
+  // the size classes of the quad fit fork to auxiliary streams and join before decode
+  hipStream_t aux_stream[3] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {};
   // device buffers
   uint8_t* d_gray = nullptr;
   uint8_t* d_thr = nullptr;
@@ -107,10 +133,10 @@ struct amdAprilTagsDetector_st {
   uint32_t* d_rank = nullptr;
   uint32_t* d_pts = nullptr;
   ClusterRec* d_clusters = nullptr;
-  unsigned long long* d_keys = nullptr;
-  double* d_lf = nullptr;
-  double* d_errs_a = nullptr;
-  double* d_errs_b = nullptr;
+  uint32_t* d_work = nullptr;        // work lists of the quad fit (all classes, FqWorkLayout)
+  uint32_t* d_workctl = nullptr;     // [0..7] items per class, [8..15] pop cursors
+  unsigned long long* d_keys_scr = nullptr;  // only when a cluster can exceed the LDS key array (large images)
+  double* d_errs_scr = nullptr;
   QuadRec* d_quads = nullptr;
   DetRec* d_dets = nullptr;
   DetRec* d_out = nullptr;
@@ -118,7 +144,9 @@ struct amdAprilTagsDetector_st {
   FrameCounters* d_counters = nullptr;
   FrameDesc* d_frames = nullptr;
   uint64_t* d_codes[AT_MAX_FAMILIES] = {nullptr, nullptr, nullptr, nullptr};
-  unsigned long long* d_fqprof = nullptr;  // optional per-phase cycle counters of k_fit_quads (profiling on)
+  unsigned long long* d_fqprof = nullptr;  // per-phase cycle counters of k_fit_quads (-DAMDAT_FQ_PROFILE builds only)
+  FqClass cls[FQ_NCLS];
+  FqWorkLayout work_layout;
   // pinned host buffers
   FrameDesc* h_frames = nullptr;
   FrameCounters* h_counters = nullptr;
@@ -127,9 +155,6 @@ struct amdAprilTagsDetector_st {
   bool profiling = false;
   bool fq_counters = false;  // per-phase cycle counters inside k_fit_quads (profiling level 2; perturbs timing)
   bool fq_attr_set = false;
-  // tuning overrides read once at creation (AMDAT_FQ_CLASSES, AMDAT_FQ_SERIAL, AMDAT_SPLIT)
-  const char* env_fq_classes = nullptr;
-  bool env_fq_serial = false, env_split = false;
   hipEvent_t ev[AMDAT_NUM_STAGES + 1] = {};
   float stage_ms[AMDAT_NUM_STAGES] = {};
   uint32_t last_n = 0;
@@ -214,8 +239,12 @@ int amdAprilTagsFamilyInfo(amdAprilTagsFamily family, const char** name, uint32_
 int amdAprilTagsFamilyFromName(const char* name) {
   std::call_once(g_fam_once, init_families);
   if (!name) return -1;
-  for (int i = 0; i < AMDAT_ENUM_SIZE; i++)
+  // registered tables take precedence over a built-in of the same name
+  static const int scan[AMDAT_ENUM_SIZE] = {AMDAT_CUSTOM0, AMDAT_CUSTOM1, AMDAT_TAG36H11, AMDAT_TAG25H9, AMDAT_TAG16H5, AMDAT_TAG36H10};
+  for (int k = 0; k < AMDAT_ENUM_SIZE; k++) {
+    const int i = scan[k];
     if (g_families[i].codes && g_families[i].name && !strcmp(g_families[i].name, name)) return i;
+  }
   return -1;
 }
 
@@ -224,7 +253,8 @@ const char* amdAprilTagsStageName(uint32_t stage) { return stage < AMDAT_NUM_STA
 static void free_all(amdAprilTagsDetector_st* D) {
   hipFree(D->d_gray); hipFree(D->d_thr); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_roots); hipFree(D->d_hkeys);
   hipFree(D->d_hcnt); hipFree(D->d_hoff); hipFree(D->d_stage); hipFree(D->d_rank); hipFree(D->d_pts); hipFree(D->d_clusters);
-  hipFree(D->d_keys); hipFree(D->d_lf); hipFree(D->d_errs_a); hipFree(D->d_errs_b); hipFree(D->d_quads);
+  hipFree(D->d_work); hipFree(D->d_workctl); hipFree(D->d_keys_scr); hipFree(D->d_errs_scr); hipFree(D->d_quads);
+  for (auto& c : D->cls) hipFree(c.d_lf);
   hipFree(D->d_fqprof);
   hipFree(D->d_dets); hipFree(D->d_out); hipFree(D->d_order); hipFree(D->d_counters); hipFree(D->d_frames);
   for (int i = 0; i < AT_MAX_FAMILIES; i++) hipFree(D->d_codes[i]);
@@ -233,12 +263,9 @@ static void free_all(amdAprilTagsDetector_st* D) {
   if (D->h_out) hipHostFree(D->h_out);
   for (auto& e : D->ev) if (e) hipEventDestroy(e);
   if (D->own_stream) hipStreamDestroy(D->own_stream);
-  for (auto& l : D->aux_stream) for (auto& a : l) if (a) hipStreamDestroy(a);
-  for (auto& e : D->ev_fork) if (e) hipEventDestroy(e);
-  for (auto& l : D->ev_join) for (auto& e : l) if (e) hipEventDestroy(e);
-  if (D->lane_stream) hipStreamDestroy(D->lane_stream);
-  if (D->ev_lane_begin) hipEventDestroy(D->ev_lane_begin);
-  if (D->ev_lane_end) hipEventDestroy(D->ev_lane_end);
+  for (auto& a : D->aux_stream) if (a) hipStreamDestroy(a);
+  if (D->ev_fork) hipEventDestroy(D->ev_fork);
+  for (auto& e : D->ev_join) if (e) hipEventDestroy(e);
 }
 
 int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsConfig_t* cfg_in) {
@@ -247,7 +274,10 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   *handle = nullptr;
   amdAprilTagsConfig_t cfg = *cfg_in;
   if (cfg.width == 0 || cfg.height == 0 || cfg.max_batch == 0 || cfg.decimate == 0) return AMDAT_INVALID_ARGUMENT;
+  if (cfg.max_batch > 65535) return AMDAT_BATCH_TOO_LARGE;   // a work item carries the batch slot in 16 bits
   if (cfg.tile_size != 4) return AMDAT_UNSUPPORTED;
+  if (cfg.decimate > 4) return AMDAT_UNSUPPORTED;     // the threshold loader is instantiated for 1..4
+  if (cfg.max_hamming > 3) return AMDAT_INVALID_ARGUMENT;  // AprilRobotics' own limit for the code search
   if (cfg.num_families < 1 || cfg.num_families > AT_MAX_FAMILIES) return AMDAT_INVALID_ARGUMENT;
   for (uint32_t i = 0; i < cfg.num_families; i++) {
     if ((int)cfg.families[i] < 0 || cfg.families[i] >= AMDAT_ENUM_SIZE || !g_families[cfg.families[i]].codes)
@@ -259,13 +289,15 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   auto* D = new (std::nothrow) amdAprilTagsDetector_st();
   if (!D) return AMDAT_OUT_OF_MEMORY;
   D->cfg = cfg;
-  D->env_fq_classes = getenv("AMDAT_FQ_CLASSES");
-  D->env_fq_serial = getenv("AMDAT_FQ_SERIAL") != nullptr;
-  D->env_split = getenv("AMDAT_SPLIT") != nullptr;
-  if (cfg.device >= 0) {
-    if (hipSetDevice(cfg.device) != hipSuccess) { delete D; return AMDAT_HIP_ERROR; }
+  int caller_device = -1;
+  if (hipGetDevice(&caller_device) != hipSuccess) { delete D; return AMDAT_HIP_ERROR; }
+  D->device = cfg.device >= 0 ? cfg.device : caller_device;
+  DeviceGuard guard(D->device);
+  if (!guard.ok) { delete D; return AMDAT_HIP_ERROR; }
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, D->device) == hipSuccess && prop.multiProcessorCount > 0) D->num_cus = prop.multiProcessorCount;
   }
-  if (hipGetDevice(&D->device) != hipSuccess) { delete D; return AMDAT_HIP_ERROR; }
 
   DetParams& P = D->P;
   memset(&P, 0, sizeof(P));
@@ -297,18 +329,55 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   if (min_tag_width < 3) min_tag_width = 3;
   P.min_tag_width = min_tag_width;
   const uint32_t npx = (uint32_t)W * (uint32_t)H;
-  P.pcap = cfg.max_points ? cfg.max_points : 2u * npx;
+  // Boundary points per frame: the hard bound is 2 per pixel; frames that binarise completely (noise on every
+  // 4x4 tile) measure ~0.85 per pixel, so the default capacity is 1.25 per pixel and an overflow is reported
+  // per frame (AMDAT_FLAG_POINTS_OVERFLOW), never silent.  max_points = 2 * pixels restores the hard bound.
+  P.pcap = cfg.max_points ? cfg.max_points : npx + npx / 4;
   P.hcap = cfg.hash_slots ? next_pow2(cfg.hash_slots) : next_pow2(npx / 8 > 4096 ? npx / 8 : 4096);
   if (P.hcap < 256) P.hcap = 256;
   { uint32_t lg = 0; while ((1u << lg) < P.hcap) lg++; P.hshift = 64 - lg; }
   P.ccap = cfg.max_clusters ? cfg.max_clusters : (P.hcap < 65536 ? P.hcap : 65536);
-  P.qcap = cfg.max_quads ? cfg.max_quads : P.ccap;   // a quad needs its own kept cluster
+  if (P.ccap > 65536) P.ccap = 65536;                 // a work item carries the cluster index in 16 bits
+  P.qcap = cfg.max_quads ? cfg.max_quads : (P.ccap < 16384 ? P.ccap : 16384);
   P.dcap = cfg.max_detections ? cfg.max_detections : 1024;
   if (P.dcap > 65535) P.dcap = 65535;
 
   const size_t B = cfg.max_batch;
+  // ---- size classes of the quad fit ------------------------------------------------------------------
+  // one wave per small cluster, bigger workgroups and LDS key arrays above; persistent grids sized to the
+  // chip (CUs x workgroups that fit one CU) but not beyond what a submission of B frames can feed
+  {
+    const unsigned cus = (unsigned)D->num_cus;
+    auto minu = [](unsigned a, unsigned b) { return a < b ? a : b; };
+    FqClass* c = D->cls;
+    c[0] = {64, 256, 0, 256, minu(16u * cus, 4096u * (unsigned)B), 256, 16};
+    c[1] = {128, 1024, 256, 1024, minu(8u * cus, 1024u * (unsigned)B), 1024, 8};
+    c[2] = {256, 4096, 1024, 4096, minu(4u * cus, 256u * (unsigned)B), 4096, 2};
+    c[3] = {256, 8192, 4096, 8192, minu(2u * cus, 64u * (unsigned)B), 8192, 1};
+    c[4] = {512, 16384, 8192, 0x7FFFFFFF, minu(cus, 16u * (unsigned)B), P.max_cluster_points, 1};
+    // the largest cluster a frame can hold is max_cluster_points = 3(2W+2H): when that is at most 18432
+    // points (1080p: 18000) the last class keeps all of them in LDS (144 KB of keys + the table region
+    // still fit the 160 KB of a CU) instead of sorting the rare >16384-point cluster in global scratch
+    if (P.max_cluster_points > 16384 && P.max_cluster_points <= 18432) c[4].sort_cap = (P.max_cluster_points + 63) & ~63;
+    if (c[4].slot_cap < 8193) c[4].slot_cap = 8193;
+    uint32_t off = 0;
+    for (int k = 0; k < FQ_NCLS; k++) {
+      D->work_layout.lo[k] = c[k].lo < 23 ? 23 : c[k].lo;
+      D->work_layout.hi[k] = c[k].hi;
+      const uint32_t per_frame = P.pcap / (uint32_t)(D->work_layout.lo[k] + 1) + 1;
+      const uint64_t cap = (uint64_t)B * (per_frame < P.ccap ? per_frame : P.ccap);
+      D->work_layout.off[k] = off;
+      D->work_layout.cap[k] = (uint32_t)(cap > 0x7FFFFFFFull ? 0x7FFFFFFFull : cap);
+      off += D->work_layout.cap[k];
+    }
+  }
+
   bool ok = true;
-  auto alloc = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes ? bytes : 16) != hipSuccess) ok = false; };
+  auto alloc = [&](void** p, size_t bytes) {
+    if (!bytes) bytes = 16;
+    if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false;
+    if (ok) D->device_bytes += bytes;
+  };
   if (P.decimate > 1) alloc((void**)&D->d_gray, B * (size_t)H * P.WS);
   alloc((void**)&D->d_thr, B * (size_t)H * P.WS);
   alloc((void**)&D->d_label, B * (size_t)npx * 4);
@@ -321,16 +390,22 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   alloc((void**)&D->d_rank, B * (size_t)P.pcap * 4);
   alloc((void**)&D->d_pts, B * (size_t)P.pcap * 4);
   alloc((void**)&D->d_clusters, B * (size_t)P.ccap * sizeof(ClusterRec));
-  alloc((void**)&D->d_keys, B * (size_t)P.pcap * 8);
-  alloc((void**)&D->d_lf, B * (size_t)P.pcap * 48);
-  alloc((void**)&D->d_errs_a, B * (size_t)P.pcap * 8);
-  alloc((void**)&D->d_errs_b, B * (size_t)P.pcap * 8);
+  alloc((void**)&D->d_work, ((size_t)D->work_layout.off[FQ_NCLS - 1] + D->work_layout.cap[FQ_NCLS - 1]) * 4);
+  alloc((void**)&D->d_workctl, 16 * 4);
+  for (int k = 0; k < FQ_NCLS; k++)
+    if (P.max_cluster_points > D->cls[k].lo) alloc((void**)&D->cls[k].d_lf, (size_t)D->cls[k].grid * D->cls[k].slot_cap * 48);
+  if (D->cls[FQ_NCLS - 1].slot_cap > D->cls[FQ_NCLS - 1].sort_cap) {   // clusters beyond the LDS key array exist
+    const FqClass& c = D->cls[FQ_NCLS - 1];
+    alloc((void**)&D->d_keys_scr, (size_t)c.grid * c.slot_cap * 8);
+    alloc((void**)&D->d_errs_scr, (size_t)c.grid * c.slot_cap * 16);
+  }
   alloc((void**)&D->d_quads, B * (size_t)P.qcap * sizeof(QuadRec));
   alloc((void**)&D->d_dets, B * (size_t)P.dcap * sizeof(DetRec));
   alloc((void**)&D->d_out, B * (size_t)P.dcap * sizeof(DetRec));
   alloc((void**)&D->d_order, B * (size_t)P.dcap * 2);
   alloc((void**)&D->d_counters, B * sizeof(FrameCounters));
   alloc((void**)&D->d_frames, B * sizeof(FrameDesc));
+  alloc((void**)&D->d_fqprof, 64 * 8);
   for (int i = 0; ok && i < P.nfam; i++) {
     const FamilyHost& f = g_families[cfg.families[i]];
     alloc((void**)&D->d_codes[i], (size_t)f.ncodes * 8);
@@ -342,12 +417,9 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   if (ok && hipHostMalloc((void**)&D->h_out, B * (size_t)P.dcap * sizeof(DetRec)) != hipSuccess) ok = false;
   if (ok && hipStreamCreateWithFlags(&D->own_stream, hipStreamNonBlocking) != hipSuccess) ok = false;
   for (auto& e : D->ev) if (ok && hipEventCreate(&e) != hipSuccess) ok = false;
-  for (auto& l : D->aux_stream) for (auto& a : l) if (ok && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) ok = false;
-  for (auto& e : D->ev_fork) if (ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
-  for (auto& l : D->ev_join) for (auto& e : l) if (ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
-  if (ok && hipStreamCreateWithFlags(&D->lane_stream, hipStreamNonBlocking) != hipSuccess) ok = false;
-  if (ok && hipEventCreateWithFlags(&D->ev_lane_begin, hipEventDisableTiming) != hipSuccess) ok = false;
-  if (ok && hipEventCreateWithFlags(&D->ev_lane_end, hipEventDisableTiming) != hipSuccess) ok = false;
+  for (auto& a : D->aux_stream) if (ok && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) ok = false;
+  if (ok && hipEventCreateWithFlags(&D->ev_fork, hipEventDisableTiming) != hipSuccess) ok = false;
+  for (auto& e : D->ev_join) if (ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
   if (ok && D->d_thr) {
     // the padding columns of the working images are read by vector loads; define them once
     if (hipMemset(D->d_thr, 127, B * (size_t)H * P.WS) != hipSuccess) ok = false;
@@ -376,10 +448,16 @@ int amdCreateAprilTagsDetector(amdAprilTagsHandle* handle, uint32_t img_width, u
 
 int amdAprilTagsDestroy(amdAprilTagsHandle handle) {
   if (!handle) return AMDAT_INVALID_ARGUMENT;
-  hipSetDevice(handle->device);
+  DeviceGuard guard(handle->device);
   hipDeviceSynchronize();
   free_all(handle);
   delete handle;
+  return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsGetDeviceBytes(amdAprilTagsHandle handle, size_t* bytes) {
+  if (!handle || !bytes) return AMDAT_INVALID_ARGUMENT;
+  *bytes = handle->device_bytes;
   return AMDAT_SUCCESS;
 }
 
@@ -416,6 +494,7 @@ static void fill_frames(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTa
     D->h_frames[i].pad = 0;
     D->h_frames[i].fx = (double)k.fx; D->h_frames[i].fy = (double)k.fy;
     D->h_frames[i].cx = (double)k.cx; D->h_frames[i].cy = (double)k.cy;
+    D->h_frames[i].skew = (double)D->cfg.skew;
   }
 }
 
@@ -438,15 +517,11 @@ static void launch_threshold(amdAprilTagsDetector_st* D, const DetParams& P, uin
 #undef TH_LAUNCH
 }
 
-struct FqClass { int nt, cap, lo, hi; unsigned gx; };
-
-// Issues the whole stage sequence for batch slots [frame0, frame0 + n) on stream s.  `lane` selects the
-// auxiliary streams/events the quad-fit size classes fork to.  mark() is called between stages (event
-// timing of lane 0 when profiling).
-static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0, uint32_t n, uint32_t ostride, hipStream_t s,
-                          const std::function<void()>& mark) {
+// Issues the whole stage sequence for batch slots [0, n) on stream s.  mark() is called between stages
+// (event timing when profiling).
+static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s, const std::function<void()>& mark) {
   DetParams P = D->P;
-  P.frame0 = (int)frame0;
+  P.frame0 = 0;
   launch_threshold(D, P, n, s);
   mark();
   hipLaunchKernelGGL(k_cc_local, dim3((P.W + CC_T - 1) / CC_T, (P.H + CC_T - 1) / CC_T, n), dim3(256), 0, s, D->d_thr,
@@ -464,6 +539,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
     if (gr < 1) gr = 1;
     if (gr > 1024) gr = 1024;
     hipLaunchKernelGGL(k_cc_sizes, dim3(gr, 1, n), dim3(256), 0, s, D->d_label, D->d_csize, D->d_roots, D->d_counters, P);
+    hipLaunchKernelGGL(k_cc_resolve, dim3(gr, 1, n), dim3(256), 0, s, D->d_label, D->d_csize, D->d_roots, D->d_counters, P);
   }
   mark();
   hipLaunchKernelGGL(k_points, dim3((P.W + PT_TW - 1) / PT_TW, (P.H + PT_TH - 1) / PT_TH, n), dim3(256), 0, s, D->d_thr,
@@ -471,6 +547,12 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
   mark();
   hipLaunchKernelGGL(k_cluster_select, dim3((P.hcap + 1023) / 1024, 1, n), dim3(1024), 0, s, D->d_hkeys, D->d_hcnt, D->d_hoff,
                      D->d_clusters, D->d_counters, P);
+  {
+    unsigned gw = (P.ccap + 255) / 256;
+    if (gw > 16) gw = 16;
+    hipLaunchKernelGGL(k_worklist, dim3(gw, 1, n), dim3(256), 0, s, D->d_clusters, D->d_counters, D->d_work, D->d_workctl,
+                       D->work_layout, P);
+  }
   mark();
   {
     unsigned gx = (P.pcap + 255) / 256;
@@ -479,32 +561,8 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
   }
   mark();
   {
-    // five size classes: one wave per small cluster, bigger workgroups and LDS key arrays above
-    auto clampu = [](unsigned v, unsigned a, unsigned b) { return v < a ? a : (v > b ? b : v); };
-    constexpr int NCLS = 5;
-    FqClass cls[NCLS] = {{64, 256, 0, 256, clampu(32768u / n, 128u, 4096u)},
-                         {128, 1024, 256, 1024, clampu(16384u / n, 64u, 2048u)},
-                         {256, 4096, 1024, 4096, clampu(2048u / n, 32u, 512u)},
-                         {256, 8192, 4096, 8192, clampu(1024u / n, 16u, 256u)},
-                         {512, 16384, 8192, 0x7FFFFFFF, clampu(512u / n, 8u, 256u)}};
-    // the largest cluster a frame can hold is max_cluster_points = 3(2W+2H): when that is at most 18432
-    // points (1080p: 18000) the last class keeps all of them in LDS (144 KB of keys + the table region
-    // still fit the 160 KB of a CU) instead of sorting the rare >16384-point cluster in global scratch
-    if (P.max_cluster_points > 16384 && P.max_cluster_points <= 18432) cls[4].cap = (P.max_cluster_points + 63) & ~63;
-    if (const char* ov = D->env_fq_classes) {  // tuning override: "nt:cap:gxbudget" x 5 (size bounds follow cap)
-      int nt[NCLS], cap[NCLS], bud[NCLS];
-      if (sscanf(ov, "%d:%d:%d,%d:%d:%d,%d:%d:%d,%d:%d:%d,%d:%d:%d", &nt[0], &cap[0], &bud[0], &nt[1], &cap[1], &bud[1], &nt[2],
-                 &cap[2], &bud[2], &nt[3], &cap[3], &bud[3], &nt[4], &cap[4], &bud[4]) == 15) {
-        int lo = 0;
-        for (int c = 0; c < NCLS; c++) {
-          cls[c].nt = nt[c]; cls[c].cap = cap[c]; cls[c].lo = lo; cls[c].hi = (c == NCLS - 1) ? 0x7FFFFFFF : cap[c];
-          cls[c].gx = clampu((unsigned)bud[c] / n, 8u, 4096u);
-          lo = cap[c];
-        }
-      }
-    }
     // keys | pair-table region
-    auto lds_bytes = [](const FqClass& c) { return (size_t)c.cap * 8 + (size_t)FQ_TABLE_DOUBLES * 8; };
+    auto lds_bytes = [](const FqClass& c) { return (size_t)c.sort_cap * 8 + (size_t)FQ_TABLE_DOUBLES * 8; };
     if (!D->fq_attr_set) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 157000));
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150000));
@@ -515,39 +573,39 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
     // The classes are independent (they only append to the quad list), so they run concurrently.  The
     // runtime multiplexes streams onto four hardware queues, and two streams on one queue serialise
     // (measured: the largest class started only when another one had finished), so exactly four streams
-    // are used: class 4 | class 2 | class 3 then 1 | class 0 on the lane's own stream (large-LDS classes
-    // first: the saturating small-cluster class then runs last, next to the tail of class 4, instead of
-    // leaving two low-occupancy classes alone at the end).
-    const bool fork = !D->env_fq_serial;
-    if (fork) HIP_TRY(hipEventRecord(D->ev_fork[lane], s));
-    static const int order[NCLS] = {4, 2, 3, 1, 0};
-    static const int smap[NCLS] = {-1, 2, 1, 2, 0};   // class -> auxiliary stream (-1: the lane's stream)
+    // are used: class 4 | class 2 | class 3 then 1 | class 0 on the submission stream (large-LDS classes
+    // first: the saturating small-cluster class then runs last, next to the tail of class 4).
+    HIP_TRY(hipEventRecord(D->ev_fork, s));
+    static const int order[FQ_NCLS] = {4, 2, 3, 1, 0};
+    static const int smap[FQ_NCLS] = {-1, 2, 1, 2, 0};   // class -> auxiliary stream (-1: the submission stream)
     bool used[3] = {false, false, false};
-    for (int oi = 0; oi < NCLS; oi++) {
+    // a submission of n < max_batch frames needs no more workgroups than its share of the persistent grid
+    for (int oi = 0; oi < FQ_NCLS; oi++) {
       const int c = order[oi];
-      if (P.max_cluster_points <= cls[c].lo) continue;
-      const dim3 grid(cls[c].gx, n);
-      const size_t lds = lds_bytes(cls[c]);
+      const FqClass& cl = D->cls[c];
+      if (P.max_cluster_points <= cl.lo || !cl.d_lf) continue;
+      const dim3 grid(cl.grid);
+      const size_t lds = lds_bytes(cl);
       hipStream_t sc = s;
-      if (fork && smap[c] >= 0) {
-        sc = D->aux_stream[lane][smap[c]];
-        if (!used[smap[c]]) HIP_TRY(hipStreamWaitEvent(sc, D->ev_fork[lane], 0));
+      if (smap[c] >= 0) {
+        sc = D->aux_stream[smap[c]];
+        if (!used[smap[c]]) HIP_TRY(hipStreamWaitEvent(sc, D->ev_fork, 0));
         used[smap[c]] = true;
       }
-#define FQ_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_keys, D->d_lf, D->d_errs_a, D->d_errs_b, D->d_quads, \
-                D->d_counters, ((D->fq_counters && D->d_fqprof) ? D->d_fqprof + 8 * c : nullptr), cls[c].cap, cls[c].lo, cls[c].hi, P
-      if (cls[c].nt == 64) hipLaunchKernelGGL(k_fit_quads<64>, grid, dim3(64), lds, sc, FQ_ARGS);
-      else if (cls[c].nt == 128) hipLaunchKernelGGL(k_fit_quads<128>, grid, dim3(128), lds, sc, FQ_ARGS);
-      else if (cls[c].nt == 256) hipLaunchKernelGGL(k_fit_quads<256>, grid, dim3(256), lds, sc, FQ_ARGS);
+      const bool big = c == FQ_NCLS - 1;
+#define FQ_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work + D->work_layout.off[c], D->d_workctl + c,                   \
+                D->work_layout.cap[c], D->d_workctl + 8 + c, cl.d_lf, (big ? D->d_keys_scr : nullptr), (big ? D->d_errs_scr : nullptr), \
+                D->d_quads, D->d_counters, (D->fq_counters ? D->d_fqprof + 8 * c : nullptr), cl.sort_cap, cl.slot_cap, cl.pop, P
+      if (cl.nt == 64) hipLaunchKernelGGL(k_fit_quads<64>, grid, dim3(64), lds, sc, FQ_ARGS);
+      else if (cl.nt == 128) hipLaunchKernelGGL(k_fit_quads<128>, grid, dim3(128), lds, sc, FQ_ARGS);
+      else if (cl.nt == 256) hipLaunchKernelGGL(k_fit_quads<256>, grid, dim3(256), lds, sc, FQ_ARGS);
       else hipLaunchKernelGGL(k_fit_quads<512>, grid, dim3(512), lds, sc, FQ_ARGS);
 #undef FQ_ARGS
     }
-    if (fork) {
-      for (int a = 0; a < 3; a++) {
-        if (!used[a]) continue;
-        HIP_TRY(hipEventRecord(D->ev_join[lane][a], D->aux_stream[lane][a]));
-        HIP_TRY(hipStreamWaitEvent(s, D->ev_join[lane][a], 0));
-      }
+    for (int a = 0; a < 3; a++) {
+      if (!used[a]) continue;
+      HIP_TRY(hipEventRecord(D->ev_join[a], D->aux_stream[a]));
+      HIP_TRY(hipStreamWaitEvent(s, D->ev_join[a], 0));
     }
   }
   mark();
@@ -560,7 +618,6 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
   mark();
   hipLaunchKernelGGL(k_reconcile, dim3(n), dim3(64), 0, s, D->d_frames, D->d_dets, D->d_out, D->d_counters, D->d_order, P);
   mark();
-  (void)ostride;
   return AMDAT_SUCCESS;
 }
 
@@ -568,42 +625,25 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, int lane, uint32_t frame0,
 static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images,
                      const amdAprilTagsCameraIntrinsics_t* intr, uint32_t ostride, hipStream_t s) {
   const DetParams& P = D->P;
-  HIP_TRY(hipSetDevice(D->device));
+  DeviceGuard guard(D->device);
+  if (!guard.ok) return AMDAT_HIP_ERROR;
   fill_frames(D, n, images, intr);
   D->last_n = n;
   const bool prof = D->profiling;
   int evi = 0;
   const std::function<void()> mark = [&]() { if (prof) hipEventRecord(D->ev[evi++], s); };
-  const std::function<void()> nomark = []() {};
 
   mark();
   HIP_TRY(hipMemcpyAsync(D->d_frames, D->h_frames, n * sizeof(FrameDesc), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(D->d_counters, 0, n * sizeof(FrameCounters), s));
+  HIP_TRY(hipMemsetAsync(D->d_workctl, 0, 16 * 4, s));
   HIP_TRY(hipMemsetAsync(D->d_hkeys, 0xFF, (size_t)n * P.hcap * 8, s));
   HIP_TRY(hipMemsetAsync(D->d_hcnt, 0, (size_t)n * P.hcap * 4, s));
-  if (D->fq_counters && !D->d_fqprof) {
-    if (hipMalloc((void**)&D->d_fqprof, 64 * 8) != hipSuccess) D->d_fqprof = nullptr;
-  }
-  if (D->fq_counters && D->d_fqprof) HIP_TRY(hipMemsetAsync(D->d_fqprof, 0, 64 * 8, s));
+  if (D->fq_counters) HIP_TRY(hipMemsetAsync(D->d_fqprof, 0, 64 * 8, s));
   mark();
-  // Opt-in experiment (AMDAT_SPLIT=1): run a large submission as two concurrent halves so that stages
-  // with different bottlenecks overlap.  Measured SLOWER on MI355X (2.95k vs 3.30k frames/s at sigma 2,
-  // 21k vs 26k noise-free): every kernel already fills the chip at 64 frames and halving its grid costs
-  // more than the overlap returns, so the default is one lane.
-  const bool split = !prof && n >= 16 && D->env_split;
-  if (!split) {
-    int rc = issue_pipeline(D, 0, 0, n, ostride, s, mark);
+  {
+    const int rc = issue_pipeline(D, n, s, mark);
     if (rc) return rc;
-  } else {
-    const uint32_t n0 = n / 2, n1 = n - n0;
-    HIP_TRY(hipEventRecord(D->ev_lane_begin, s));
-    HIP_TRY(hipStreamWaitEvent(D->lane_stream, D->ev_lane_begin, 0));
-    int rc = issue_pipeline(D, 0, 0, n0, ostride, s, nomark);
-    if (rc) return rc;
-    rc = issue_pipeline(D, 1, n0, n1, ostride, D->lane_stream, nomark);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(D->ev_lane_end, D->lane_stream));
-    HIP_TRY(hipStreamWaitEvent(s, D->ev_lane_end, 0));
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(D->h_counters, D->d_counters, n * sizeof(FrameCounters), hipMemcpyDeviceToHost, s));
@@ -695,7 +735,8 @@ int amdAprilTagsThresholdOnly(amdAprilTagsHandle handle, uint32_t n, const amdAp
   int rc = check_images(handle, n, images);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : handle->own_stream;
-  HIP_TRY(hipSetDevice(handle->device));
+  DeviceGuard guard(handle->device);
+  if (!guard.ok) return AMDAT_HIP_ERROR;
   fill_frames(handle, n, images, nullptr);
   handle->last_n = n;
   HIP_TRY(hipMemcpyAsync(handle->d_frames, handle->h_frames, n * sizeof(FrameDesc), hipMemcpyHostToDevice, s));
@@ -779,7 +820,8 @@ int amdAprilTagsDebugCopy(amdAprilTagsHandle handle, uint32_t frame, amdAprilTag
                           size_t capacity, size_t* bytes) {
   if (!handle || !bytes || frame >= handle->last_n) return AMDAT_INVALID_ARGUMENT;
   const DetParams& P = handle->P;
-  HIP_TRY(hipSetDevice(handle->device));
+  DeviceGuard guard(handle->device);
+  if (!guard.ok) return AMDAT_HIP_ERROR;
   HIP_TRY(hipDeviceSynchronize());
   const FrameCounters& fc = handle->h_counters[frame];
   const size_t npx = (size_t)P.W * P.H;
@@ -823,7 +865,6 @@ int amdAprilTagsDebugCopy(amdAprilTagsHandle handle, uint32_t frame, amdAprilTag
       sz = (size_t)(fc.nquads < P.qcap ? fc.nquads : P.qcap) * sizeof(QuadRec);
       break;
     case AMDAT_DBG_FQPROF:
-      if (!handle->d_fqprof) { *bytes = 0; return AMDAT_SUCCESS; }
       src = handle->d_fqprof; sz = 64 * 8;
       break;
     case AMDAT_DBG_COUNTS: {
@@ -842,16 +883,15 @@ int amdAprilTagsDebugCopy(amdAprilTagsHandle handle, uint32_t frame, amdAprilTag
 int amdAprilTagsDebugMath(int op, uint32_t n, const double* a, const double* b, double* out) {
   if (!a || !b || !out || n == 0) return AMDAT_INVALID_ARGUMENT;
   double *da = nullptr, *db = nullptr, *dout = nullptr;
-  HIP_TRY(hipMalloc((void**)&da, n * 8));
-  HIP_TRY(hipMalloc((void**)&db, n * 8));
-  HIP_TRY(hipMalloc((void**)&dout, n * 8));
-  HIP_TRY(hipMemcpy(da, a, n * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(db, b, n * 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, 0, op, n, da, db, dout);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost));
+  int rc = AMDAT_HIP_ERROR;
+  if (hipMalloc((void**)&da, n * 8) == hipSuccess && hipMalloc((void**)&db, n * 8) == hipSuccess &&
+      hipMalloc((void**)&dout, n * 8) == hipSuccess && hipMemcpy(da, a, n * 8, hipMemcpyHostToDevice) == hipSuccess &&
+      hipMemcpy(db, b, n * 8, hipMemcpyHostToDevice) == hipSuccess) {
+    hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, 0, op, n, da, db, dout);
+    if (hipGetLastError() == hipSuccess && hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost) == hipSuccess) rc = AMDAT_SUCCESS;
+  }
   hipFree(da); hipFree(db); hipFree(dout);
-  return AMDAT_SUCCESS;
+  return rc;
 }
 
 }  // extern "C"

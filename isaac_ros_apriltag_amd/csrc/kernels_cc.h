@@ -14,6 +14,7 @@
 //                and its pixel count is added there.  Pixels keep the index of their tile-local root, so
 //                a consumer reaches the representative with two loads (label[label[p]]) and the image-wide
 //                flatten pass (12 B/pixel of traffic) is not needed.
+//   k_cc_resolve second pass over the root list: non-representative roots receive the component's total size.
 //   k_cc_flatten only used on demand by the stage-inspection call (writes representatives per pixel).
 #pragma once
 #include "common.h"
@@ -253,6 +254,27 @@ __global__ __launch_bounds__(256) void k_cc_sizes(uint32_t* __restrict__ label_a
       label[p] = r;  // every chain through p now ends in one more hop
       atomicAdd(&csize[r], csize[p]);
     }
+  }
+}
+
+// Second pass over the root list, after every k_cc_sizes thread has finished: a tile-local root that is not
+// its component's representative receives the component's TOTAL pixel count (until here it held the tile-local
+// count, which nothing reads any more).  A consumer then needs only two dependent loads per pixel --
+// l = label[p], then label[l] (the representative) and csize[l] (the component size) side by side -- instead
+// of three.
+__global__ __launch_bounds__(256) void k_cc_resolve(const uint32_t* __restrict__ label_all, uint32_t* __restrict__ csize_all,
+                                                    const uint32_t* __restrict__ roots_all,
+                                                    const FrameCounters* __restrict__ counters, DetParams P) {
+  const int frame = (int)blockIdx.z + P.frame0;
+  const size_t n = (size_t)P.W * P.H;
+  const uint32_t* label = label_all + (size_t)frame * n;
+  uint32_t* csize = csize_all + (size_t)frame * n;
+  const uint32_t* roots = roots_all + (size_t)frame * n;
+  const uint32_t nroots = counters[frame].nroots;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nroots; i += gridDim.x * 256) {
+    const uint32_t p = roots[i];
+    const uint32_t r = label[p];
+    if (r != p) csize[p] = csize[r];   // representatives are never written here, only read
   }
 }
 

@@ -88,15 +88,16 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   const int tid = threadIdx.x;
 
   {
-    // tile + halo: 17 x 66 = 1122 entries, up to 5 per thread.  The three dependent gathers per entry
-    // (pixel -> tile-local root -> representative -> its size) are issued stage by stage for all of a
-    // thread's entries, so their latencies overlap instead of adding up.
+    // tile + halo: 17 x 66 = 1122 entries, up to 5 per thread.  Two dependent gather levels per entry (pixel ->
+    // tile-local root l, then label[l] = representative and csize[l] = component size side by side; k_cc_resolve
+    // has put the total size at every root), issued level by level for all of a thread's entries so that their
+    // latencies overlap instead of adding up.
     constexpr int NE = (PT_LH * PT_LW + 255) / 256;
-    uint32_t v[NE], l[NE], r[NE];
+    uint32_t v[NE], l[NE], r[NE], cs[NE];
 #pragma unroll
     for (int e = 0; e < NE; e++) {
       const int i = tid + e * 256;
-      v[e] = 127; l[e] = AT_NO_LABEL; r[e] = AT_NO_LABEL;
+      v[e] = 127; l[e] = AT_NO_LABEL; r[e] = AT_NO_LABEL; cs[e] = 0;
       if (i < PT_LH * PT_LW) {
         const int ly = i / PT_LW, lx = i % PT_LW;
         const int gx = X0 + lx - 1, gy = Y0 + ly;
@@ -108,12 +109,11 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     }
 #pragma unroll
     for (int e = 0; e < NE; e++)
-      if (v[e] != 127 && l[e] != AT_NO_LABEL) r[e] = label[l[e]];
+      if (v[e] != 127 && l[e] != AT_NO_LABEL) { r[e] = label[l[e]]; cs[e] = csize[l[e]]; }
 #pragma unroll
     for (int e = 0; e < NE; e++) {
       const int i = tid + e * 256;
-      uint32_t lab = AT_NO_LABEL;
-      if (r[e] != AT_NO_LABEL && (int)csize[r[e]] >= P.min_component_size) lab = r[e];
+      const uint32_t lab = (r[e] != AT_NO_LABEL && (int)cs[e] >= P.min_component_size) ? r[e] : AT_NO_LABEL;
       if (i < PT_LH * PT_LW) { sv[i] = (uint8_t)v[e]; slab[i] = lab; }
     }
   }
@@ -263,6 +263,47 @@ __global__ __launch_bounds__(1024) void k_cluster_select(const unsigned long lon
     }
   }
   if (in_range) hoff_all[hi] = off;
+}
+
+// Work lists of the quad fit: the kept clusters of all frames of the submission, bucketed by size class
+// (class c holds lo[c] < count <= hi[c]).  An item is (frame << 16) | cluster index.  Appends are aggregated per
+// block in LDS, so every class counter sees one global atomic per block.
+#define FQ_NCLS 5
+struct FqWorkLayout {
+  int lo[FQ_NCLS], hi[FQ_NCLS];
+  uint32_t off[FQ_NCLS], cap[FQ_NCLS];   // item range of class c inside the work array
+};
+__global__ __launch_bounds__(256) void k_worklist(const ClusterRec* __restrict__ clusters_all, FrameCounters* __restrict__ counters,
+                                                  uint32_t* __restrict__ work, uint32_t* __restrict__ work_n, FqWorkLayout L,
+                                                  DetParams P) {
+  __shared__ uint32_t s_cnt[FQ_NCLS], s_base[FQ_NCLS];
+  const int frame = (int)blockIdx.z + P.frame0;
+  uint32_t ncl = counters[frame].nclusters;
+  if (ncl > P.ccap) ncl = P.ccap;
+  const int tid = threadIdx.x;
+  for (uint32_t base = blockIdx.x * 256; base < ncl; base += gridDim.x * 256) {
+    if (tid < FQ_NCLS) s_cnt[tid] = 0;
+    __syncthreads();
+    const uint32_t ci = base + tid;
+    int c = -1;
+    uint32_t rank = 0;
+    if (ci < ncl) {
+      const int count = (int)clusters_all[(size_t)frame * P.ccap + ci].count;
+#pragma unroll
+      for (int k = 0; k < FQ_NCLS; k++)
+        if (count > L.lo[k] && count <= L.hi[k]) c = k;
+      if (c >= 0) rank = atomicAdd(&s_cnt[c], 1u);
+    }
+    __syncthreads();
+    if (tid < FQ_NCLS) s_base[tid] = s_cnt[tid] ? atomicAdd(&work_n[tid], s_cnt[tid]) : 0u;
+    __syncthreads();
+    if (c >= 0) {
+      const uint32_t pos = s_base[c] + rank;
+      if (pos < L.cap[c]) work[L.off[c] + pos] = ((uint32_t)frame << 16) | ci;
+      else atomicOr(&counters[frame].flags, 0x4u);
+    }
+    __syncthreads();
+  }
 }
 
 // one thread per staged point: final position = cluster range start + rank, no atomics

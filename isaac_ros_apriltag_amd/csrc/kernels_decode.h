@@ -127,12 +127,17 @@ __device__ void mat33_inv_transpose_dev(const double* M, double* O) {
   O[6] = c20 / det; O[7] = c21 / det; O[8] = c22 / det;
 }
 
-__device__ void pose_from_homography_dev(const double* H, double fx_in, double fy, double cx, double cy, double tag_size,
-                                         double* R, double* t) {
+__device__ void pose_from_homography_dev(const double* H, double fx_in, double fy, double cx, double cy, double skew,
+                                         double tag_size, double* R, double* t) {
   const double fx = -fx_in;
   double R20 = H[6], R21 = H[7], TZ = H[8];
-  double R00 = (H[0] - cx * R20) / fx, R01 = (H[1] - cx * R21) / fx, TX = (H[2] - cx * TZ) / fx;
   double R10 = (H[3] - cy * R20) / fy, R11 = (H[4] - cy * R21) / fy, TY = (H[5] - cy * TZ) / fy;
+  double R00, R01, TX;
+  if (skew == 0.0) {
+    R00 = (H[0] - cx * R20) / fx; R01 = (H[1] - cx * R21) / fx; TX = (H[2] - cx * TZ) / fx;
+  } else {  // first row of K = (fx, skew, cx): remove the skew share of the second camera axis as well
+    R00 = (H[0] - cx * R20 - skew * R10) / fx; R01 = (H[1] - cx * R21 - skew * R11) / fx; TX = (H[2] - cx * TZ - skew * TY) / fx;
+  }
   const double length1 = (double)at_sqrtf_rn((float)(R00 * R00 + R10 * R10 + R20 * R20));
   const double length2 = (double)at_sqrtf_rn((float)(R01 * R01 + R11 * R11 + R21 * R21));
   double s = 1.0 / (double)at_sqrtf_rn((float)(length1 * length2));
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(64) void k_reconcile(const FrameDesc* __restrict__ 
   const FrameDesc fd = frames[frame];
   for (uint32_t i = threadIdx.x; i < nk; i += 64) {
     DetRec d = dets[order[i]];
-    pose_from_homography_dev(d.H, fd.fx, fd.fy, fd.cx, fd.cy, P.tag_size, d.R, d.t);
+    pose_from_homography_dev(d.H, fd.fx, fd.fy, fd.cx, fd.cy, fd.skew, P.tag_size, d.R, d.t);
     out[i] = d;
   }
 }

@@ -1,7 +1,12 @@
 // kernels_quad.h -- S5 quad fitting (inside cuAprilTagsDetect, reference
 // src/apriltag_node.cpp:491-493).  One workgroup per cluster, five launch classes by cluster size
 // (one wave for <= 256 points ... 512 threads above 8192) so that small clusters do not pay for idle
-// waves and the slope sort always runs in LDS (2 KB ... 144 KB of keys):
+// waves and the slope sort always runs in LDS (2 KB ... 144 KB of keys).  Every class is one launch of
+// PERSISTENT workgroups: k_worklist has bucketed the clusters of all frames of the submission into one
+// compact work list per class, and a workgroup pops the next cluster with one atomic until its list is
+// empty -- no workgroup walks clusters of another class, and the cumulative-moment array of a cluster lives
+// in a scratch slot owned by the workgroup (reused cluster after cluster, so it stays cache-resident) instead
+// of 48 bytes per boundary point of every frame.  Per cluster:
 //   bbox / gradient-dot: seven DPP wave reductions, one barrier -> slope keys, stored so that their order
 //   as IEEE doubles is the wanted order -> bitonic sort in LDS (first three levels in registers, then up
 //   to three network steps per pass, compare-exchange = v_min_f64 + v_max_f64) -> one sweep that drops
@@ -11,9 +16,8 @@
 //   7-tap smoothing -> local maxima compacted into LDS -> wave 0 alone: top-10 selection (rank among
 //   <= 64 candidates, else 11 arg-max rounds) -> table of the 45 pairwise segment fits (all threads) ->
 //   wave 0 alone: best of the C(10,4) corner choices, 4 line fits, intersections, area/angle checks.
-// Where the time goes (1080p sigma-2 frames, 256 per submission, 27.6 ms; measured by truncating the
-// kernel after each phase, -DFQ_STOP=n): cluster loop + bbox 3.7 ms, keys + sort 6.8, moment sweep 9.0,
-// errors + smoothing 2.5, maxima + selection 3.3, pair table + corner choice + checks 2.3.
+// Per-phase shader-cycle counters exist behind -DAMDAT_FQ_PROFILE (tools/build_variants.py); the product
+// build carries none.
 #pragma once
 #include "common.h"
 
@@ -396,11 +400,12 @@ template <int NT>
 // second launch-bound argument = minimum waves per SIMD the register allocation must allow
 __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 : NT == 256 ? FQ_WPE_256 : FQ_WPE_512)) void k_fit_quads(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
                                                    const uint32_t* __restrict__ pts_all, const ClusterRec* __restrict__ clusters_all,
-                                                   unsigned long long* __restrict__ keys_all, double* __restrict__ lf_all,
-                                                   double* __restrict__ errs_a_all, double* __restrict__ errs_b_all,
+                                                   const uint32_t* __restrict__ work, const uint32_t* __restrict__ work_n, uint32_t work_cap,
+                                                   uint32_t* __restrict__ work_cursor, double* __restrict__ lf_scratch,
+                                                   unsigned long long* __restrict__ keys_scratch, double* __restrict__ errs_scratch,
                                                    QuadRec* __restrict__ quads_all, FrameCounters* __restrict__ counters,
-                                                   unsigned long long* __restrict__ prof, int sort_cap, int size_lo, int size_hi,
-                                                   DetParams P) {
+                                                   unsigned long long* __restrict__ prof, int sort_cap, int slot_cap,
+                                                   int pop, DetParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fq_smem[];
   unsigned long long* skeys = reinterpret_cast<unsigned long long*>(fq_smem);
   double* chunk = reinterpret_cast<double*>(fq_smem + (size_t)sort_cap * 8);
@@ -425,18 +430,21 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
   __shared__ int s_wcnt[NW];
   __shared__ int s_coff[NW + 1];    // kept-point offsets per wave, [NW] = chunk total
   __shared__ U128 s_carry[12];   // [chunk parity][moment]: running totals up to the chunk
+  __shared__ uint32_t s_item;
 
-  const int frame = (int)blockIdx.y + P.frame0;
   const int tid = threadIdx.x;
-  const FrameDesc fd = frames[frame];
-  const uint8_t* gray = (P.decimate > 1) ? gray_all + (size_t)frame * P.H * P.WS : fd.img;
-  const int gpitch = (P.decimate > 1) ? P.WS : (int)fd.pitch;
   const int W = P.W, H = P.H;
-  uint32_t ncl = counters[frame].nclusters;
-  if (ncl > P.ccap) ncl = P.ccap;
+  const uint32_t nwork = min(*work_n, work_cap);
+  // scratch slot of this workgroup: cumulative moments of the cluster in flight (and, for clusters that do
+  // not fit the LDS key array, their sort keys and two error arrays)
+  double* const lf = lf_scratch + (size_t)blockIdx.x * slot_cap * 6;
+  unsigned long long* const gkeys = keys_scratch ? keys_scratch + (size_t)blockIdx.x * slot_cap : nullptr;
+  double* const gerrs_a = errs_scratch ? errs_scratch + (size_t)blockIdx.x * slot_cap * 2 : nullptr;
+  double* const gerrs_b = errs_scratch ? gerrs_a + slot_cap : nullptr;
 
   for (int t = tid; t < 210; t += NT) s_combo[t] = g_combo_table.v[t];
 
+#ifdef AMDAT_FQ_PROFILE
 #define FQ_TICK(slot)                                                                  \
   if (prof && tid == 0) {                                                              \
     const unsigned long long now_ = __builtin_readcyclecounter();                      \
@@ -444,12 +452,34 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     t_prev_ = now_;                                                                    \
   }
   unsigned long long t_prev_ = prof ? __builtin_readcyclecounter() : 0ull;
+#else
+#define FQ_TICK(slot)
+  (void)prof;
+#endif
 
-  for (uint32_t ci = blockIdx.x; ci < ncl; ci += gridDim.x) {
-    const ClusterRec cl = clusters_all[(size_t)frame * P.ccap + ci];
+  // Work is popped `pop` clusters at a time: one device-scope atomic on a single word saturates near 90
+  // returns per microsecond (MI355X_MICROARCH.md, "dequeue"), which a one-cluster pop of the small classes
+  // (0.7 M clusters per 256-frame submission) would hit.
+  uint32_t next_item = 0, chunk_left = 0;   // uniform
+  for (;;) {
+    __syncthreads();   // the previous cluster's LDS use (and s_item) is finished in every wave
+    if (chunk_left == 0) {
+      if (tid == 0) s_item = atomicAdd(work_cursor, (uint32_t)pop);
+      __syncthreads();
+      next_item = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);   // uniform: keeps everything derived from it in SGPRs
+      chunk_left = (uint32_t)pop;
+    }
+    const uint32_t item = next_item++;
+    chunk_left--;
+    if (item >= nwork) break;
+    const uint32_t wi = (uint32_t)__builtin_amdgcn_readfirstlane((int)work[item]);
+    const int frame = (int)(wi >> 16);
+    const FrameDesc fd = frames[frame];
+    const uint8_t* gray = (P.decimate > 1) ? gray_all + (size_t)frame * P.H * P.WS : fd.img;
+    const int gpitch = (P.decimate > 1) ? P.WS : (int)fd.pitch;
+    const ClusterRec cl = clusters_all[(size_t)frame * P.ccap + (wi & 0xFFFFu)];
     const int sz = (int)cl.count;
-    if (sz <= size_lo || sz > size_hi || sz < 24) continue;
-    __syncthreads();
+    if (sz < 24 || sz > slot_cap) continue;   // (the work list only holds clusters of this class)
     FQ_TICK(0)
     const uint32_t* pts = pts_all + (size_t)frame * P.pcap + cl.start;
 
@@ -489,14 +519,10 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     if (!P.reversed_border && q_reversed) continue;
     if (!P.normal_border && !q_reversed) continue;
     FQ_TICK(1)
-#if defined(FQ_STOP) && FQ_STOP == 1
-    if (P.max_nmaxima == 10) continue;
-#endif
 
     // ---- slope keys + sort -----------------------------------------------------------------------
     const float cx = (float)cxd, cy = (float)cyd;
     const bool in_lds = sz <= sort_cap;
-    unsigned long long* gkeys = keys_all + (size_t)frame * P.pcap + cl.start;
     for (int i = tid; i < sz; i += NT) {
       const uint32_t p = pts[i];
       const int x = (int)(p >> 18), y = (int)((p >> 4) & 0x3FFF);
@@ -514,9 +540,6 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     __syncthreads();
     if (in_lds) bitonic_sort_block2<NT>(skeys, sz); else bitonic_sort_block2<NT>(gkeys, sz);
     FQ_TICK(2)
-#if defined(FQ_STOP) && FQ_STOP == 2
-    if (P.max_nmaxima == 10) continue;
-#endif
 
     // ---- duplicate removal + weighted moment terms + exact cumulative sums, one sweep ---------------
     // Duplicate points (same half-pixel location, adjacent after the sort) contribute nothing and get no
@@ -526,7 +549,6 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     // prefix is rounded to nearest-even double once -- the same definition the CPU oracle uses,
     // independent of order.  Wave totals are double-buffered by chunk parity, so a chunk costs one
     // barrier; the running carries are double-buffered in LDS the same way (one wave: registers).
-    double* lf = lf_all + ((size_t)frame * P.pcap + cl.start) * 6;
     int szd;
     {
       // EPT consecutive elements per lane: the DPP scan, the barrier and the carry traffic are paid once
@@ -666,15 +688,12 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     __syncthreads();   // lf complete (read by other threads below); key array free
     if (szd < 24) continue;
     FQ_TICK(4)
-#if defined(FQ_STOP) && FQ_STOP == 4
-    if (P.max_nmaxima == 10) continue;
-#endif
 
     // ---- windowed line-fit error, smoothing ------------------------------------------------------
     const int ksz = min(20, szd / 12);
     // raw errors: the key array is dead after the moment terms, so they live there (LDS); global scratch
     // for clusters that do not fit it
-    double* ea = in_lds ? reinterpret_cast<double*>(skeys) : errs_a_all + (size_t)frame * P.pcap + cl.start;
+    double* ea = in_lds ? reinterpret_cast<double*>(skeys) : gerrs_a;
     // (indices wrap with compare/subtract: integer division by a run-time value costs ~40 instructions)
     for (int i = tid; i < szd; i += NT) {
       double e;
@@ -750,7 +769,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
         }
       }
     } else {
-      double* eb = errs_b_all + (size_t)frame * P.pcap + cl.start;
+      double* eb = gerrs_b;
       for (int i = tid; i < szd; i += NT) {
         double acc = 0;
         acc += ea[wrap(i - 3)] * F0;
@@ -785,9 +804,6 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       }
     }
     FQ_TICK(5)
-#if defined(FQ_STOP) && FQ_STOP == 5
-    if (P.max_nmaxima == 10) continue;
-#endif
     __syncthreads();
     const int nmaxima = s_ncand;
     if (nmaxima < 4) continue;
@@ -897,9 +913,6 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     const int m = s_nkept;
     if (m < 4) continue;
     FQ_TICK(6)
-#if defined(FQ_STOP) && FQ_STOP == 6
-    if (P.max_nmaxima == 10) continue;
-#endif
 
     // ---- pairwise segment fits, then all corner quadruples ---------------------------------------
     for (int task = tid; task < 90; task += NT) {

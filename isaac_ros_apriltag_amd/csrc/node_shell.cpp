@@ -6,6 +6,7 @@
 
 #include <dlfcn.h>
 
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -75,8 +76,27 @@ int bytes_per_pixel(const std::string& enc) {
   return 0;
 }
 
-bool selects_gpu_backend(const std::string& backends) {
-  return backends == "CUDA" || backends == "HIP" || backends == "GPU";
+// `backends` is the reference's VPI backend flag string: one name or a comma-separated list
+// (test/isaac_ros_apriltag_backends_compare_test.py:33-37 uses 'CPU', 'CUDA', 'PVA').  Names the reference's
+// VPI builds know plus this library's own.  Throws on an unknown name.
+std::set<std::string> parse_backends(const std::string& backends) {
+  static const char* const kKnown[] = {"CPU", "CUDA", "PVA", "VIC", "NVENC", "OFA", "ALL", "HIP", "GPU"};
+  std::set<std::string> out;
+  size_t pos = 0;
+  while (pos <= backends.size()) {
+    size_t comma = backends.find(',', pos);
+    if (comma == std::string::npos) comma = backends.size();
+    std::string tok = backends.substr(pos, comma - pos);
+    const size_t a = tok.find_first_not_of(" \t"), b = tok.find_last_not_of(" \t");
+    tok = (a == std::string::npos) ? std::string() : tok.substr(a, b - a + 1);
+    for (auto& ch : tok) ch = static_cast<char>(std::toupper(static_cast<unsigned char>(ch)));
+    bool known = false;
+    for (const char* k : kKnown) known |= tok == k;
+    if (!known) throw std::runtime_error("Unrecognized backend '" + tok + "' in 'backends' parameter");
+    out.insert(tok);
+    pos = comma + 1;
+  }
+  return out;
 }
 
 // Rotation matrix (column-major 3x3 float, as cuAprilTagsID_t::orientation) -> quaternion, the
@@ -125,9 +145,17 @@ struct AprilTagNode::Impl {
   uint8_t* d_mono = nullptr; // converted mono8 frame
   size_t d_mono_pitch = 0;
 
+  // exactly {CUDA}: the reference runs cuAprilTags, which decodes tag36h11 only (src/apriltag_node.cpp:429-432)
+  bool cuapriltags_mode = false;
+
   std::set<std::string> SupportedTagFamilies() const {
-    // families this backend can decode = those with a code table in the library
     std::set<std::string> out;
+    if (cuapriltags_mode) {
+      out.insert("tag36h11");
+      return out;
+    }
+    // any other backend list: the reference runs VPI, whose family table is src/apriltag_node.cpp:47-58;
+    // here the families this library can decode = those with a code table
     for (const char* f : kKnownFamilyStrings)
       if (api().family_from_name(f) >= 0) out.insert(f);
     // user-registered tables
@@ -136,7 +164,9 @@ struct AprilTagNode::Impl {
   }
 
   void Initialize(const Image& image, const CameraInfo& info) {
-    initialized = true;
+    if (opt.max_tags <= 0) throw std::runtime_error("'max_tags' must be positive");
+    if (detector) { api().destroy(detector); detector = nullptr; }   // left over from a failed attempt
+    if (d_mono) { api().dev_free(d_mono); d_mono = nullptr; }
     // intrinsics from K, double -> float as the reference does (src/apriltag_node.cpp:442-447)
     amdAprilTagsConfig_t cfg;
     api().default_config(&cfg, info.width, info.height);
@@ -148,6 +178,8 @@ struct AprilTagNode::Impl {
     cfg.intrinsics.fy = static_cast<float>(info.k[4]);
     cfg.intrinsics.cx = static_cast<float>(info.k[2]);
     cfg.intrinsics.cy = static_cast<float>(info.k[5]);
+    // the VPI path also passes the skew K[1] (src/apriltag_node.cpp:215-225); cuAprilTags has no such field
+    cfg.skew = cuapriltags_mode ? 0.0f : static_cast<float>(info.k[1]);
     cfg.tag_size = static_cast<float>(opt.size);
     cfg.max_batch = 1;
     const int error = api().create_ex(&detector, &cfg);
@@ -161,6 +193,7 @@ struct AprilTagNode::Impl {
     void* p = nullptr;
     if (api().dev_alloc(&p, d_mono_pitch * height) != 0) throw std::runtime_error("device allocation failed");
     d_mono = static_cast<uint8_t*>(p);
+    initialized = true;   // only now: a failed creation is retried (and reported) on the next frame
     (void)image;
   }
 
@@ -169,6 +202,14 @@ struct AprilTagNode::Impl {
     if (bpp == 0) {
       std::fprintf(stderr, "[apriltag_node] Unsupported image encoding: %s\n", image.encoding.c_str());
       throw std::runtime_error("AprilTags detector only supports 'mono8', 'rgb8', 'bgr8', 'rgba8' or 'bgra8' image input");
+    }
+    // the detector and the conversion buffer are sized from camera_info at initialisation
+    // (src/apriltag_node.cpp:228-231,257-260): a frame of another size is dropped before anything is written
+    if (image.width != width || image.height != height || info.width != width || info.height != height ||
+        static_cast<size_t>(image.step) < static_cast<size_t>(image.width) * bpp || image.data == nullptr) {
+      std::fprintf(stderr, "[apriltag_node] image %ux%u (step %u) does not match the initialised size %ux%u: frame dropped\n",
+                   image.width, image.height, image.step, width, height);
+      return;
     }
     const uint8_t* dev_src = image.data;
     if (!image.is_device) {
@@ -246,8 +287,11 @@ AprilTagNode::AprilTagNode(const NodeOptions& options) : impl_(new Impl()) {
   impl_->opt = options;
   // Backend selection (src/apriltag_node.cpp:575-582): this build has exactly one implementation, the
   // HIP detector; CPU / PVA backends of VPI do not exist here and support no family.
-  std::set<std::string> supported;
-  if (selects_gpu_backend(options.backends)) supported = impl_->SupportedTagFamilies();
+  // cuAprilTags when exactly CUDA was asked for, VPI otherwise; the HIP detector stands behind both, whatever
+  // names the list holds (there is one implementation and no CPU fallback).
+  const std::set<std::string> backends = parse_backends(options.backends);
+  impl_->cuapriltags_mode = backends.size() == 1 && *backends.begin() == "CUDA";
+  const std::set<std::string> supported = impl_->SupportedTagFamilies();
   if (supported.find(options.tag_family) == supported.end()) {
     std::ostringstream os;
     os << "Tag family not supported by specified backend: '" << options.tag_family << "'" << std::endl;
@@ -260,7 +304,7 @@ AprilTagNode::AprilTagNode(const NodeOptions& options) : impl_(new Impl()) {
 }
 
 AprilTagNode::~AprilTagNode() {
-  if (impl_ && impl_->initialized) {
+  if (impl_) {
     if (impl_->detector) api().destroy(impl_->detector);
     if (impl_->d_input) api().dev_free(impl_->d_input);
     if (impl_->d_mono) api().dev_free(impl_->d_mono);

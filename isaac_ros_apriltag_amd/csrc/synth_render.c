@@ -123,8 +123,10 @@ int synth_render(uint8_t* img, int w, int h, int pitch, int background, int sigm
 /* Family table access for the scene generator (data from include/apriltag_amd_families.h). */
 #include "../../include/apriltag_amd_families.h"
 const uint64_t* synth_family_codes(const char* name, int* ncodes, int* d) {
-  if (!strcmp(name, "tag36h11")) { *ncodes = APRILTAG_AMD_TAG36H11_VALIDATED; *d = 6; return apriltag_amd_tag36h11_codes; }
-  if (!strcmp(name, "synth36h11")) { *ncodes = APRILTAG_AMD_SYNTH36H11_NCODES; *d = 6; return apriltag_amd_synth36h11_codes; }
+  if (!strcmp(name, "tag36h11")) { *ncodes = APRILTAG_AMD_TAG36H11_NCODES; *d = 6; return apriltag_amd_tag36h11_codes; }
+#ifdef APRILTAG_AMD_TAG36H10_NCODES
+  if (!strcmp(name, "tag36h10")) { *ncodes = APRILTAG_AMD_TAG36H10_NCODES; *d = 6; return apriltag_amd_tag36h10_codes; }
+#endif
   if (!strcmp(name, "tag25h9")) { *ncodes = APRILTAG_AMD_TAG25H9_NCODES; *d = 5; return apriltag_amd_tag25h9_codes; }
   if (!strcmp(name, "tag16h5")) { *ncodes = APRILTAG_AMD_TAG16H5_NCODES; *d = 4; return apriltag_amd_tag16h5_codes; }
   *ncodes = 0; *d = 0;

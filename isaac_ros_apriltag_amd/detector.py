@@ -101,17 +101,21 @@ class AprilTagDetector:
         return res
 
     # ---- prepared submissions: argument marshalling done once, the timed call is only the C ABI call ----
-    def prepare(self, frames, max_dets=64):
+    def prepare(self, frames, max_dets=64, intrinsics=None):
         imgs, keep = _as_images(frames, self.width, self.height)
         n = len(imgs)
-        return {"imgs": imgs, "keep": keep, "n": n, "max_dets": max_dets,
+        intr = None
+        if intrinsics is not None:
+            assert len(intrinsics) == n
+            intr = (capi.Intrinsics * n)(*[capi.Intrinsics(*[float(v) for v in k]) for k in intrinsics])
+        return {"imgs": imgs, "keep": keep, "n": n, "max_dets": max_dets, "intr": intr,
                 "out": (capi.DetectionEx * (n * max_dets))(), "cnt": (C.c_uint32 * n)()}
 
     def run_prepared(self, prep, stream=None):
         """One blocking amdAprilTagsDetectBatchEx call; results stay in prep['out'] / prep['cnt']."""
         capi._check("amdAprilTagsDetectBatchEx",
-                    self._L.amdAprilTagsDetectBatchEx(self._h, prep["n"], prep["imgs"], None, prep["out"], prep["cnt"],
-                                                      prep["max_dets"], stream))
+                    self._L.amdAprilTagsDetectBatchEx(self._h, prep["n"], prep["imgs"], prep.get("intr"), prep["out"],
+                                                      prep["cnt"], prep["max_dets"], stream))
 
     def unpack(self, prep):
         res = []
@@ -159,6 +163,19 @@ class AprilTagDetector:
         fl = (C.c_uint32 * n)()
         capi._check("amdAprilTagsGetFrameFlags", self._L.amdAprilTagsGetFrameFlags(self._h, fl, n))
         return [int(v) for v in fl]
+
+    def mean_counts(self, n, sample=16):
+        """Mean per-frame content counters of the last submission over `sample` evenly spaced frames."""
+        idx = sorted(set(int(i) for i in np.linspace(0, n - 1, min(sample, n))))
+        c = np.array([self.debug(i, capi.DBG_COUNTS)[:5] for i in idx], dtype=np.float64).mean(axis=0)
+        return {"npoints_raw": float(c[0]), "nclusters": float(c[1]), "npoints_kept": float(c[2]), "nquads": float(c[3]),
+                "ndets_raw": float(c[4])}
+
+    def device_bytes(self):
+        """Device memory the handle owns."""
+        nb = C.c_size_t()
+        capi._check("amdAprilTagsGetDeviceBytes", self._L.amdAprilTagsGetDeviceBytes(self._h, C.byref(nb)))
+        return int(nb.value)
 
     def debug(self, frame, what):
         nbytes = C.c_size_t()

@@ -186,7 +186,7 @@ def scene_c5(seed=1234, sigma=2.0):
 
 
 def scene_c3(seed=77, sigma=2.0):
-    """Config 3: 3840x2160, 10x10 board of the stand-in family synth36h11 ids 0-99, side 160 px,
+    """Config 3: 3840x2160, 10x10 board of tag36h11 ids 0-99, side 160 px,
     gap 40 px, board tilted 10 deg about the vertical axis (long lens, f = 4000 px, so that the whole
     board stays in view)."""
     width, height = 3840, 2160
@@ -202,7 +202,7 @@ def scene_c3(seed=77, sigma=2.0):
             t = np.array([0.0, 0.0, z]) + Rb @ off
             H = homography_from_pose(Rb, t, K, size)
             tid = r * 10 + c
-            tags.append({"family": "synth36h11", "id": tid, "H": H})
-            truth.append(truth_from_H("synth36h11", tid, H, Rb, t))
+            tags.append({"family": "tag36h11", "id": tid, "H": H})
+            truth.append(truth_from_H("tag36h11", tid, H, Rb, t))
     img = render(width, height, tags, background=150, sigma=sigma, seed=seed)
     return img, K, truth, size

@@ -45,9 +45,11 @@ int ato_builtin_family(const char* name, ato_family_t* out) {
   memset(out, 0, sizeof(*out));
   strncpy(out->name, name, sizeof(out->name) - 1);
   if (!strcmp(name, "tag36h11")) {
-    out->d = 6; out->ncodes = APRILTAG_AMD_TAG36H11_VALIDATED; out->codes = apriltag_amd_tag36h11_codes;
-  } else if (!strcmp(name, "synth36h11")) {
-    out->d = 6; out->ncodes = APRILTAG_AMD_SYNTH36H11_NCODES; out->codes = apriltag_amd_synth36h11_codes;
+    out->d = 6; out->ncodes = APRILTAG_AMD_TAG36H11_NCODES; out->codes = apriltag_amd_tag36h11_codes;
+#ifdef APRILTAG_AMD_TAG36H10_NCODES
+  } else if (!strcmp(name, "tag36h10")) {
+    out->d = 6; out->ncodes = APRILTAG_AMD_TAG36H10_NCODES; out->codes = apriltag_amd_tag36h10_codes;
+#endif
   } else if (!strcmp(name, "tag25h9")) {
     out->d = 5; out->ncodes = APRILTAG_AMD_TAG25H9_NCODES; out->codes = apriltag_amd_tag25h9_codes;
   } else if (!strcmp(name, "tag16h5")) {
@@ -316,6 +318,15 @@ static size_t group_points(const kp_t* kp, size_t n, ato_cluster_t** clusters_ou
 /* ------------------------------------------------------------------------------------------- */
 typedef struct { double Mx, My, Mxx, Mxy, Myy, W; } lfp_t;
 
+/* Diagnostic counters (not thread-safe; tools/cluster_stats.py only): [r] = clusters that left fit_quad for
+ * reason r, [16 + r] = their points.  Reasons: 0 bbox, 1 border direction, 2 < 24 points after duplicate removal,
+ * 3 fewer than 4 maxima, 4 no admissible corner choice, 5 total error, 6 final line mse, 7 degenerate
+ * intersection, 8 area, 9 angles / winding, 10 accepted. */
+long long ato_stats[32];
+#define ATO_STAT(r, n) do { ato_stats[(r)]++; ato_stats[16 + (r)] += (n); } while (0)
+static __thread int g_qsm_reason;
+
+
 static const float GAUSS7[7] = {0x1.6c0504p-7f, 0x1.152aaap-3f, 0x1.368b3p-1f, 1.0f,
                                 0x1.368b3p-1f, 0x1.152aaap-3f, 0x1.6c0504p-7f};
 
@@ -363,6 +374,7 @@ static int dbl_desc(const void* a, const void* b) {
 
 static int quad_segment_maxima(const ato_params_t* prm, const lfp_t* lfps, int sz, int indices[4]) {
   int ksz = sz / 12 < 20 ? sz / 12 : 20;
+  g_qsm_reason = 3;
   if (ksz < 2) return 0;
   double* errs = (double*)malloc(sizeof(double) * sz);
   double* sm = (double*)malloc(sizeof(double) * sz);
@@ -398,6 +410,7 @@ static int quad_segment_maxima(const ato_params_t* prm, const lfp_t* lfps, int s
     }
     int best[4] = {0, 0, 0, 0};
     double best_error = (double)HUGE_VALF;
+    g_qsm_reason = 4;
     double err01, err12, err23, err30, mse01, mse12, mse23, mse30, p01[4], p12[4];
     double max_dot = prm->cos_critical_rad;
     for (int m0 = 0; m0 < nmaxima - 3; m0++) {
@@ -426,6 +439,7 @@ static int quad_segment_maxima(const ato_params_t* prm, const lfp_t* lfps, int s
     }
     if (best_error != (double)HUGE_VALF) {
       for (int i = 0; i < 4; i++) indices[i] = best[i];
+      g_qsm_reason = 5;
       if (best_error / sz < prm->max_line_fit_mse) ok = 1;
     }
   }
@@ -487,13 +501,24 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
     sxg += (long long)x * gx + (long long)y * gy;
     sgx += gx; sgy += gy;
   }
-  if ((xmax - xmin) * (ymax - ymin) < tag_width) return 0;
+  const int sz_in = sz;
+  if ((xmax - xmin) * (ymax - ymin) < tag_width) { ATO_STAT(0, sz_in); return 0; }
   double cxd = (xmin + xmax) * 0.5 + 0.05118, cyd = (ymin + ymax) * 0.5 + -0.028581;
   /* CANONICAL: dot = sum(dx*gx + dy*gy) evaluated exactly (upstream: float accumulation in hash order) */
   double dot = (double)sxg - cxd * (double)sgx - cyd * (double)sgy;
+  if (prm->variant & ATO_VAR_FLOAT_DOT) {   /* upstream: float accumulation in the cluster's point order */
+    float fcx = (float)cxd, fcy = (float)cyd, fdot = 0;
+    for (int i = 0; i < sz; i++) {
+      int x, y, gx, gy;
+      unpack_point(pts[i], &x, &y, &gx, &gy);
+      float dx = (float)x - fcx, dy = (float)y - fcy;
+      fdot += dx * (float)gx + dy * (float)gy;
+    }
+    dot = (double)fdot;
+  }
   quad->reversed_border = dot < 0;
-  if (!reversed_border && quad->reversed_border) return 0;
-  if (!normal_border && !quad->reversed_border) return 0;
+  if (!reversed_border && quad->reversed_border) { ATO_STAT(1, sz_in); return 0; }
+  if (!normal_border && !quad->reversed_border) { ATO_STAT(1, sz_in); return 0; }
 
   /* slope key: quadrant band + dy/dx after rotating into the first quadrant (float, as upstream) */
   float cx = (float)cxd, cy = (float)cyd;
@@ -520,7 +545,7 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
       if ((keys[i] >> 4) != (keys[i - 1] >> 4)) keys[outpos++] = keys[i];   /* bits 4..31 = (y,x) */
     sz = outpos;
   }
-  if (sz < 24) { free(keys); return 0; }
+  if (sz < 24) { free(keys); ATO_STAT(2, sz_in); return 0; }
 
   /* cumulative weighted moments (compute_lfps).  Per-point terms are formed exactly as upstream does
    * (W*x, W*y, (W*x)*x, (W*x)*y, (W*y)*y, W in double).  CANONICAL: the running sums are the EXACT sums
@@ -529,6 +554,7 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
    * term is >= 1 and < 2^36, so 52 fractional bits in a 128-bit integer hold each term exactly. */
   lfp_t* lfps = (lfp_t*)malloc(sizeof(lfp_t) * sz);
   unsigned __int128 acc[6] = {0, 0, 0, 0, 0, 0};
+  double seq[6] = {0, 0, 0, 0, 0, 0};   /* ATO_VAR_SEQ_MOMENTS: upstream's running double sums */
   for (int i = 0; i < sz; i++) {
     int px = (int)((keys[i] >> 4) & 0x3FFF), py = (int)((keys[i] >> 18) & 0x3FFF);
     double x = px * .5 + 0.5, y = py * .5 + 0.5;
@@ -541,18 +567,22 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
     }
     double t[6] = {W * x, W * y, W * x * x, W * x * y, W * y * y, W};
     double r[6];
-    for (int j = 0; j < 6; j++) { acc[j] += exact_to_fixed(t[j]); r[j] = exact_from_fixed(acc[j]); }
+    for (int j = 0; j < 6; j++) {
+      acc[j] += exact_to_fixed(t[j]); r[j] = exact_from_fixed(acc[j]);
+      seq[j] += t[j];
+      if (prm->variant & ATO_VAR_SEQ_MOMENTS) r[j] = seq[j];
+    }
     lfps[i].Mx = r[0]; lfps[i].My = r[1]; lfps[i].Mxx = r[2]; lfps[i].Mxy = r[3]; lfps[i].Myy = r[4]; lfps[i].W = r[5];
   }
   free(keys);
 
   int res = 0, indices[4];
   double lines[4][4];
-  if (!quad_segment_maxima(prm, lfps, sz, indices)) goto finish;
+  if (!quad_segment_maxima(prm, lfps, sz, indices)) { ATO_STAT(g_qsm_reason, sz_in); goto finish; }
   for (int i = 0; i < 4; i++) {
     double mse;
     fit_line(lfps, sz, indices[i], indices[(i + 1) & 3], lines[i], NULL, &mse);
-    if (mse > prm->max_line_fit_mse) goto finish;
+    if (mse > prm->max_line_fit_mse) { ATO_STAT(6, sz_in); goto finish; }
   }
   for (int i = 0; i < 4; i++) {
     double A00 = lines[i][3], A01 = -lines[(i + 1) & 3][3];
@@ -560,7 +590,7 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
     double B0 = -lines[i][0] + lines[(i + 1) & 3][0];
     double B1 = -lines[i][1] + lines[(i + 1) & 3][1];
     double det = A00 * A11 - A10 * A01;
-    if (fabs(det) < 0.001) goto finish;
+    if (fabs(det) < 0.001) { ATO_STAT(7, sz_in); goto finish; }
     double W00 = A11 / det, W01 = -A01 / det;
     double L0 = W00 * B0 + W01 * B1;
     quad->p[i][0] = (float)(lines[i][0] + L0 * A00);
@@ -584,16 +614,17 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
     }
     p = (length[0] + length[1] + length[2]) / 2;
     area += sqrt(p * (p - length[0]) * (p - length[1]) * (p - length[2]));
-    if (area < 0.95 * tag_width * tag_width) goto finish;
+    if (area < 0.95 * tag_width * tag_width) { ATO_STAT(8, sz_in); goto finish; }
   }
   for (int i = 0; i < 4; i++) {
     int i0 = i, i1 = (i + 1) & 3, i2 = (i + 2) & 3;
     double dx1 = (double)quad->p[i1][0] - (double)quad->p[i0][0], dy1 = (double)quad->p[i1][1] - (double)quad->p[i0][1];
     double dx2 = (double)quad->p[i2][0] - (double)quad->p[i1][0], dy2 = (double)quad->p[i2][1] - (double)quad->p[i1][1];
     double cos_dtheta = (dx1 * dx2 + dy1 * dy2) / sqrt((dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2));
-    if ((cos_dtheta > prm->cos_critical_rad || cos_dtheta < -prm->cos_critical_rad) || dx1 * dy2 < dy1 * dx2) goto finish;
+    if ((cos_dtheta > prm->cos_critical_rad || cos_dtheta < -prm->cos_critical_rad) || dx1 * dy2 < dy1 * dx2) { ATO_STAT(9, sz_in); goto finish; }
   }
   res = 1;
+  ATO_STAT(10, sz_in);
 finish:
   free(lfps);
   return res;
@@ -655,6 +686,11 @@ static void refine_edges(const ato_params_t* prm, const uint8_t* im, int w, int 
     if (M1 > M2) { nx = nx1; ny = ny1; M = M1; } else { nx = nx2; ny = ny2; M = M2; }
     double length = (double)sqrtf((float)M);
     if (fabs(length) < 1e-12) { nx = 0; ny = 0; } else { nx = nx / length; ny = ny / length; }
+    if (prm->variant & ATO_VAR_ATAN_NORMAL) {   /* upstream refine_edges */
+      float normal_theta = 0.5f * atan2f((float)(-2 * Cxy), (float)(Cyy - Cxx));
+      nx = (double)cosf(normal_theta);
+      ny = (double)sinf(normal_theta);
+    }
     lines[edge][0] = Ex; lines[edge][1] = Ey; lines[edge][2] = nx; lines[edge][3] = ny;
   }
   for (int i = 0; i < 4; i++) {
@@ -940,25 +976,75 @@ static void mat33_inv_transpose(const double* M, double* O) {
   O[6] = c20 / det; O[7] = c21 / det; O[8] = c22 / det;
 }
 
-void ato_pose_from_homography(const double H[9], double fx_in, double fy, double cx, double cy, double tag_size,
-                              double R[9], double t[3]) {
+/* Orthogonal polar factor of a 3x3 matrix through its singular value decomposition, M = U S V^T -> U V^T
+ * (upstream: matd_svd, then R = U*V').  U V^T = M V S^-1 V^T with V, S^2 from the Jacobi eigen-decomposition of
+ * M^T M. */
+static void polar_by_svd(const double* M, double* O) {
+  double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) A[i * 3 + j] = M[0 * 3 + i] * M[0 * 3 + j] + M[1 * 3 + i] * M[1 * 3 + j] + M[2 * 3 + i] * M[2 * 3 + j];
+  for (int sweep = 0; sweep < 30; sweep++) {
+    double off = fabs(A[1]) + fabs(A[2]) + fabs(A[5]);
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        double apq = A[p * 3 + q];
+        if (apq == 0) continue;
+        double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2 * apq);
+        double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+        double c = 1 / sqrt(tt * tt + 1), sn = tt * c;
+        for (int k = 0; k < 3; k++) {  /* A <- A J */
+          double akp = A[k * 3 + p], akq = A[k * 3 + q];
+          A[k * 3 + p] = c * akp - sn * akq; A[k * 3 + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < 3; k++) {  /* A <- J^T A */
+          double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+          A[p * 3 + k] = c * apk - sn * aqk; A[q * 3 + k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; k++) {
+          double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
+          V[k * 3 + p] = c * vkp - sn * vkq; V[k * 3 + q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+  double is[3] = {1 / sqrt(A[0]), 1 / sqrt(A[4]), 1 / sqrt(A[8])};
+  double T[9];  /* V S^-1 V^T */
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) T[i * 3 + j] = V[i * 3 + 0] * is[0] * V[j * 3 + 0] + V[i * 3 + 1] * is[1] * V[j * 3 + 1] + V[i * 3 + 2] * is[2] * V[j * 3 + 2];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) O[i * 3 + j] = M[i * 3 + 0] * T[0 * 3 + j] + M[i * 3 + 1] * T[1 * 3 + j] + M[i * 3 + 2] * T[2 * 3 + j];
+}
+
+void ato_pose_from_homography_ex(const double H[9], double fx_in, double fy, double cx, double cy, double skew,
+                                 double tag_size, int variant, double R[9], double t[3]) {
   double fx = -fx_in; /* upstream calls homography_to_pose(H, -fx, fy, cx, cy) */
   double R20 = H[6], R21 = H[7], TZ = H[8];
-  double R00 = (H[0] - cx * R20) / fx, R01 = (H[1] - cx * R21) / fx, TX = (H[2] - cx * TZ) / fx;
   double R10 = (H[3] - cy * R20) / fy, R11 = (H[4] - cy * R21) / fy, TY = (H[5] - cy * TZ) / fy;
+  double R00, R01, TX;
+  if (skew == 0.0) {
+    R00 = (H[0] - cx * R20) / fx; R01 = (H[1] - cx * R21) / fx; TX = (H[2] - cx * TZ) / fx;
+  } else {  /* first row of K = (fx, skew, cx); upstream has no skew term (the VPI path of the reference does) */
+    R00 = (H[0] - cx * R20 - skew * R10) / fx; R01 = (H[1] - cx * R21 - skew * R11) / fx; TX = (H[2] - cx * TZ - skew * TY) / fx;
+  }
   double length1 = (double)sqrtf((float)(R00 * R00 + R10 * R10 + R20 * R20));
   double length2 = (double)sqrtf((float)(R01 * R01 + R11 * R11 + R21 * R21));
   double s = 1.0 / (double)sqrtf((float)(length1 * length2));
   if (TZ > 0) s *= -1;
   R20 *= s; R21 *= s; TZ *= s; R00 *= s; R01 *= s; TX *= s; R10 *= s; R11 *= s; TY *= s;
   double R02 = R10 * R21 - R20 * R11, R12 = R20 * R01 - R00 * R21, R22 = R00 * R11 - R10 * R01;
-  /* polar decomposition (upstream: R = U*V' from the SVD); here the orthogonal polar factor by a
+  /* polar decomposition (upstream: R = U*V' from the SVD); canonically the orthogonal polar factor by a
    * fixed number of Newton steps X <- (X + X^-T)/2, which converges to the same matrix. */
   double X[9] = {R00, R01, R02, R10, R11, R12, R20, R21, R22};
-  for (int it = 0; it < 12; it++) {
+  if (variant & ATO_VAR_SVD_POLAR) {
     double Y[9];
-    mat33_inv_transpose(X, Y);
-    for (int i = 0; i < 9; i++) X[i] = 0.5 * (X[i] + Y[i]);
+    polar_by_svd(X, Y);
+    memcpy(X, Y, sizeof(X));
+  } else {
+    for (int it = 0; it < 12; it++) {
+      double Y[9];
+      mat33_inv_transpose(X, Y);
+      for (int i = 0; i < 9; i++) X[i] = 0.5 * (X[i] + Y[i]);
+    }
   }
   double scale = tag_size / 2.0;
   TX *= scale; TY *= scale; TZ *= scale;
@@ -967,6 +1053,12 @@ void ato_pose_from_homography(const double H[9], double fx_in, double fy, double
   R[3] = -X[3]; R[4] = -X[4]; R[5] = -X[5];
   R[6] = -X[6]; R[7] = -X[7]; R[8] = -X[8];
   t[0] = TX; t[1] = -TY; t[2] = -TZ;
+}
+
+
+void ato_pose_from_homography(const double H[9], double fx, double fy, double cx, double cy, double tag_size,
+                              double R[9], double t[3]) {
+  ato_pose_from_homography_ex(H, fx, fy, cx, cy, 0.0, tag_size, 0, R, t);
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -1090,7 +1182,7 @@ int ato_detect(const ato_params_t* prm, const ato_family_t* fams, int nfam, cons
   }
   nd = nk;
   for (size_t i = 0; i < nd; i++)
-    ato_pose_from_homography(dets[i].H, prm->fx, prm->fy, prm->cx, prm->cy, prm->tag_size, dets[i].R, dets[i].t);
+    ato_pose_from_homography_ex(dets[i].H, prm->fx, prm->fy, prm->cx, prm->cy, prm->skew, prm->tag_size, prm->variant, dets[i].R, dets[i].t);
 
   int nout = (int)(nd < (size_t)max_det ? nd : (size_t)max_det);
   for (int i = 0; i < nout; i++) out[i] = dets[i];

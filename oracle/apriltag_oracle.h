@@ -48,7 +48,17 @@ typedef struct {
   int32_t max_hamming;           /* 2 */
   double fx, fy, cx, cy;         /* intrinsics K[0],K[4],K[2],K[5] (apriltag_node.cpp:442-446) */
   double tag_size;               /* metres, black-border edge (apriltag_node.cpp:565) */
+  double skew;                   /* K[0][1]; the reference's VPI path passes it (apriltag_node.cpp:215-225) */
+  int32_t variant;               /* 0 = canonical definitions (what the HIP path is checked against bit for bit);
+                                  * ATO_VAR_* bits switch single steps to AprilRobotics' own formulation, used only
+                                  * to BOUND the distance between the two (tests/test_oracle_variants_cpu.py) */
 } ato_params_t;
+
+/* upstream formulations of the steps this restatement defines canonically */
+#define ATO_VAR_SEQ_MOMENTS 1  /* compute_lfps: the six running sums are sequential double additions */
+#define ATO_VAR_ATAN_NORMAL 2  /* refine_edges: normal = (cosf, sinf) of 0.5*atan2f(-2Cxy, Cyy-Cxx) */
+#define ATO_VAR_SVD_POLAR 4    /* homography_to_pose: R = U V^T from the SVD instead of Newton steps */
+#define ATO_VAR_FLOAT_DOT 8    /* fit_quad: border-direction dot accumulated in float, point by point */
 
 typedef struct {
   int32_t family;   /* index into the family list */
@@ -117,6 +127,9 @@ void ato_rectify_mono8(const uint8_t* src, int spitch, uint8_t* dst, int dpitch,
  * estimate_pose_for_tag_homography). */
 void ato_pose_from_homography(const double H[9], double fx, double fy, double cx, double cy,
                               double tag_size, double R[9], double t[3]);
+/* same with a skew term in K and a choice of formulation (ATO_VAR_SVD_POLAR) */
+void ato_pose_from_homography_ex(const double H[9], double fx, double fy, double cx, double cy, double skew,
+                                 double tag_size, int variant, double R[9], double t[3]);
 
 #ifdef __cplusplus
 }

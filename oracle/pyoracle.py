@@ -27,7 +27,7 @@ class Params(C.Structure):
                 ("max_line_fit_mse", C.c_double), ("refine_edges", C.c_int32),
                 ("decode_sharpening", C.c_double), ("max_hamming", C.c_int32),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
-                ("tag_size", C.c_double)]
+                ("tag_size", C.c_double), ("skew", C.c_double), ("variant", C.c_int32)]
 
 
 class Detection(C.Structure):
@@ -61,6 +61,13 @@ def build():
 _lib = None
 
 
+def use_library(path):
+    """Binds another build of the same source (bench.py's -O3 -march=native CPU leg); call before lib()."""
+    global _lib, _LIB_PATH
+    _LIB_PATH = path
+    _lib = None
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -83,6 +90,8 @@ def lib():
                                            C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib.ato_pose_from_homography.argtypes = [C.POINTER(C.c_double)] + [C.c_double] * 5 + \
             [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        _lib.ato_pose_from_homography_ex.argtypes = [C.POINTER(C.c_double)] + [C.c_double] * 6 + \
+            [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     return _lib
 
 
@@ -162,11 +171,14 @@ def rectify_mono8(img, K, D, Knew):
     return out
 
 
-def pose_from_homography(H, fx, fy, cx, cy, tag_size):
+VAR_SEQ_MOMENTS, VAR_ATAN_NORMAL, VAR_SVD_POLAR, VAR_FLOAT_DOT = 1, 2, 4, 8
+
+
+def pose_from_homography(H, fx, fy, cx, cy, tag_size, skew=0.0, variant=0):
     Hc = (C.c_double * 9)(*np.asarray(H, dtype=np.float64).reshape(-1))
     R = (C.c_double * 9)()
     t = (C.c_double * 3)()
-    lib().ato_pose_from_homography(Hc, fx, fy, cx, cy, tag_size, R, t)
+    lib().ato_pose_from_homography_ex(Hc, fx, fy, cx, cy, skew, tag_size, variant, R, t)
     return np.array(list(R)).reshape(3, 3), np.array(list(t))
 
 

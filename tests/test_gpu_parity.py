@@ -80,9 +80,9 @@ def test_stage_and_detection_parity(built, name, scene, families, decimate):
 def test_c3_4k_board_decimate2(built):
     img, K, truth, size = synth.scene_c3()
     h, w = img.shape
-    det = AprilTagDetector(w, h, families=("synth36h11",), decimate=2, intrinsics=_k4(K), tag_size=size, max_batch=1)
+    det = AprilTagDetector(w, h, families=("tag36h11",), decimate=2, intrinsics=_k4(K), tag_size=size, max_batch=1)
     g = det.detect_batch_ex(torch.from_numpy(img).cuda(), max_dets=256)[0]
-    errs, odets = pu.compare_stages(det, 0, img, ("synth36h11",), K, 2, tag_size=size)
+    errs, odets = pu.compare_stages(det, 0, img, ("tag36h11",), K, 2, tag_size=size)
     errs += pu.compare_detections(g, odets)
     det.close()
     assert not errs, errs[:5]
@@ -163,6 +163,36 @@ def test_reference_pol_golden_through_c_abi(built):
         assert np.abs(R - np.diag([-1.0, -1.0, 1.0])).max() <= 0.02   # quaternion (0,0,0,1)
 
 
+def _bt601(rgb):
+    """numpy statement of the conversion: Y = (4899 R + 9617 G + 1868 B + 8192) >> 14 (the 14-bit fixed-point
+    BT.601 weights 0.299 / 0.587 / 0.114 that cv_bridge / OpenCV apply for the reference's mono8 test input)."""
+    r, g, b = (rgb[..., i].astype(np.uint32) for i in range(3))
+    return ((4899 * r + 9617 * g + 1868 * b + 8192) >> 14).astype(np.uint8)
+
+
+@pytest.mark.parametrize("encoding,nch,order", [("rgb8", 3, (0, 1, 2)), ("bgr8", 3, (2, 1, 0)), ("rgba8", 4, (0, 1, 2)),
+                                                ("bgra8", 4, (2, 1, 0))])
+def test_colour_conversion_random_pixels(built, encoding, nch, order):
+    """All four colour encodings of apriltag_node.cpp:76-82 on RANDOM colours (so that a swapped channel order
+    cannot pass), odd width, padded pitch, against the numpy BT.601 statement."""
+    rng = np.random.default_rng(len(encoding) * 7 + nch)
+    h, w = 37, 1001
+    rgb = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    pitch = w * nch + 12
+    buf = rng.integers(0, 256, size=(h, pitch), dtype=np.uint8)       # garbage in the padding and in alpha
+    px = buf[:, :w * nch].reshape(h, w, nch)
+    for c in range(3):
+        px[..., order[c]] = rgb[..., c]                                # channel `order[c]` of the pixel holds R/G/B
+    src = torch.from_numpy(buf).cuda()
+    dpitch = 1024
+    dst = torch.zeros((h, dpitch), dtype=torch.uint8, device="cuda")
+    rc = capi.lib().amdAprilTagsConvertToMono8(src.data_ptr(), pitch, encoding.encode(), w, h, dst.data_ptr(), dpitch, None)
+    assert rc == 0
+    got = dst.cpu().numpy()
+    assert np.array_equal(got[:, :w], _bt601(rgb))
+    assert (got[:, w:] == 0).all()                                      # nothing written beyond the row
+
+
 def test_bgr8_input_through_conversion(built):
     """Reference fixture encoding is bgr8 (test_cases/apriltag0/image.json): replicate the gray frame
     into 3 channels, convert on the device, detect."""
@@ -178,6 +208,42 @@ def test_bgr8_input_through_conversion(built):
     g = det.detect_batch_ex(dst)[0]
     det.close()
     assert [d["id"] for d in g] == [0]
+
+
+def test_skew_in_pose(built):
+    """K[0][1] of the VPI path (apriltag_node.cpp:215-225): bit-identical to the oracle's skewed pose solve, and
+    different from the skew-free pose; corners do not depend on the intrinsics."""
+    img, K, _ = synth.scene_c2(seed=1250, sigma=0.0)
+    det0 = AprilTagDetector(1920, 1080, intrinsics=_k4(K), max_batch=1)
+    det1 = AprilTagDetector(1920, 1080, intrinsics=_k4(K), max_batch=1, skew=3.25)
+    t = torch.from_numpy(img).cuda()
+    g0, g1 = det0.detect_batch_ex(t)[0], det1.detect_batch_ex(t)[0]
+    det0.close(); det1.close()
+    prm = pu.oracle_params(K, 1, 0.22)
+    prm.skew = 3.25
+    o1 = po.detect(img, params=prm)[0]
+    assert len(g1) == 10 and not pu.compare_detections(g1, o1)
+    for a, b in zip(g0, g1):
+        assert np.array_equal(a["p"], b["p"]) and not np.array_equal(a["t"], b["t"])
+
+
+def test_4k_decimate1_batch(built):
+    """3840x2160 at decimate 1 in a batch: clusters may exceed the LDS key array (3(2W+2H) = 36000 points), so the
+    last size class sorts in its global scratch slot; the handle's memory stays bounded (no per-point moment
+    arrays).  Detections bit-identical to the oracle."""
+    img, K, truth, size = synth.scene_c3(seed=77, sigma=2.0)
+    img2 = synth.scene_c3(seed=78, sigma=2.0)[0]
+    det = AprilTagDetector(3840, 2160, intrinsics=_k4(K), tag_size=size, max_batch=4)
+    assert det.device_bytes() < 4 * 700e6
+    batch = torch.from_numpy(np.stack([img, img2, img, img2])).cuda()
+    r = det.detect_batch_ex(batch, max_dets=128)
+    assert det.frame_flags(4) == [0, 0, 0, 0]
+    det.close()
+    for f, im in ((0, img), (1, img2)):
+        o = po.detect(im, params=pu.oracle_params(K, 1, size))[0]
+        assert sorted(d["id"] for d in o) == list(range(100))
+        assert not pu.compare_detections(r[f], o)
+        assert not pu.compare_detections(r[f + 2], o)
 
 
 def test_batch_properties_full_size(built):
@@ -268,7 +334,23 @@ def test_node_shell_pol_and_mono8(built):
     assert n.on_frame(img.ctypes.data, False, "mono8", 1920, 1080, 1920, K9, stamp=(1, 0), info_stamp=(1, 5)) == (None, None)
     with pytest.raises(RuntimeError):
         n.on_frame(img.ctypes.data, False, "yuv422", 1920, 1080, 1920 * 2, K9)
+    # a later frame of another size (or a step too small for its width) is dropped before any device write
+    big = np.zeros((1200, 2048, 3), dtype=np.uint8)
+    assert n.on_frame(big.ctypes.data, False, "bgr8", 2048, 1200, 2048 * 3, K9)[0] == []
+    assert n.on_frame(bgr.ctypes.data, False, "bgr8", 1920, 1080, 1920 * 2, K9)[0] == []
+    d4, _ = n.on_frame(bgr.ctypes.data, False, "bgr8", 1920, 1080, 1920 * 3, K9)
+    assert d4 == dets                                      # the node keeps working afterwards
     n.close()
+    # VPI-mode node (any backend list other than exactly CUDA) passes the skew K[1] on
+    K9s = list(K9)
+    K9s[1] = 4.0
+    nv = nd.AprilTagNode(backends="CUDA,CPU")
+    dv, _ = nv.on_frame(img.ctypes.data, False, "mono8", 1920, 1080, 1920, K9s)
+    nc = nd.AprilTagNode(backends="CUDA")
+    dc, _ = nc.on_frame(img.ctypes.data, False, "mono8", 1920, 1080, 1920, K9s)
+    assert dv[0]["corners"] == dc[0]["corners"] and dv[0]["position"] != dc[0]["position"]
+    assert dc[0]["position"] == dets[0]["position"]        # cuAprilTags mode has no skew term
+    nv.close(); nc.close()
 
 
 @pytest.mark.parametrize("shape", [(4, 4), (8, 8), (16, 20), (5, 7), (64, 4)])
@@ -292,6 +374,12 @@ def test_create_rejects_unsupported_sizes(built):
     cam = capi.Intrinsics(100, 100, 1, 1)
     assert L.amdCreateAprilTagsDetector(C.byref(h), 3, 3, 4, 0, C.byref(cam), 0.1) == 2       # smaller than one tile
     assert L.amdCreateAprilTagsDetector(C.byref(h), 10000, 100, 4, 0, C.byref(cam), 0.1) == 2  # 2x+1 must fit 14 bits
+    with pytest.raises(capi.AprilTagsError) as e:
+        AprilTagDetector(640, 480, decimate=5)             # the threshold loader exists for decimate 1..4
+    assert e.value.code == 2
+    with pytest.raises(capi.AprilTagsError) as e:
+        AprilTagDetector(640, 480, max_hamming=4)
+    assert e.value.code == 1
 
 
 def test_max_tags_truncation_and_order(built):
@@ -358,10 +446,10 @@ def test_front_steps_bit_exact(built):
     ref = po.resize_mono8(img, 1920, 1080)
     assert np.array_equal(dst.cpu().numpy(), ref)
     Ks = np.array([[2000.0, 0, 960.0], [0, 2000.0, 540.0], [0, 0, 1]])
-    det = AprilTagDetector(1920, 1080, families=("synth36h11",), intrinsics=_k4(Ks), tag_size=size, max_batch=1)
+    det = AprilTagDetector(1920, 1080, families=("tag36h11",), intrinsics=_k4(Ks), tag_size=size, max_batch=1)
     g = det.detect_batch_ex(dst, max_dets=128)[0]
     det.close()
-    o, _ = po.detect(ref, families=("synth36h11",), params=pu.oracle_params(Ks, 1, size))
+    o, _ = po.detect(ref, families=("tag36h11",), params=pu.oracle_params(Ks, 1, size))
     assert not pu.compare_detections(g, o) and len(g) == 100
     # odd sizes, up- and down-scaling
     rng = np.random.default_rng(2)

@@ -1,5 +1,9 @@
 """Constructor validation of the node shell -- the three cases of the reference's gtest
-(isaac_ros_apriltag/test/apriltag_node_test.cpp:29-89).  Pure host logic, no GPU."""
+(isaac_ros_apriltag/test/apriltag_node_test.cpp:29-89) plus the backend-list semantics of
+test/isaac_ros_apriltag_backends_compare_test.py:33-37.  Pure host logic, no GPU.
+
+Reference behaviour mirrored: backends == exactly "CUDA" selects cuAprilTags, which decodes tag36h11 only
+(src/apriltag_node.cpp:429-432,575-582); any other backend list selects VPI with its family table (:47-58)."""
 import pytest
 
 from isaac_ros_apriltag_amd import build as b
@@ -19,30 +23,53 @@ def node_mod():
     return node
 
 
+def _have_36h10():
+    return capi.lib().amdAprilTagsFamilyFromName(b"tag36h10") >= 0
+
+
 def test_invalid_tag_family(node_mod):
-    with pytest.raises(RuntimeError) as e:
-        node_mod.AprilTagNode(tag_family="NOTHING")
-    assert MSG in str(e.value)
+    # apriltag_node_test.cpp:29-49
+    for backends in ("CUDA", "CPU"):
+        with pytest.raises(RuntimeError) as e:
+            node_mod.AprilTagNode(tag_family="NOTHING", backends=backends)
+        assert MSG in str(e.value)
 
 
 def test_unsupported_tag_family(node_mod):
-    # tag36h10 is a family string the reference knows, but this backend has no codebook for it
+    # apriltag_node_test.cpp:51-72: tag36h10 on the default (CUDA = cuAprilTags) backend
     with pytest.raises(RuntimeError) as e:
         node_mod.AprilTagNode(tag_family="tag36h10")
     assert MSG in str(e.value) and "'tag_family' parameter must be one of:" in str(e.value)
+    assert "tag36h11" in str(e.value)           # the message lists what the backend supports
 
 
-def test_supported_tag_family_and_defaults(node_mod):
-    for fam in ("tag36h11", "tag25h9", "tag16h5"):
-        n = node_mod.AprilTagNode(tag_family=fam)
-        n.close()
-    n = node_mod.AprilTagNode()          # defaults: max_tags 64, size 0.22, tile_size 4, tag36h11
+def test_supported_tag_family(node_mod):
+    # apriltag_node_test.cpp:74-89: tag36h10 with backends:=CPU (the VPI path) constructs
+    if not _have_36h10():
+        pytest.skip("tag36h10 table not built in")
+    node_mod.AprilTagNode(tag_family="tag36h10", backends="CPU").close()
+
+
+def test_defaults_and_vpi_families(node_mod):
+    n = node_mod.AprilTagNode()          # defaults: max_tags 64, size 0.22, tile_size 4, tag36h11, CUDA
     assert n.max_tags == 64
     n.close()
+    for fam in ("tag36h11", "tag25h9", "tag16h5"):
+        for backends in ("CPU", "PVA", "CUDA,CPU", "CPU, CUDA", "HIP"):   # comma lists as in backends_compare_test.py
+            node_mod.AprilTagNode(tag_family=fam, backends=backends).close()
+    # cuAprilTags mode: tag36h11 only
+    for fam in ("tag25h9", "tag16h5"):
+        with pytest.raises(RuntimeError) as e:
+            node_mod.AprilTagNode(tag_family=fam, backends="CUDA")
+        assert MSG in str(e.value)
+    # families the reference's VPI table names but this library has no codebook for
+    for fam in ("circle21h7", "standard41h12"):
+        with pytest.raises(RuntimeError) as e:
+            node_mod.AprilTagNode(tag_family=fam, backends="CPU")
+        assert MSG in str(e.value)
 
 
-def test_backend_without_implementation(node_mod):
-    # the reference routes 'CPU'/'PVA' to VPI; this build has only the HIP detector and no CPU fallback
+def test_unknown_backend_name(node_mod):
     with pytest.raises(RuntimeError) as e:
-        node_mod.AprilTagNode(tag_family="tag36h11", backends="CPU")
-    assert MSG in str(e.value)
+        node_mod.AprilTagNode(backends="TPU")
+    assert "Unrecognized backend" in str(e.value)

@@ -33,43 +33,6 @@ def _quat_wxyz(R):
     return q / np.linalg.norm(q)
 
 
-def test_family_tables_stride_property(built):
-    P = 982451653
-    for name, nbits in (("tag36h11", 36), ("tag25h9", 25), ("tag16h5", 16)):
-        codes, d = po.family_codes(name)
-        assert d * d == nbits
-        inv = pow(P, -1, 1 << nbits)
-        ks = [((c - codes[0]) * inv) & ((1 << nbits) - 1) for c in codes]
-        assert all(b > a for a, b in zip(ks, ks[1:])), name
-    assert len(po.family_codes("tag25h9")[0]) == 35 and len(po.family_codes("tag16h5")[0]) == 30
-    s36, _ = po.family_codes("synth36h11")
-    assert s36[:27] == po.family_codes("tag36h11")[0]
-
-
-def test_family_min_hamming(built):
-    def rot(w, d):
-        o = 0
-        nb = d * d
-        for r in range(d):
-            for c in range(d):
-                if (w >> (nb - 1 - (c * d + (d - 1 - r)))) & 1:
-                    o |= 1 << (nb - 1 - (r * d + c))
-        return o
-    for name, hmin in (("tag36h11", 11), ("tag25h9", 9), ("tag16h5", 5), ("synth36h11", 11)):
-        codes, d = po.family_codes(name)
-        codes = codes[:120]
-        rots = []
-        for c in codes:
-            r1 = rot(c, d); r2 = rot(r1, d); r3 = rot(r2, d)
-            rots.append((c, r1, r2, r3))
-        best = 99
-        for i in range(len(codes)):
-            for j in range(i + 1, len(codes)):
-                for r in rots[j]:
-                    best = min(best, bin(codes[i] ^ r).count("1"))
-        assert best >= hmin, (name, best)
-
-
 def test_pol_golden_vector(built):
     """Reference golden numbers, reference tolerances (2 px, 0.01 m, 0.01)."""
     img, K, truth = synth.scene_pol_golden()
@@ -257,7 +220,7 @@ def test_front_steps_resize_and_rectify(built):
     assert (po.resize_mono8(np.full((40, 60), 99, dtype=np.uint8), 17, 23) == 99).all()
     img, K, truth, size = synth.scene_c3()
     small = po.resize_mono8(img, 1920, 1080)
-    dets, _ = po.detect(small, families=("synth36h11",), params=po.default_params(fx=2000, fy=2000, cx=960, cy=540, tag_size=size))
+    dets, _ = po.detect(small, families=("tag36h11",), params=po.default_params(fx=2000, fy=2000, cx=960, cy=540, tag_size=size))
     assert sorted(d["id"] for d in dets) == list(range(100))
     img1, K1, _ = synth.scene_c1()
     assert np.array_equal(po.rectify_mono8(img1, K1, [0, 0, 0, 0, 0], K1), img1)

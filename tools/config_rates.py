@@ -36,4 +36,4 @@ rate("config 2, decimate 2 (sigma 2)", c2, K2, ("tag36h11",), 2, 0.22, 64)
 c5 = [synth.scene_c5(seed=1234 + i)[0] for i in range(8)]
 rate("config 5, two families (sigma 2)", c5, K2, ("tag36h11", "tag25h9"), 1, 0.22, 64)
 img3, K3, _, size3 = synth.scene_c3()
-rate("config 3, 4K 100 tags, decimate 2", [img3, synth.scene_c3(seed=78)[0]], K3, ("synth36h11",), 2, size3, 32)
+rate("config 3, 4K 100 tags, decimate 2", [img3, synth.scene_c3(seed=78)[0]], K3, ("tag36h11",), 2, size3, 32)
