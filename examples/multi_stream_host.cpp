@@ -1,0 +1,182 @@
+// multi_stream_host.cpp -- C++ front end for BASELINE.json configs[3]: independent camera streams sharded over the GPUs
+// of one node, one detector handle and one host thread per GPU, and exactly one collective: an RCCL broadcast (over
+// xGMI) of the per-stream parameter block -- intrinsics, tag size, decimation -- from device 0 at start-up.
+//
+// Frames are independent units (the reference handles one frame at a time with no cross-frame state,
+// isaac_ros_apriltag/src/apriltag_node.cpp:613-623), so stream s is owned by GPU s % G and the data path needs no
+// collective; results return by per-GPU D2H inside amdAprilTagsDetectBatch.  Single process, one communicator over the
+// local devices (ncclCommInitAll), no MPI -- SURVEY.md section 8(e).
+//
+//   hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude examples/multi_stream_host.cpp \
+//         -Lisaac_ros_apriltag_amd -lapriltag_amd -lrccl -Wl,-rpath,$PWD/isaac_ros_apriltag_amd -o examples/multi_stream_host
+//   python tools/dump_streams.py streams.bin            # frames + per-stream parameters (same generator as bench.py)
+//   ./examples/multi_stream_host streams.bin [gpus] [steps]
+//
+// Input file: int32 magic 'ATS1', streams S, frames-per-stream F, width, height, decimate; then S records of five
+// doubles {fx, fy, cx, cy, tag_size}; then S*F mono8 frames.  Output: one JSON line with the whole-job frame rate and,
+// per stream, the detection count and an FNV-1a checksum of (id, corners) that tests/test_gpu_parity.py compares with
+// the Python path.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "apriltag_amd.h"
+
+#define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(3); } } while (0)
+#define CHECK_NCCL(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "%s: %s\n", #x, ncclGetErrorString(r_)); exit(4); } } while (0)
+#define CHECK_AT(x) do { int r_ = (x); if (r_ != 0) { fprintf(stderr, "%s: error code %d\n", #x, r_); exit(5); } } while (0)
+
+struct StreamParams { double fx, fy, cx, cy, tag_size; };
+
+struct Barrier {   // reusable spin barrier for the few host threads
+  std::atomic<int> count{0}, gen{0};
+  int n;
+  explicit Barrier(int n_) : n(n_) {}
+  void wait() {
+    const int g = gen.load();
+    if (count.fetch_add(1) + 1 == n) { count.store(0); gen.fetch_add(1); }
+    else while (gen.load() == g) std::this_thread::yield();
+  }
+};
+
+static uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
+  const unsigned char* b = static_cast<const unsigned char*>(p);
+  for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001B3ull; }
+  return h;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "usage: %s streams.bin [gpus] [steps]\n", argv[0]); return 2; }
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) { perror(argv[1]); return 2; }
+  int32_t hdr[6];
+  if (fread(hdr, 4, 6, f) != 6 || hdr[0] != 0x31535441) { fprintf(stderr, "bad header\n"); return 2; }
+  const int S = hdr[1], F = hdr[2], W = hdr[3], H = hdr[4], decimate = hdr[5];
+  std::vector<StreamParams> params(S);
+  if (fread(params.data(), sizeof(StreamParams), S, f) != (size_t)S) { fprintf(stderr, "short file\n"); return 2; }
+  const size_t fbytes = (size_t)W * H;
+  std::vector<uint8_t> frames((size_t)S * F * fbytes);
+  if (fread(frames.data(), 1, frames.size(), f) != frames.size()) { fprintf(stderr, "short file\n"); return 2; }
+  fclose(f);
+
+  int ndev = 0;
+  CHECK_HIP(hipGetDeviceCount(&ndev));
+  int G = argc > 2 ? atoi(argv[2]) : ndev;
+  if (G < 1 || G > ndev) { fprintf(stderr, "%d GPUs requested, %d visible\n", G, ndev); return 2; }
+  const int steps = argc > 3 ? atoi(argv[3]) : 5;
+
+  // ---- the one collective: broadcast of the parameter block from device 0 (RCCL over xGMI) ---------------------
+  std::vector<int> devs(G);
+  for (int i = 0; i < G; i++) devs[i] = i;
+  std::vector<ncclComm_t> comms(G);
+  CHECK_NCCL(ncclCommInitAll(comms.data(), G, devs.data()));
+  std::vector<hipStream_t> streams(G);
+  std::vector<double*> d_block(G);
+  const size_t block_doubles = (size_t)S * 5 + 1;   // parameters + decimate
+  for (int i = 0; i < G; i++) {
+    CHECK_HIP(hipSetDevice(i));
+    CHECK_HIP(hipStreamCreate(&streams[i]));
+    CHECK_HIP(hipMalloc((void**)&d_block[i], block_doubles * 8));
+    CHECK_HIP(hipMemset(d_block[i], 0, block_doubles * 8));
+  }
+  {
+    std::vector<double> host(block_doubles);
+    memcpy(host.data(), params.data(), (size_t)S * 5 * 8);
+    host[(size_t)S * 5] = (double)decimate;
+    CHECK_HIP(hipSetDevice(0));
+    CHECK_HIP(hipMemcpy(d_block[0], host.data(), block_doubles * 8, hipMemcpyHostToDevice));   // only device 0 holds it
+  }
+  CHECK_NCCL(ncclGroupStart());
+  for (int i = 0; i < G; i++) {
+    CHECK_HIP(hipSetDevice(i));
+    CHECK_NCCL(ncclBroadcast(d_block[i], d_block[i], block_doubles, ncclDouble, 0, comms[i], streams[i]));
+  }
+  CHECK_NCCL(ncclGroupEnd());
+  for (int i = 0; i < G; i++) { CHECK_HIP(hipSetDevice(i)); CHECK_HIP(hipStreamSynchronize(streams[i])); }
+
+  // ---- one host thread, one handle, one share of the streams per GPU ------------------------------------------
+  Barrier bar(G);
+  std::vector<double> seconds(G, 0.0);
+  std::vector<uint64_t> sums(S, 0);
+  std::vector<uint32_t> ndet(S, 0);
+  const uint32_t max_tags = 64;
+  auto worker = [&](int g) {
+    CHECK_HIP(hipSetDevice(g));
+    // this GPU's copy of the block, as received through the broadcast
+    std::vector<double> blk(block_doubles);
+    CHECK_HIP(hipMemcpy(blk.data(), d_block[g], block_doubles * 8, hipMemcpyDeviceToHost));
+    std::vector<int> mine;
+    for (int s = 0; s < S; s++) if (s % G == g) mine.push_back(s);
+    const uint32_t B = (uint32_t)(mine.size() * F);
+    if (B == 0) { bar.wait(); bar.wait(); return; }
+    amdAprilTagsConfig_t cfg;
+    amdAprilTagsDefaultConfig(&cfg, (uint32_t)W, (uint32_t)H);
+    cfg.decimate = (uint32_t)blk[(size_t)S * 5];
+    cfg.max_batch = B;
+    cfg.device = g;
+    cfg.tag_size = (float)blk[(size_t)mine[0] * 5 + 4];
+    amdAprilTagsHandle h = nullptr;
+    CHECK_AT(amdCreateAprilTagsDetectorEx(&h, &cfg));
+    uint8_t* d_frames = nullptr;
+    CHECK_HIP(hipMalloc((void**)&d_frames, (size_t)B * fbytes));
+    std::vector<amdAprilTagsImageInput_t> imgs(B);
+    std::vector<amdAprilTagsCameraIntrinsics_t> intr(B);
+    for (size_t k = 0; k < mine.size(); k++) {
+      const int s = mine[k];
+      CHECK_HIP(hipMemcpy(d_frames + k * F * fbytes, frames.data() + (size_t)s * F * fbytes, (size_t)F * fbytes, hipMemcpyHostToDevice));
+      for (int i = 0; i < F; i++) {
+        const size_t b = k * F + i;
+        imgs[b] = {(uint32_t)W, (uint32_t)H, d_frames + b * fbytes, (size_t)W};
+        intr[b] = {(float)blk[(size_t)s * 5 + 0], (float)blk[(size_t)s * 5 + 1], (float)blk[(size_t)s * 5 + 2], (float)blk[(size_t)s * 5 + 3]};
+      }
+    }
+    std::vector<amdAprilTagsID_t> tags((size_t)B * max_tags);
+    std::vector<uint32_t> cnt(B);
+    CHECK_AT(amdAprilTagsDetectBatch(h, B, imgs.data(), intr.data(), tags.data(), cnt.data(), max_tags, nullptr));   // warm-up
+    bar.wait();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0; it < steps; it++)
+      CHECK_AT(amdAprilTagsDetectBatch(h, B, imgs.data(), intr.data(), tags.data(), cnt.data(), max_tags, nullptr));
+    seconds[g] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    bar.wait();
+    for (size_t k = 0; k < mine.size(); k++) {
+      uint64_t hsh = 0xCBF29CE484222325ull;
+      uint32_t n = 0;
+      for (int i = 0; i < F; i++) {
+        const size_t b = k * F + i;
+        for (uint32_t d = 0; d < cnt[b]; d++) {
+          const amdAprilTagsID_t& t = tags[b * max_tags + d];
+          hsh = fnv1a(hsh, &t.id, sizeof(t.id));
+          hsh = fnv1a(hsh, t.corners, sizeof(t.corners));
+          hsh = fnv1a(hsh, t.translation, sizeof(t.translation));
+        }
+        n += cnt[b];
+      }
+      sums[mine[k]] = hsh;
+      ndet[mine[k]] = n;
+    }
+    CHECK_HIP(hipFree(d_frames));
+    CHECK_AT(amdAprilTagsDestroy(h));
+  };
+  std::vector<std::thread> th;
+  for (int g = 0; g < G; g++) th.emplace_back(worker, g);
+  for (auto& t : th) t.join();
+  double worst = 0;
+  for (double s : seconds) worst = s > worst ? s : worst;
+  for (int i = 0; i < G; i++) { CHECK_HIP(hipSetDevice(i)); (void)hipFree(d_block[i]); (void)hipStreamDestroy(streams[i]); ncclCommDestroy(comms[i]); }
+
+  printf("{\"gpus\": %d, \"streams\": %d, \"frames_per_stream\": %d, \"steps\": %d, \"fps\": %.1f, \"collective\": \"ncclBroadcast of %zu doubles\", \"streams_out\": [",
+         G, S, F, steps, worst > 0 ? (double)S * F * steps / worst : 0.0, block_doubles);
+  for (int s = 0; s < S; s++) printf("%s{\"stream\": %d, \"gpu\": %d, \"detections\": %u, \"fnv\": \"%016llx\"}", s ? ", " : "", s, s % G, ndet[s], (unsigned long long)sums[s]);
+  printf("]}\n");
+  return 0;
+}

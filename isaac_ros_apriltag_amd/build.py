@@ -3,6 +3,7 @@
   libapriltag_amd.so    HIP kernels + C ABI (hipcc, gfx950 only)         <- csrc/detector.hip
   libapriltag_synth.so  deterministic frame renderer (host C)            <- csrc/synth_render.c
   libapriltag_node.so   ROS-free C++ mirror of the reference node shell  <- csrc/node_shell.cpp (if present)
+  examples/multi_stream_host   C++ multi-GPU front end (RCCL broadcast)  <- examples/multi_stream_host.cpp
 """
 import os
 import shutil
@@ -66,10 +67,25 @@ def build_node(force=False):
     return LIB_NODE
 
 
+HOST_BIN = os.path.join(os.path.dirname(_HERE), "examples", "multi_stream_host")
+
+
+def build_host(force=False):
+    """C++ multi-GPU front end (one handle per device, RCCL broadcast of the parameter block)."""
+    src = os.path.join(os.path.dirname(_HERE), "examples", "multi_stream_host.cpp")
+    if not os.path.exists(src):
+        return None
+    if force or _newer(HOST_BIN, [src, LIB_AMD] + _sources(".h")):
+        subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(os.path.dirname(_HERE), "include"),
+                               src, "-L" + _HERE, "-lapriltag_amd", "-lrccl", "-Wl,-rpath," + _HERE, "-o", HOST_BIN])
+    return HOST_BIN
+
+
 def build_all(force=False):
     build_synth(force)
     build_amd(force)
     build_node(force)
+    build_host(force)
 
 
 if __name__ == "__main__":

@@ -108,6 +108,8 @@ struct FqClass {
   int slot_cap;
   int pop;                                // clusters taken from the work list per atomic
   double* d_lf = nullptr;                 // grid x slot_cap x 6 doubles
+  double* d_errs = nullptr;               // grid x slot_cap x 2 doubles: error arrays of clusters that exceed what the
+                                          // kernel keeps in LDS / registers (slot_cap > 16 x nt, or > sort_cap)
 };
 
 struct amdAprilTagsDetector_st {
@@ -136,7 +138,6 @@ struct amdAprilTagsDetector_st {
   uint32_t* d_work = nullptr;        // work lists of the quad fit (all classes, FqWorkLayout)
   uint32_t* d_workctl = nullptr;     // [0..7] items per class, [8..15] pop cursors
   unsigned long long* d_keys_scr = nullptr;  // only when a cluster can exceed the LDS key array (large images)
-  double* d_errs_scr = nullptr;
   QuadRec* d_quads = nullptr;
   DetRec* d_dets = nullptr;
   DetRec* d_out = nullptr;
@@ -253,8 +254,8 @@ const char* amdAprilTagsStageName(uint32_t stage) { return stage < AMDAT_NUM_STA
 static void free_all(amdAprilTagsDetector_st* D) {
   hipFree(D->d_gray); hipFree(D->d_thr); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_roots); hipFree(D->d_hkeys);
   hipFree(D->d_hcnt); hipFree(D->d_hoff); hipFree(D->d_stage); hipFree(D->d_rank); hipFree(D->d_pts); hipFree(D->d_clusters);
-  hipFree(D->d_work); hipFree(D->d_workctl); hipFree(D->d_keys_scr); hipFree(D->d_errs_scr); hipFree(D->d_quads);
-  for (auto& c : D->cls) hipFree(c.d_lf);
+  hipFree(D->d_work); hipFree(D->d_workctl); hipFree(D->d_keys_scr); hipFree(D->d_quads);
+  for (auto& c : D->cls) { hipFree(c.d_lf); hipFree(c.d_errs); }
   hipFree(D->d_fqprof);
   hipFree(D->d_dets); hipFree(D->d_out); hipFree(D->d_order); hipFree(D->d_counters); hipFree(D->d_frames);
   for (int i = 0; i < AT_MAX_FAMILIES; i++) hipFree(D->d_codes[i]);
@@ -392,12 +393,16 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   alloc((void**)&D->d_clusters, B * (size_t)P.ccap * sizeof(ClusterRec));
   alloc((void**)&D->d_work, ((size_t)D->work_layout.off[FQ_NCLS - 1] + D->work_layout.cap[FQ_NCLS - 1]) * 4);
   alloc((void**)&D->d_workctl, 16 * 4);
-  for (int k = 0; k < FQ_NCLS; k++)
-    if (P.max_cluster_points > D->cls[k].lo) alloc((void**)&D->cls[k].d_lf, (size_t)D->cls[k].grid * D->cls[k].slot_cap * 48);
+  for (int k = 0; k < FQ_NCLS; k++) {
+    FqClass& c = D->cls[k];
+    if (P.max_cluster_points <= c.lo) continue;
+    alloc((void**)&c.d_lf, (size_t)c.grid * c.slot_cap * 48);
+    // smoothed errors stay in registers up to FQ_SMOOTH_REGS points per thread; larger clusters need a second array
+    if (c.slot_cap > FQ_SMOOTH_REGS * c.nt || c.slot_cap > c.sort_cap) alloc((void**)&c.d_errs, (size_t)c.grid * c.slot_cap * 16);
+  }
   if (D->cls[FQ_NCLS - 1].slot_cap > D->cls[FQ_NCLS - 1].sort_cap) {   // clusters beyond the LDS key array exist
     const FqClass& c = D->cls[FQ_NCLS - 1];
     alloc((void**)&D->d_keys_scr, (size_t)c.grid * c.slot_cap * 8);
-    alloc((void**)&D->d_errs_scr, (size_t)c.grid * c.slot_cap * 16);
   }
   alloc((void**)&D->d_quads, B * (size_t)P.qcap * sizeof(QuadRec));
   alloc((void**)&D->d_dets, B * (size_t)P.dcap * sizeof(DetRec));
@@ -594,7 +599,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
       }
       const bool big = c == FQ_NCLS - 1;
 #define FQ_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work + D->work_layout.off[c], D->d_workctl + c,                   \
-                D->work_layout.cap[c], D->d_workctl + 8 + c, cl.d_lf, (big ? D->d_keys_scr : nullptr), (big ? D->d_errs_scr : nullptr), \
+                D->work_layout.cap[c], D->d_workctl + 8 + c, cl.d_lf, (big ? D->d_keys_scr : nullptr), cl.d_errs,                        \
                 D->d_quads, D->d_counters, (D->fq_counters ? D->d_fqprof + 8 * c : nullptr), cl.sort_cap, cl.slot_cap, cl.pop, P
       if (cl.nt == 64) hipLaunchKernelGGL(k_fit_quads<64>, grid, dim3(64), lds, sc, FQ_ARGS);
       else if (cl.nt == 128) hipLaunchKernelGGL(k_fit_quads<128>, grid, dim3(128), lds, sc, FQ_ARGS);

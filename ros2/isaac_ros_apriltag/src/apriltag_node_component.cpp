@@ -45,7 +45,7 @@ public:
     opt.size = declare_parameter<double>("size", 0.22);
     opt.tile_size = declare_parameter<uint16_t>("tile_size", 4);
     opt.tag_family = declare_parameter<std::string>("tag_family", "tag36h11");
-    opt.backends = declare_parameter<std::string>("backends", "CUDA");  // "CUDA" | "HIP" | "GPU"
+    opt.backends = declare_parameter<std::string>("backends", "CUDA");  // name or comma list; exactly "CUDA" = cuAprilTags mode
     opt.decimate = static_cast<uint32_t>(declare_parameter<int>("decimate", 1));
     // throws std::runtime_error("Tag family not supported by specified backend ...") like the reference
     impl_ = std::make_unique<shell::AprilTagNode>(opt);

@@ -538,6 +538,47 @@ def test_checkerboard_more_quads_than_the_old_fixed_capacity(built):
     assert nq > 8192
 
 
+def test_cpp_multi_stream_host(built, tmp_path):
+    """examples/multi_stream_host.cpp: one handle per GPU, ncclBroadcast of the per-stream parameter block, streams
+    sharded s % G.  On this 1-GPU box G = 1; every stream's records must equal the Python path's, byte for byte."""
+    import subprocess
+    import sys
+    from isaac_ros_apriltag_amd import build as b
+    from isaac_ros_apriltag_amd import streams
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import dump_streams
+    exe = b.HOST_BIN
+    assert os.path.exists(exe), "examples/multi_stream_host was not built (isaac_ros_apriltag_amd.build.build_host)"
+    path = str(tmp_path / "streams.bin")
+    S, F = 3, 2
+    block = dump_streams.dump(path, S, F, 0.0, 1)
+    out = subprocess.run([exe, path, "1", "2"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["gpus"] == 1 and rec["streams"] == S and len(rec["streams_out"]) == S
+
+    def fnv(h, data):
+        for byte in data:
+            h = ((h ^ byte) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+        return h
+    for s in range(S):
+        sp = streams.stream_params(block, s)
+        frames = np.stack([synth.scene_c2(seed=int(sp["seed"]) + i, sigma=0.0)[0] for i in range(F)])
+        det = AprilTagDetector(1920, 1080, intrinsics=(sp["fx"], sp["fy"], sp["cx"], sp["cy"]), tag_size=sp["tag_size"], max_batch=F)
+        tags, cnt = det.detect_batch_raw(torch.from_numpy(frames).cuda(), max_tags=64)
+        det.close()
+        h = 0xCBF29CE484222325
+        for i in range(F):
+            for d in range(cnt[i]):
+                t = tags[i * 64 + d]
+                h = fnv(h, int(t.id).to_bytes(2, "little"))
+                h = fnv(h, bytes(t.corners))
+                h = fnv(h, bytes(t.translation))
+        o = rec["streams_out"][s]
+        assert o["detections"] == sum(cnt) == 10 * F
+        assert o["fnv"] == "%016x" % h, (s, o)
+
+
 def test_c99_example_runs(built, tmp_path):
     """The plain-C example host (examples/detect_one.c) detects the config-1 tag from a PGM file."""
     import subprocess

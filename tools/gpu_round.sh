@@ -6,7 +6,12 @@ TAG=${1:-run}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-echo "== pytest -m gpu" | tee $OUT/summary.txt
+echo "== quick parity check" | tee $OUT/summary.txt
+timeout 400 python tools/gpu_check.py > $OUT/gpu_check.log 2>&1
+RC=$?
+grep -E "PARITY|MISMATCH|ALL OK|FAILURES|fault|batch 16" $OUT/gpu_check.log | cut -c1-200 | tee -a $OUT/summary.txt
+if [ $RC -ne 0 ]; then echo "quick check failed (exit $RC): stopping here" | tee -a $OUT/summary.txt; tail -30 $OUT/gpu_check.log | cut -c1-300 | tee -a $OUT/summary.txt; exit 0; fi
+echo "== pytest -m gpu" | tee -a $OUT/summary.txt
 timeout 900 python -m pytest tests -m gpu -q --maxfail=8 -x -p no:cacheprovider > $OUT/pytest.log 2>&1
 echo "pytest exit $?" | tee -a $OUT/summary.txt
 tail -5 $OUT/pytest.log | tee -a $OUT/summary.txt
