@@ -126,7 +126,7 @@ typedef struct {
   uint32_t max_hamming;        /* 2 */
   float decode_sharpening;     /* 0.25 */
   /* capacities per frame; 0 = defaults derived from the image size */
-  uint32_t max_points;         /* boundary points; default 1.25 per working pixel (hard bound: 2 per pixel) */
+  uint32_t max_points;         /* boundary points; default 2 per working pixel */
   uint32_t hash_slots;         /* power of two */
   uint32_t max_clusters;
   uint32_t max_quads;

@@ -50,6 +50,17 @@ def build_amd(force=False):
     return LIB_AMD
 
 
+def build_amd_variant(tag, defines):
+    """Measurement builds for tools/ (e.g. -DAMDAT_FQ_PROFILE: per-phase cycle counters in the quad-fit kernel).
+    The product library carries none of this; the variant is written next to it as libapriltag_amd_<tag>.so."""
+    out = os.path.join(_HERE, "libapriltag_amd_%s.so" % tag)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-fno-fast-math", "-Wno-unused-value", "-Wno-unused-function"] + ["-D" + d for d in defines] + \
+          [os.path.join(_CSRC, "detector.hip"), "-o", out]
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_synth(force=False):
     src = os.path.join(_CSRC, "synth_render.c")
     if force or _newer(LIB_SYNTH, [src] + _sources(".h")):

@@ -80,6 +80,7 @@ struct DetParams {
   int refine_edges;
   int max_hamming;
   int nfam;
+  int split_moments;  // moment sums carried as two doubles (exact while terms < 2^31 and clusters < 2^15 points)
   double cos_critical_rad;
   double max_line_fit_mse;
   double decode_sharpening;

@@ -311,6 +311,9 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   P.min_cluster_points = 24;
   P.max_cluster_points = 3 * (2 * W + 2 * H);
   P.max_nmaxima = 10;
+  // exactness bounds of the two-double moment sums (kernels_quad.h, split_term): W * x * x < 2^31, < 2^15 points
+  P.split_moments = (W <= 2048 && H <= 2048 && P.max_cluster_points < 32768) ? 1 : 0;
+  if (getenv("AMDAT_NO_SPLIT_MOMENTS")) P.split_moments = 0;   // A/B switch for tools/ only; both paths give identical bits
   P.refine_edges = cfg.refine_edges ? 1 : 0;
   P.max_hamming = (int)cfg.max_hamming;
   P.nfam = (int)cfg.num_families;
@@ -330,10 +333,11 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   if (min_tag_width < 3) min_tag_width = 3;
   P.min_tag_width = min_tag_width;
   const uint32_t npx = (uint32_t)W * (uint32_t)H;
-  // Boundary points per frame: the hard bound is 2 per pixel; frames that binarise completely (noise on every
-  // 4x4 tile) measure ~0.85 per pixel, so the default capacity is 1.25 per pixel and an overflow is reported
-  // per frame (AMDAT_FLAG_POINTS_OVERFLOW), never silent.  max_points = 2 * pixels restores the hard bound.
-  P.pcap = cfg.max_points ? cfg.max_points : npx + npx / 4;
+  // Boundary points per frame: 2 per pixel covers every content the fuzzer produces (thin diagonal lines come
+  // closest); frames that binarise completely (noise on every 4x4 tile) measure ~0.85 per pixel.  A smaller
+  // max_points trades memory (16 bytes per point and batch slot) for the chance of a reported overflow
+  // (AMDAT_FLAG_POINTS_OVERFLOW) on adversarial content.
+  P.pcap = cfg.max_points ? cfg.max_points : 2u * npx;
   P.hcap = cfg.hash_slots ? next_pow2(cfg.hash_slots) : next_pow2(npx / 8 > 4096 ? npx / 8 : 4096);
   if (P.hcap < 256) P.hcap = 256;
   { uint32_t lg = 0; while ((1u << lg) < P.hcap) lg++; P.hshift = 64 - lg; }
@@ -569,10 +573,11 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
     // keys | pair-table region
     auto lds_bytes = [](const FqClass& c) { return (size_t)c.sort_cap * 8 + (size_t)FQ_TABLE_DOUBLES * 8; };
     if (!D->fq_attr_set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 157000));
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150000));
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 150000));
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fit_quads<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150000));
+      const void* fns[8] = {reinterpret_cast<const void*>(k_fit_quads<512, false>), reinterpret_cast<const void*>(k_fit_quads<256, false>),
+                            reinterpret_cast<const void*>(k_fit_quads<128, false>), reinterpret_cast<const void*>(k_fit_quads<64, false>),
+                            reinterpret_cast<const void*>(k_fit_quads<512, true>), reinterpret_cast<const void*>(k_fit_quads<256, true>),
+                            reinterpret_cast<const void*>(k_fit_quads<128, true>), reinterpret_cast<const void*>(k_fit_quads<64, true>)};
+      for (const void* fn : fns) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 157000));
       D->fq_attr_set = true;
     }
     // The classes are independent (they only append to the quad list), so they run concurrently.  The
@@ -601,10 +606,14 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
 #define FQ_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work + D->work_layout.off[c], D->d_workctl + c,                   \
                 D->work_layout.cap[c], D->d_workctl + 8 + c, cl.d_lf, (big ? D->d_keys_scr : nullptr), cl.d_errs,                        \
                 D->d_quads, D->d_counters, (D->fq_counters ? D->d_fqprof + 8 * c : nullptr), cl.sort_cap, cl.slot_cap, cl.pop, P
-      if (cl.nt == 64) hipLaunchKernelGGL(k_fit_quads<64>, grid, dim3(64), lds, sc, FQ_ARGS);
-      else if (cl.nt == 128) hipLaunchKernelGGL(k_fit_quads<128>, grid, dim3(128), lds, sc, FQ_ARGS);
-      else if (cl.nt == 256) hipLaunchKernelGGL(k_fit_quads<256>, grid, dim3(256), lds, sc, FQ_ARGS);
-      else hipLaunchKernelGGL(k_fit_quads<512>, grid, dim3(512), lds, sc, FQ_ARGS);
+#define FQ_LAUNCH(NTV)                                                                                          \
+  if (P.split_moments) hipLaunchKernelGGL((k_fit_quads<NTV, true>), grid, dim3(NTV), lds, sc, FQ_ARGS);          \
+  else hipLaunchKernelGGL((k_fit_quads<NTV, false>), grid, dim3(NTV), lds, sc, FQ_ARGS);
+      if (cl.nt == 64) { FQ_LAUNCH(64) }
+      else if (cl.nt == 128) { FQ_LAUNCH(128) }
+      else if (cl.nt == 256) { FQ_LAUNCH(256) }
+      else { FQ_LAUNCH(512) }
+#undef FQ_LAUNCH
 #undef FQ_ARGS
     }
     for (int a = 0; a < 3; a++) {

@@ -156,6 +156,54 @@ __device__ __forceinline__ double exact_from_fixed(U128 v) {
   return top == 0 ? 0.0 : __longlong_as_double((long long)bits);
 }
 
+// ---- the same exact sums in two doubles (fast path of the moment sweep) ---------------------------------
+// For images up to 2048 x 2048 working pixels every moment term t is a double with 1 <= t < 2^31 and a cluster
+// holds fewer than 2^15 points, so every partial sum S is a multiple of 2^-52 below 2^46.  Such a sum is kept as
+// (hi, lo): hi a multiple of 2^-6 (exact in a double below 2^47), lo the remainder.  A term splits exactly with
+// hi = (t + C) - C, lo = t - hi, C = 1.5 * 2^46 (adding C rounds t to the 2^-6 grid; |lo| <= 2^-7).  Sums of up to
+// 128 such terms stay exact component-wise (|sum lo| <= 1 is a multiple of 2^-52 below 2^53 ulps); across chunks and
+// waves the running lo part is renormalised onto the grid after every addition (split_renorm).  The rounded prefix
+// is the single IEEE addition hi + lo -- the correctly rounded value of the exact sum, i.e. bit for bit what
+// exact_from_fixed produces from the 128-bit form.  Three instructions per term instead of a dozen, one instead
+// of twenty-five per rounding.
+#define AT_SPLIT_C 0x1.8p+46
+struct D2 { double hi, lo; };
+__device__ __forceinline__ D2 split_term(double t) {
+  D2 r;
+  r.hi = (t + AT_SPLIT_C) - AT_SPLIT_C;
+  r.lo = t - r.hi;
+  return r;
+}
+// (a.hi + b.hi, a.lo + b.lo) with the lo part brought back to |lo| <= 2^-7; requires |a.lo| <= 2^-7, |b.lo| <= 1
+__device__ __forceinline__ D2 split_add_renorm(D2 a, D2 b) {
+  const double l = a.lo + b.lo;
+  const double c = (l + AT_SPLIT_C) - AT_SPLIT_C;
+  D2 r;
+  r.hi = (a.hi + b.hi) + c;
+  r.lo = l - c;
+  return r;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double f64_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// inclusive wave scan of a double whose partial sums are exact (lanes without a source add +0.0)
+__device__ __forceinline__ double wave_scan_f64(double v) {
+  v += f64_dpp<0x111, 0xF>(v);
+  v += f64_dpp<0x112, 0xF>(v);
+  v += f64_dpp<0x114, 0xF>(v);
+  v += f64_dpp<0x118, 0xF>(v);
+  v += f64_dpp<0x142, 0xA>(v);
+  v += f64_dpp<0x143, 0xC>(v);
+  return v;
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
 // n / d with the reciprocal refinement hoisted: shared_recip is v_rcp_f64 + two Newton steps (the
 // operations the compiler's f64 division expands to), div_by is quotient, exact residual, correction.
 // Correctly rounded -- bit-identical to n / d -- for operands that need no v_div_scale rescaling; the
@@ -383,7 +431,7 @@ __device__ const PairTable g_pair_table = make_pair_table();
 // Dynamic LDS layout: [0, 8*sort_cap) slope keys (later: raw/smoothed errors, then maxima candidates) |
 // FQ_TABLE_DOUBLES doubles of pair-fit tables.  Clusters with size in (size_lo, size_hi] are processed by this
 // launch; those above sort_cap (only possible in the last class) sort in global scratch.
-template <int NT>
+template <int NT, bool SPLIT>
 #ifndef FQ_EPT
 #define FQ_EPT(NT) ((NT) >= 256 ? 2 : 1)   // elements per lane in the moment sweep
 #endif
@@ -456,6 +504,13 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
 #define FQ_TICK(slot)
   (void)prof;
 #endif
+  // tools-only builds (-DAMDAT_FQ_STOP=n) drop every cluster after phase n, to count the instructions of the phases
+  // before it (tools/fq_phase_insts.sh); the product build has no such exit
+#ifdef AMDAT_FQ_STOP
+#define FQ_STOP_AT(n) if (AMDAT_FQ_STOP == (n) && P.max_nmaxima == 10) continue;
+#else
+#define FQ_STOP_AT(n)
+#endif
 
   // Work is popped `pop` clusters at a time: one device-scope atomic on a single word saturates near 90
   // returns per microsecond (MI355X_MICROARCH.md, "dequeue"), which a one-cluster pop of the small classes
@@ -519,6 +574,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     if (!P.reversed_border && q_reversed) continue;
     if (!P.normal_border && !q_reversed) continue;
     FQ_TICK(1)
+    FQ_STOP_AT(1)
 
     // ---- slope keys + sort -----------------------------------------------------------------------
     const float cx = (float)cxd, cy = (float)cyd;
@@ -540,6 +596,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     __syncthreads();
     if (in_lds) bitonic_sort_block2<NT>(skeys, sz); else bitonic_sort_block2<NT>(gkeys, sz);
     FQ_TICK(2)
+    FQ_STOP_AT(2)
 
     // ---- duplicate removal + weighted moment terms + exact cumulative sums, one sweep ---------------
     // Duplicate points (same half-pixel location, adjacent after the sort) contribute nothing and get no
@@ -550,7 +607,123 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     // independent of order.  Wave totals are double-buffered by chunk parity, so a chunk costs one
     // barrier; the running carries are double-buffered in LDS the same way (one wave: registers).
     int szd;
-    {
+    if constexpr (SPLIT) {
+      // fast path (see split_term above): the same exact prefix sums carried as two doubles per moment
+      constexpr int EPT = FQ_EPT(NT);
+      D2 carry[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) { carry[j].hi = 0; carry[j].lo = 0; }
+      int cnt_carry = 0;
+      int par = 0;
+      const int lane = lane_id(), wv = tid >> 6;
+      const unsigned long long lt_mask = (1ull << lane) - 1ull;
+      D2* const sd_wtot = reinterpret_cast<D2*>(s_wtot);
+      D2* const sd_woff = reinterpret_cast<D2*>(s_woff);
+      D2* const sd_carry = reinterpret_cast<D2*>(s_carry);
+      if (NW > 1 && tid < 6) { sd_carry[tid].hi = 0; sd_carry[tid].lo = 0; }   // visible after the first chunk's barrier
+      for (int base = 0; base < sz; base += NT * EPT, par ^= 1) {
+        D2 v[6];    // sum of the lane's elements, then the in-wave inclusive prefix
+        D2 t1[6];   // terms of the lane's second element (EPT == 2)
+#pragma unroll
+        for (int j = 0; j < 6; j++) { v[j].hi = 0; v[j].lo = 0; t1[j].hi = 0; t1[j].lo = 0; }
+        bool keep[EPT];
+        unsigned long long prev_key = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+          const int i = base + tid * EPT + e;
+          keep[e] = false;
+          if (i < sz) {
+            const unsigned long long key = key_dec(in_lds ? skeys[i] : gkeys[i]);
+            const unsigned long long prev = (e > 0) ? prev_key : ((i > 0) ? key_dec(in_lds ? skeys[i - 1] : gkeys[i - 1]) : ~key);
+            prev_key = key;
+            keep[e] = (i == 0) || ((key >> 4) != (prev >> 4));
+            if (keep[e]) {
+              const int px = (int)((key >> 4) & 0x3FFF), py = (int)((key >> 18) & 0x3FFF);
+              const double x = px * .5 + 0.5, y = py * .5 + 0.5;
+              const int ix = (int)x, iy = (int)y;
+              double Wt = 1;
+              if (ix > 0 && ix + 1 < W && iy > 0 && iy + 1 < H) {
+                const int grad_x = (int)gray[(size_t)iy * gpitch + ix + 1] - (int)gray[(size_t)iy * gpitch + ix - 1];
+                const int grad_y = (int)gray[(size_t)(iy + 1) * gpitch + ix] - (int)gray[(size_t)(iy - 1) * gpitch + ix];
+                Wt = __dsqrt_rn((double)(grad_x * grad_x + grad_y * grad_y)) + 1;
+              }
+              const double tt[6] = {Wt * x, Wt * y, Wt * x * x, Wt * x * y, Wt * y * y, Wt};
+#pragma unroll
+              for (int j = 0; j < 6; j++) {
+                const D2 t = split_term(tt[j]);
+                v[j].hi += t.hi; v[j].lo += t.lo;
+                if (e == 1) t1[j] = t;
+              }
+            }
+          }
+        }
+        unsigned long long kmask[EPT];
+        int before = 0, wcount = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+          kmask[e] = __ballot(keep[e]);
+          before += (int)__popcll(kmask[e] & lt_mask);
+          wcount += (int)__popcll(kmask[e]);
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) { v[j].hi = wave_scan_f64(v[j].hi); v[j].lo = wave_scan_f64(v[j].lo); }
+        int pos = cnt_carry + before;   // slot of the lane's first kept element
+        D2 w[6];     // workgroup-wide prefix including the lane's last element (hi exact, |lo| <= 1 + 2^-7)
+        if (NW > 1) {
+          if (lane == 63) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) sd_wtot[wv * 6 + j] = v[j];
+            s_wcnt[wv] = wcount;
+          }
+          __syncthreads();
+          if (tid < NW * 6) {
+            const int ww = tid / 6, j = tid - ww * 6;
+            D2 run = sd_carry[par * 6 + j];
+            for (int w2 = 0; w2 < ww; w2++) run = split_add_renorm(run, sd_wtot[w2 * 6 + j]);
+            sd_woff[tid] = run;
+            if (ww == NW - 1) sd_carry[(par ^ 1) * 6 + j] = split_add_renorm(run, sd_wtot[ww * 6 + j]);
+          } else if (tid < NW * 7) {
+            const int ww = tid - NW * 6;
+            int run = 0;
+            for (int w2 = 0; w2 < ww; w2++) run += s_wcnt[w2];
+            s_coff[ww] = run;
+            if (ww == NW - 1) s_coff[NW] = run + s_wcnt[ww];
+          }
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < 6; j++) { const D2 o = sd_woff[wv * 6 + j]; w[j].hi = v[j].hi + o.hi; w[j].lo = v[j].lo + o.lo; }
+          pos += s_coff[wv];
+          cnt_carry += s_coff[NW];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 6; j++) {
+            w[j].hi = v[j].hi + carry[j].hi; w[j].lo = v[j].lo + carry[j].lo;
+            D2 tot;
+            tot.hi = readlane_f64(v[j].hi, 63); tot.lo = readlane_f64(v[j].lo, 63);
+            carry[j] = split_add_renorm(carry[j], tot);
+          }
+          cnt_carry += wcount;
+        }
+        if (EPT == 2) {
+          // second element: prefix w; first element: w minus the second element's terms
+          if (keep[1]) {
+            double* o = lf + (size_t)(pos + (keep[0] ? 1 : 0)) * 6;
+#pragma unroll
+            for (int j = 0; j < 6; j++) o[j] = w[j].hi + w[j].lo;
+          }
+          if (keep[0]) {
+            double* o = lf + (size_t)pos * 6;
+#pragma unroll
+            for (int j = 0; j < 6; j++) o[j] = (w[j].hi - t1[j].hi) + (w[j].lo - t1[j].lo);
+          }
+        } else if (keep[0]) {
+          double* o = lf + (size_t)pos * 6;
+#pragma unroll
+          for (int j = 0; j < 6; j++) o[j] = w[j].hi + w[j].lo;
+        }
+      }
+      szd = cnt_carry;
+    } else {
       // EPT consecutive elements per lane: the DPP scan, the barrier and the carry traffic are paid once
       // per EPT elements; the lane's own elements are separated again after the scan by subtraction
       constexpr int EPT = FQ_EPT(NT);
@@ -688,6 +861,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     __syncthreads();   // lf complete (read by other threads below); key array free
     if (szd < 24) continue;
     FQ_TICK(4)
+    FQ_STOP_AT(4)
 
     // ---- windowed line-fit error, smoothing ------------------------------------------------------
     const int ksz = min(20, szd / 12);
@@ -804,6 +978,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       }
     }
     FQ_TICK(5)
+    FQ_STOP_AT(5)
     __syncthreads();
     const int nmaxima = s_ncand;
     if (nmaxima < 4) continue;
@@ -913,6 +1088,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     const int m = s_nkept;
     if (m < 4) continue;
     FQ_TICK(6)
+    FQ_STOP_AT(6)
 
     // ---- pairwise segment fits, then all corner quadruples ---------------------------------------
     for (int task = tid; task < 90; task += NT) {
@@ -987,34 +1163,40 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
         }
         __threadfence_block();
         const bool all_ok = __ballot(!okq) == 0ull;
-        if (lane == 0 && all_ok) {
-          bool ok = true;
-          const double p00 = s_corner[0][0], p01 = s_corner[0][1], p10 = s_corner[1][0], p11 = s_corner[1][1];
-          const double p20 = s_corner[2][0], p21 = s_corner[2][1], p30 = s_corner[3][0], p31 = s_corner[3][1];
-          {
-            // triangles (0,1,2) and (2,3,0), Heron
-            const double l0 = __dsqrt_rn((p10 - p00) * (p10 - p00) + (p11 - p01) * (p11 - p01));
-            const double l1 = __dsqrt_rn((p20 - p10) * (p20 - p10) + (p21 - p11) * (p21 - p11));
-            const double l2 = __dsqrt_rn((p00 - p20) * (p00 - p20) + (p01 - p21) * (p01 - p21));
-            const double pp = (l0 + l1 + l2) / 2;
-            double area = 0;
-            area += __dsqrt_rn(pp * (pp - l0) * (pp - l1) * (pp - l2));
-            const double k0 = __dsqrt_rn((p30 - p20) * (p30 - p20) + (p31 - p21) * (p31 - p21));
-            const double k1 = __dsqrt_rn((p00 - p30) * (p00 - p30) + (p01 - p31) * (p01 - p31));
-            const double k2 = __dsqrt_rn((p20 - p00) * (p20 - p00) + (p21 - p01) * (p21 - p01));
-            const double qq = (k0 + k1 + k2) / 2;
-            area += __dsqrt_rn(qq * (qq - k0) * (qq - k1) * (qq - k2));
-            if (area < 0.95 * P.min_tag_width * P.min_tag_width) ok = false;
+        if (all_ok) {   // uniform over the wave
+          // Area (two Heron triangles) and the four corner-angle / winding checks, spread over lanes instead of
+          // one lane doing eight square roots and six divisions in sequence: lane i < 4 owns corner i with the
+          // edges i -> i+1 -> i+2 (edge length and angle check), lane 4 the diagonal p0-p2; lanes 0 and 1 then
+          // take one triangle each.  Every expression is the one the serial form (and the CPU oracle) evaluates.
+          bool cok = true;
+          double len = 0;
+          if (lane < 5) {
+            const int i0 = lane & 3, i1 = (lane + 1) & 3, i2 = (lane + 2) & 3;
+            const double ax = s_corner[i0][0], ay = s_corner[i0][1];
+            if (lane < 4) {
+              const double bx = s_corner[i1][0], by = s_corner[i1][1], cx2 = s_corner[i2][0], cy2 = s_corner[i2][1];
+              const double dx1 = bx - ax, dy1 = by - ay, dx2 = cx2 - bx, dy2 = cy2 - by;
+              const double q1 = dx1 * dx1 + dy1 * dy1;
+              len = __dsqrt_rn(q1);
+              const double cos_dtheta = (dx1 * dx2 + dy1 * dy2) / __dsqrt_rn(q1 * (dx2 * dx2 + dy2 * dy2));
+              if ((cos_dtheta > P.cos_critical_rad || cos_dtheta < -P.cos_critical_rad) || dx1 * dy2 < dy1 * dx2) cok = false;
+            } else {
+              const double px2 = s_corner[2][0], py2 = s_corner[2][1];
+              len = __dsqrt_rn((ax - px2) * (ax - px2) + (ay - py2) * (ay - py2));
+            }
           }
-          const double px[4] = {p00, p10, p20, p30}, py[4] = {p01, p11, p21, p31};
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const int i0 = i, i1 = (i + 1) & 3, i2 = (i + 2) & 3;
-            const double dx1 = px[i1] - px[i0], dy1 = py[i1] - py[i0];
-            const double dx2 = px[i2] - px[i1], dy2 = py[i2] - py[i1];
-            const double cos_dtheta = (dx1 * dx2 + dy1 * dy2) / __dsqrt_rn((dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2));
-            if ((cos_dtheta > P.cos_critical_rad || cos_dtheta < -P.cos_critical_rad) || dx1 * dy2 < dy1 * dx2) ok = false;
-          }
+          const double e0 = readlane_f64(len, 0), e1 = readlane_f64(len, 1), e2 = readlane_f64(len, 2), e3 = readlane_f64(len, 3);
+          const double ed = readlane_f64(len, 4);
+          // lane 0: triangle (0,1,2) with sides e0, e1, diagonal; lane 1: triangle (2,3,0) with sides e2, e3, diagonal
+          const double sa = lane == 0 ? e0 : e2, sb = lane == 0 ? e1 : e3;
+          const double hp = (sa + sb + ed) / 2;
+          const double tri = __dsqrt_rn(hp * (hp - sa) * (hp - sb) * (hp - ed));
+          double area = 0;
+          area += readlane_f64(tri, 0);
+          area += readlane_f64(tri, 1);
+          bool ok = __ballot(!cok) == 0ull;
+          if (area < 0.95 * P.min_tag_width * P.min_tag_width) ok = false;
+          if (lane != 0) ok = false;   // lane 0 appends the quad
           if (ok) {
             QuadRec q;
 #pragma unroll

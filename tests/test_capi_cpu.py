@@ -55,12 +55,28 @@ def test_family_names_of_the_reference():
     codebook resolve."""
     _need_lib()
     L = capi.lib()
-    for name in ("tag36h11", "tag25h9", "tag16h5"):
+    for name, n in (("tag36h11", 587), ("tag25h9", 35), ("tag16h5", 30), ("tag36h10", 2320)):
         assert L.amdAprilTagsFamilyFromName(name.encode()) >= 0
-    for name in ("tag36h10", "circle21h7", "circle49h12", "custom48h12", "standard41h12", "standard52h13", "NOTHING"):
+        assert len(capi.family_info(name)["codes"]) == n
+    # the AprilTag-3 layout families of the reference's table have no codebook here
+    for name in ("circle21h7", "circle49h12", "custom48h12", "standard41h12", "standard52h13", "NOTHING"):
         assert L.amdAprilTagsFamilyFromName(name.encode()) == -1
     info = capi.family_info("tag36h11")
-    assert info["d"] == 6 and info["codes"][0] == 0xd5d628584
+    assert info["d"] == 6 and info["codes"][0] == 0xd5d628584 and info["codes"][-1] == 0xe83be4b73
+
+
+def test_create_rejects_bad_decimate_and_hamming_before_touching_the_device():
+    """decimate > 4 used to sample with DEC = 4 silently; max_hamming > 3 matched any code."""
+    _need_lib()
+    L = capi.lib()
+    h = C.c_void_p()
+    cfg = capi.Config()
+    L.amdAprilTagsDefaultConfig(C.byref(cfg), 640, 480)
+    cfg.decimate = 5
+    assert L.amdCreateAprilTagsDetectorEx(C.byref(h), C.byref(cfg)) == 2 and not h
+    cfg.decimate = 1
+    cfg.max_hamming = 4
+    assert L.amdCreateAprilTagsDetectorEx(C.byref(h), C.byref(cfg)) == 1 and not h
 
 
 def test_create_argument_validation():

@@ -3,7 +3,9 @@ serialise kernels and are slow on a full bench).  Usage: python tools/pipeline_o
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-from isaac_ros_apriltag_amd import synth
+from isaac_ros_apriltag_amd import capi, synth
+if os.environ.get("AMDAT_LIB"):   # measurement variant built by isaac_ros_apriltag_amd.build.build_amd_variant
+    capi.LIB_PATH = os.path.join(ROOT, "isaac_ros_apriltag_amd", "libapriltag_amd_%s.so" % os.environ["AMDAT_LIB"])
 from isaac_ros_apriltag_amd.detector import AprilTagDetector
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
