@@ -106,6 +106,9 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   }
   __syncthreads();
 
+#if defined(AMDAT_CC_STOP) && AMDAT_CC_STOP == 1   // tools-only: instruction counts per phase
+  if (P.max_nmaxima == 10) return;
+#endif
   // ---- 2. unions with the row above (only the first pixel of every overlap) -------------------
   for (int k = 0; k < 16; k++) {
     const int r = wv * 16 + k;
@@ -130,6 +133,9 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   }
   __syncthreads();
 
+#if defined(AMDAT_CC_STOP) && AMDAT_CC_STOP == 2
+  if (P.max_nmaxima == 10) return;
+#endif
   // ---- 3. flatten into registers, then count pixels per root (one LDS atomic per run) ----------
   uint32_t root[16];
   for (int k = 0; k < 16; k++) {
@@ -153,6 +159,9 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   }
   __syncthreads();
 
+#if defined(AMDAT_CC_STOP) && AMDAT_CC_STOP == 3
+  if (P.max_nmaxima == 10) return;
+#endif
   // ---- 4. write global labels (index of the local root), local sizes at the roots, root list -------
   uint32_t* label = label_all + (size_t)frame * W * H;
   uint32_t* csize = csize_all + (size_t)frame * W * H;

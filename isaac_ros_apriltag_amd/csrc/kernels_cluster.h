@@ -38,6 +38,7 @@ __device__ __forceinline__ uint32_t hash_insert(unsigned long long* hkeys, uint3
 }
 
 #define PT_TB 256  // entries of the per-block component-pair table
+#define PT_ELIST 2048   // emissions of one tile kept in the LDS list of pass 2 (the tile has 1024 pixels)
 
 // per-block table in LDS: returns entry index or -1 when full
 __device__ __forceinline__ int ltab_insert(unsigned long long* tkey, uint64_t key) {
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   __shared__ uint32_t sbase;
   __shared__ unsigned long long tkey[PT_TB];
   __shared__ uint32_t tcnt[PT_TB], tslot[PT_TB], tbase[PT_TB];
+  __shared__ uint32_t elist[PT_ELIST];
   const int frame = (int)blockIdx.z + P.frame0;
   const int W = P.W, H = P.H;
   const size_t npx = (size_t)W * H;
@@ -120,6 +122,9 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   tkey[tid] = AT_EMPTY_KEY;
   tcnt[tid] = 0;
   __syncthreads();
+#if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 1   // tools-only: instruction counts per phase (tools/pt_phase_insts.sh)
+  if (P.max_nmaxima == 10) return;
+#endif
 
   const int lx = tid & 63;
   const int gx = X0 + lx;
@@ -127,6 +132,8 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   // pass 1: count per pair in the block table; every emitting (pixel, direction) of this thread is
   // remembered as a bit of emask plus the byte index of its table entry (0xFF: the table was full), so
   // that pass 2 does not walk the neighbourhood again
+  // (Aggregating the table inserts and counter atomics of pass 1 over the wave -- one leader per distinct key -- was
+  // measured slower, 9.6 vs 6.1 ms: a 64-pixel row step meets too many distinct component pairs.)
   uint32_t cnt = 0;
   uint32_t emask = 0;
   uint32_t eidx[4] = {0, 0, 0, 0};
@@ -164,6 +171,9 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   uint32_t total;
   const uint32_t off = block_excl_scan256(cnt, sscan, &total);  // contains __syncthreads
   if (total == 0) return;
+#if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 2   // (pass 1's results are written out so that they stay live)
+  if (P.max_nmaxima == 10) { rank_all[(size_t)frame * P.pcap + blockIdx.x * 256 + tid] = emask ^ eidx[0] ^ eidx[1] ^ eidx[2] ^ eidx[3] ^ off; return; }
+#endif
   unsigned long long* hkeys = hkeys_all + (size_t)frame * P.hcap;
   uint32_t* hcnt = hcnt_all + (size_t)frame * P.hcap;
   if (tid == 0) sbase = atomicAdd(&counters[frame].npoints_raw, total);
@@ -181,25 +191,29 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     }
   }
   __syncthreads();
+#if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 3
+  if (P.max_nmaxima == 10) { rank_all[(size_t)frame * P.pcap + blockIdx.x * 256 + tid] = emask ^ eidx[0] ^ eidx[1] ^ eidx[2] ^ eidx[3] ^ off ^ sbase; return; }
+#endif
   const uint32_t base = sbase;
   if (base + total > P.pcap) {
     if (tid == 0) atomicOr(&counters[frame].flags, 0x1u);
   }
-  // pass 2: emit {slot, point} and the rank inside the cluster for the remembered emitters
+  // pass 2: emit {slot, point} and the rank inside the cluster.  The emitters pass 1 remembered are first written
+  // to a block-wide list in LDS (at the thread's scan offset), then the list is consumed DENSELY: entry q belongs to
+  // thread q mod 256, so every lane of every wave has an emission to work on (the per-thread loop over a 16-bit
+  // mask ran at under half the lanes and as long as the busiest lane), the staging stores of a wave are 64
+  // consecutive records, and the rank inside the (block, pair) group is handed out with one LDS atomic per distinct
+  // pair and wave instead of one per point.  Emissions beyond the list capacity (more than two per pixel of the
+  // tile on average) take the per-thread path.
   uint2* stage = stage_all + (size_t)frame * P.pcap;
   uint32_t* rank = rank_all + (size_t)frame * P.pcap;
-  uint32_t pos = base + off;
-  while (emask) {
-    const int sidx = __ffs((int)emask) - 1;
-    emask &= emask - 1;
-    const int k = sidx >> 2, d = sidx & 3;
-    const int ly = (tid >> 6) + 4 * k;
-    const int gy = Y0 + ly;
-    const int c = ly * PT_LW + lx + 1;
+  auto emit_direct = [&](uint32_t rec, uint32_t pos) {
+    const int ly = (int)(rec & 1023u) >> 6, plx = (int)(rec & 63u), d = (int)((rec >> 10) & 3u);
+    const uint32_t e = rec >> 12;
+    const int c = ly * PT_LW + plx + 1;
     const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
     const int n = c + ddy * PT_LW + ddx;
     const int v0 = sv[c], v1 = sv[n];
-    const uint32_t e = (eidx[k] >> (8 * d)) & 255u;
     uint32_t slot, rk = 0;
     if (e != 255u) {
       slot = tslot[e];
@@ -212,10 +226,64 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
       else rk = atomicAdd(&hcnt[slot], 1u);
     }
     if (pos < P.pcap) {
-      stage[pos] = make_uint2(slot, pack_point(2 * gx + ddx, 2 * gy + ddy, ddx * (v1 - v0), ddy * (v1 - v0)));
+      stage[pos] = make_uint2(slot, pack_point(2 * (X0 + plx) + ddx, 2 * (Y0 + ly) + ddy, ddx * (v1 - v0), ddy * (v1 - v0)));
       rank[pos] = rk;
     }
-    pos++;
+  };
+  {
+    uint32_t q = off, m = emask;
+    while (m) {
+      const int sidx = __ffs((int)m) - 1;
+      m &= m - 1;
+      const int k = sidx >> 2, d = sidx & 3;
+      const uint32_t e = (eidx[k] >> (8 * d)) & 255u;
+      const uint32_t rec = (uint32_t)(((tid >> 6) + 4 * k) * 64 + lx) | ((uint32_t)d << 10) | (e << 12);
+      if (q < PT_ELIST) elist[q] = rec;
+      else emit_direct(rec, base + q);
+      q++;
+    }
+  }
+  __syncthreads();
+  const uint32_t nlist = total < PT_ELIST ? total : PT_ELIST;
+  const int lane = lane_id();
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  for (uint32_t q0 = 0; q0 < nlist; q0 += 256) {
+    const uint32_t q = q0 + tid;
+    const bool act = q < nlist;
+    const uint32_t rec = act ? elist[q] : 0u;
+    const uint32_t e = rec >> 12;
+    // rank inside the (block, pair) group: one LDS atomic per distinct table entry present in the wave
+    uint32_t rk_local = 0;
+    bool pending = act && e != 255u;
+    unsigned long long todo = __ballot(pending);
+    while (todo) {
+      const int leader = (int)__ffsll((long long)todo) - 1;
+      const uint32_t le = (uint32_t)__builtin_amdgcn_readlane((int)e, leader);
+      const unsigned long long same = __ballot(pending && e == le);
+      uint32_t b = 0;
+      if (lane == leader) b = atomicAdd(&tcnt[le], (uint32_t)__popcll(same));
+      b = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
+      if (pending && e == le) { rk_local = b + (uint32_t)__popcll(same & lt_mask); pending = false; }
+      todo &= ~same;
+    }
+    if (act) {
+      if (e == 255u) {
+        emit_direct(rec, base + q);
+      } else {
+        const int ly = (int)(rec & 1023u) >> 6, plx = (int)(rec & 63u), d = (int)((rec >> 10) & 3u);
+        const int c = ly * PT_LW + plx + 1;
+        const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
+        const int n = c + ddy * PT_LW + ddx;
+        const int v0 = sv[c], v1 = sv[n];
+        const uint32_t slot = tslot[e];
+        const uint32_t rk = (slot != AT_INVALID_SLOT) ? tbase[e] + rk_local : 0u;
+        const uint32_t pos = base + q;
+        if (pos < P.pcap) {
+          stage[pos] = make_uint2(slot, pack_point(2 * (X0 + plx) + ddx, 2 * (Y0 + ly) + ddy, ddx * (v1 - v0), ddy * (v1 - v0)));
+          rank[pos] = rk;
+        }
+      }
+    }
   }
 }
 
