@@ -156,6 +156,11 @@ struct amdAprilTagsDetector_st {
   bool profiling = false;
   bool fq_counters = false;  // per-phase cycle counters inside k_fit_quads (profiling level 2; perturbs timing)
   bool fq_attr_set = false;
+  // captured enqueue sequence of small submissions (see run_batch)
+  uint32_t graph_max_frames = 8;
+  hipGraphExec_t graph_exec = nullptr;
+  uint32_t graph_n = 0, graph_ostride = 0;
+  hipStream_t graph_stream = nullptr;
   hipEvent_t ev[AMDAT_NUM_STAGES + 1] = {};
   float stage_ms[AMDAT_NUM_STAGES] = {};
   uint32_t last_n = 0;
@@ -252,6 +257,7 @@ int amdAprilTagsFamilyFromName(const char* name) {
 const char* amdAprilTagsStageName(uint32_t stage) { return stage < AMDAT_NUM_STAGES ? kStageNames[stage] : ""; }
 
 static void free_all(amdAprilTagsDetector_st* D) {
+  if (D->graph_exec) hipGraphExecDestroy(D->graph_exec);
   hipFree(D->d_gray); hipFree(D->d_thr); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_roots); hipFree(D->d_hkeys);
   hipFree(D->d_hcnt); hipFree(D->d_hoff); hipFree(D->d_stage); hipFree(D->d_rank); hipFree(D->d_pts); hipFree(D->d_clusters);
   hipFree(D->d_work); hipFree(D->d_workctl); hipFree(D->d_keys_scr); hipFree(D->d_quads);
@@ -313,7 +319,6 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   P.max_nmaxima = 10;
   // exactness bounds of the two-double moment sums (kernels_quad.h, split_term): W * x * x < 2^31, < 2^15 points
   P.split_moments = (W <= 2048 && H <= 2048 && P.max_cluster_points < 32768) ? 1 : 0;
-  if (getenv("AMDAT_NO_SPLIT_MOMENTS")) P.split_moments = 0;   // A/B switch for tools/ only; both paths give identical bits
   P.refine_edges = cfg.refine_edges ? 1 : 0;
   P.max_hamming = (int)cfg.max_hamming;
   P.nfam = (int)cfg.num_families;
@@ -429,6 +434,14 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   for (auto& a : D->aux_stream) if (ok && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) ok = false;
   if (ok && hipEventCreateWithFlags(&D->ev_fork, hipEventDisableTiming) != hipSuccess) ok = false;
   for (auto& e : D->ev_join) if (ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
+  // dynamic LDS beyond 64 KB has to be allowed per kernel (once per device; not allowed while a stream is being captured)
+  if (ok) {
+      const void* fns[8] = {reinterpret_cast<const void*>(k_fit_quads<512, false>), reinterpret_cast<const void*>(k_fit_quads<256, false>),
+                            reinterpret_cast<const void*>(k_fit_quads<128, false>), reinterpret_cast<const void*>(k_fit_quads<64, false>),
+                            reinterpret_cast<const void*>(k_fit_quads<512, true>), reinterpret_cast<const void*>(k_fit_quads<256, true>),
+                            reinterpret_cast<const void*>(k_fit_quads<128, true>), reinterpret_cast<const void*>(k_fit_quads<64, true>)};
+      for (const void* fn : fns) if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 157000) != hipSuccess) ok = false;
+  }
   if (ok && D->d_thr) {
     // the padding columns of the working images are read by vector loads; define them once
     if (hipMemset(D->d_thr, 127, B * (size_t)H * P.WS) != hipSuccess) ok = false;
@@ -572,14 +585,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
   {
     // keys | pair-table region
     auto lds_bytes = [](const FqClass& c) { return (size_t)c.sort_cap * 8 + (size_t)FQ_TABLE_DOUBLES * 8; };
-    if (!D->fq_attr_set) {
-      const void* fns[8] = {reinterpret_cast<const void*>(k_fit_quads<512, false>), reinterpret_cast<const void*>(k_fit_quads<256, false>),
-                            reinterpret_cast<const void*>(k_fit_quads<128, false>), reinterpret_cast<const void*>(k_fit_quads<64, false>),
-                            reinterpret_cast<const void*>(k_fit_quads<512, true>), reinterpret_cast<const void*>(k_fit_quads<256, true>),
-                            reinterpret_cast<const void*>(k_fit_quads<128, true>), reinterpret_cast<const void*>(k_fit_quads<64, true>)};
-      for (const void* fn : fns) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 157000));
-      D->fq_attr_set = true;
-    }
+
     // The classes are independent (they only append to the quad list), so they run concurrently.  The
     // runtime multiplexes streams onto four hardware queues, and two streams on one queue serialise
     // (measured: the largest class started only when another one had finished), so exactly four streams
@@ -603,9 +609,11 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
         used[smap[c]] = true;
       }
       const bool big = c == FQ_NCLS - 1;
+      // a small submission spreads its clusters over the workgroups one by one (latency); large ones pop in chunks
+      const int pop = cl.pop < (int)(n / 16u) ? cl.pop : ((int)(n / 16u) < 1 ? 1 : (int)(n / 16u));
 #define FQ_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work + D->work_layout.off[c], D->d_workctl + c,                   \
                 D->work_layout.cap[c], D->d_workctl + 8 + c, cl.d_lf, (big ? D->d_keys_scr : nullptr), cl.d_errs,                        \
-                D->d_quads, D->d_counters, (D->fq_counters ? D->d_fqprof + 8 * c : nullptr), cl.sort_cap, cl.slot_cap, cl.pop, P
+                D->d_quads, D->d_counters, (D->fq_counters ? D->d_fqprof + 8 * c : nullptr), cl.sort_cap, cl.slot_cap, pop, P
 #define FQ_LAUNCH(NTV)                                                                                          \
   if (P.split_moments) hipLaunchKernelGGL((k_fit_quads<NTV, true>), grid, dim3(NTV), lds, sc, FQ_ARGS);          \
   else hipLaunchKernelGGL((k_fit_quads<NTV, false>), grid, dim3(NTV), lds, sc, FQ_ARGS);
@@ -635,18 +643,10 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
   return AMDAT_SUCCESS;
 }
 
-// One batched submission; results land in h_out / h_counters with `ostride` records per frame.
-static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images,
-                     const amdAprilTagsCameraIntrinsics_t* intr, uint32_t ostride, hipStream_t s) {
+// Everything one submission enqueues on stream s (and the auxiliary streams forked from it): descriptor upload, clears,
+// the stage sequence, result download.  No host synchronisation inside, so the sequence can be stream-captured.
+static int enqueue_submission(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s, const std::function<void()>& mark) {
   const DetParams& P = D->P;
-  DeviceGuard guard(D->device);
-  if (!guard.ok) return AMDAT_HIP_ERROR;
-  fill_frames(D, n, images, intr);
-  D->last_n = n;
-  const bool prof = D->profiling;
-  int evi = 0;
-  const std::function<void()> mark = [&]() { if (prof) hipEventRecord(D->ev[evi++], s); };
-
   mark();
   HIP_TRY(hipMemcpyAsync(D->d_frames, D->h_frames, n * sizeof(FrameDesc), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(D->d_counters, 0, n * sizeof(FrameCounters), s));
@@ -659,12 +659,60 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
     const int rc = issue_pipeline(D, n, s, mark);
     if (rc) return rc;
   }
-  HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(D->h_counters, D->d_counters, n * sizeof(FrameCounters), hipMemcpyDeviceToHost, s));
-  if (ostride > P.dcap) ostride = P.dcap;
   HIP_TRY(hipMemcpy2DAsync(D->h_out, (size_t)ostride * sizeof(DetRec), D->d_out, (size_t)P.dcap * sizeof(DetRec),
                            (size_t)ostride * sizeof(DetRec), n, hipMemcpyDeviceToHost, s));
   mark();
+  return AMDAT_SUCCESS;
+}
+
+// One batched submission; results land in h_out / h_counters with `ostride` records per frame.
+static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images,
+                     const amdAprilTagsCameraIntrinsics_t* intr, uint32_t ostride, hipStream_t s) {
+  const DetParams& P = D->P;
+  DeviceGuard guard(D->device);
+  if (!guard.ok) return AMDAT_HIP_ERROR;
+  fill_frames(D, n, images, intr);   // image pointers, pitches and intrinsics travel through the pinned descriptor block
+  D->last_n = n;
+  if (ostride > P.dcap) ostride = P.dcap;
+  const bool prof = D->profiling;
+  int evi = 0;
+  const std::function<void()> mark = [&]() { if (prof) hipEventRecord(D->ev[evi++], s); };
+  const std::function<void()> nomark = []() {};
+
+  // Small submissions (the node's one-frame calls) are launch-bound: ~17 enqueues for well under a millisecond of
+  // device work.  Their enqueue sequence is captured once per (frames, output stride, stream) into a hipGraph and
+  // replayed; everything that changes between calls lives in the descriptor block the graph's first node uploads.
+  if (D->graph_max_frames && n <= D->graph_max_frames && !prof) {
+    if (!(D->graph_exec && D->graph_n == n && D->graph_ostride == ostride && D->graph_stream == s)) {
+      if (D->graph_exec) { hipGraphExecDestroy(D->graph_exec); D->graph_exec = nullptr; }
+      hipGraph_t graph = nullptr;
+      bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (ok) {
+        const int rc = enqueue_submission(D, n, ostride, s, nomark);
+        const hipError_t e = hipStreamEndCapture(s, &graph);
+        ok = rc == AMDAT_SUCCESS && e == hipSuccess && graph != nullptr;
+      }
+      if (ok) ok = hipGraphInstantiate(&D->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) hipGraphDestroy(graph);
+      if (ok) { D->graph_n = n; D->graph_ostride = ostride; D->graph_stream = s; }
+      else {
+        (void)hipGetLastError();
+        D->graph_exec = nullptr;
+        D->graph_max_frames = 0;   // capture is not usable here: plain enqueues from now on
+      }
+    }
+    if (D->graph_exec) {
+      HIP_TRY(hipGraphLaunch(D->graph_exec, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      return AMDAT_SUCCESS;
+    }
+  }
+  {
+    const int rc = enqueue_submission(D, n, ostride, s, mark);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));
   if (prof) {
     for (int i = 0; i < AMDAT_NUM_STAGES; i++) {
