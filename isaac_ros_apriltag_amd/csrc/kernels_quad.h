@@ -313,7 +313,10 @@ __device__ __forceinline__ void bitonic_group(unsigned long long (&v)[8], bool f
   }
 }
 
-template <int NT, int R, typename KeyPtr>
+// PADDED: the array physically holds +infinity keys in [n, 2^lpow), so loads and stores need no bounds tests (a
+// group that lies entirely in the pad region is skipped with one comparison: the pads never move, every exchange
+// puts the smaller key at the lower index).
+template <int NT, int R, bool PADDED, typename KeyPtr>
 __device__ __forceinline__ void bitonic_pass_r(KeyPtr A, int n, int lpow, int lk, int s) {
   // steps s .. s+R-1 of merge level lk (step 0 = flip of 2^lk blocks, step t = half-cleaner of stride 2^(lk-1-t))
   constexpr int M = 1 << R;
@@ -337,18 +340,26 @@ __device__ __forceinline__ void bitonic_pass_r(KeyPtr A, int n, int lpow, int lk
     }
     if (idx[1] >= n) continue;  // at most one real element: nothing to exchange
     unsigned long long v[8];
+    if (PADDED) {
 #pragma unroll
-    for (int e = 0; e < M; e++) v[e] = idx[e] < n ? A[idx[e]] : INF;
-    bitonic_group<R>(v, s == 0);
+      for (int e = 0; e < M; e++) v[e] = A[idx[e]];
+      bitonic_group<R>(v, s == 0);
 #pragma unroll
-    for (int e = 0; e < M; e++)
-      if (idx[e] < n) A[idx[e]] = v[e];
+      for (int e = 0; e < M; e++) A[idx[e]] = v[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < M; e++) v[e] = idx[e] < n ? A[idx[e]] : INF;
+      bitonic_group<R>(v, s == 0);
+#pragma unroll
+      for (int e = 0; e < M; e++)
+        if (idx[e] < n) A[idx[e]] = v[e];
+    }
   }
   __syncthreads();
 }
 
 // merge levels 1..3 in one pass: every thread sorts 8 consecutive elements in registers
-template <int NT, typename KeyPtr>
+template <int NT, bool PADDED, typename KeyPtr>
 __device__ __forceinline__ void bitonic_first8(KeyPtr A, int n, int lpow) {
   auto ce = [](unsigned long long& lo, unsigned long long& hi) {
     const double a = __longlong_as_double((long long)lo), b = __longlong_as_double((long long)hi);
@@ -364,7 +375,7 @@ __device__ __forceinline__ void bitonic_first8(KeyPtr A, int n, int lpow) {
     if (base + 1 >= n) continue;
     unsigned long long v[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) v[e] = base + e < n ? A[base + e] : AT_KEY_PAD;
+    for (int e = 0; e < 8; e++) v[e] = (PADDED || base + e < n) ? A[base + e] : AT_KEY_PAD;
 #pragma unroll
     for (int lk = 1; lk <= 3; lk++) {
       const int k = 1 << lk;
@@ -382,24 +393,22 @@ __device__ __forceinline__ void bitonic_first8(KeyPtr A, int n, int lpow) {
     }
 #pragma unroll
     for (int e = 0; e < 8; e++)
-      if (base + e < n) A[base + e] = v[e];
+      if (PADDED || base + e < n) A[base + e] = v[e];
   }
   __syncthreads();
 }
 
-template <int NT, typename KeyPtr>
-__device__ __forceinline__ void bitonic_sort_block2(KeyPtr A, int n) {
-  int lpow = 0;
-  while ((1 << lpow) < n) lpow++;
+template <int NT, bool PADDED, typename KeyPtr>
+__device__ __forceinline__ void bitonic_sort_block2(KeyPtr A, int n, int lpow) {
   int lk0 = 1;
-  if (lpow >= 3) { bitonic_first8<NT>(A, n, lpow); lk0 = 4; }
+  if (lpow >= 3) { bitonic_first8<NT, PADDED>(A, n, lpow); lk0 = 4; }
   for (int lk = lk0; lk <= lpow; lk++) {
     int s = 0;
     while (s < lk) {
       const int left = lk - s;
-      if (left >= 3) { bitonic_pass_r<NT, 3>(A, n, lpow, lk, s); s += 3; }
-      else if (left == 2) { bitonic_pass_r<NT, 2>(A, n, lpow, lk, s); s += 2; }
-      else { bitonic_pass_r<NT, 1>(A, n, lpow, lk, s); s += 1; }
+      if (left >= 3) { bitonic_pass_r<NT, 3, PADDED>(A, n, lpow, lk, s); s += 3; }
+      else if (left == 2) { bitonic_pass_r<NT, 2, PADDED>(A, n, lpow, lk, s); s += 2; }
+      else { bitonic_pass_r<NT, 1, PADDED>(A, n, lpow, lk, s); s += 1; }
     }
   }
 }
@@ -595,8 +604,17 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
                                              ((unsigned long long)x << 4) | (unsigned long long)(p & 15u));
       if (in_lds) skeys[i] = key; else gkeys[i] = key;
     }
+    int lpow = 0;
+    while ((1 << lpow) < sz) lpow++;
+    // when the LDS array holds the next power of two, the tail is filled with +infinity keys and the network runs
+    // without per-element bounds tests
+    const bool padded = in_lds && (1 << lpow) <= sort_cap;
+    if (padded)
+      for (int i = sz + tid; i < (1 << lpow); i += NT) skeys[i] = AT_KEY_PAD;
     __syncthreads();
-    if (in_lds) bitonic_sort_block2<NT>(skeys, sz); else bitonic_sort_block2<NT>(gkeys, sz);
+    if (padded) bitonic_sort_block2<NT, true>(skeys, sz, lpow);
+    else if (in_lds) bitonic_sort_block2<NT, false>(skeys, sz, lpow);
+    else bitonic_sort_block2<NT, false>(gkeys, sz, lpow);
     FQ_TICK(2)
     FQ_STOP_AT(2)
 
@@ -610,121 +628,117 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     // barrier; the running carries are double-buffered in LDS the same way (one wave: registers).
     int szd;
     if constexpr (SPLIT) {
-      // fast path (see split_term above): the same exact prefix sums carried as two doubles per moment
-      constexpr int EPT = FQ_EPT(NT);
-      D2 carry[6];
-#pragma unroll
-      for (int j = 0; j < 6; j++) { carry[j].hi = 0; carry[j].lo = 0; }
-      int cnt_carry = 0;
-      int par = 0;
+      // Fast path (see split_term above): the same exact prefix sums carried as two doubles per moment, and ONE scan
+      // per cluster instead of one per 64-point chunk.  Every lane owns E consecutive points of the sorted order:
+      //   walk 1  terms of the lane's points, summed into lane totals (exact); the key slot of a point is rewritten
+      //           with what walk 2 needs (kept flag, coordinates, squared gradient);
+      //   scan    lane totals over the wave (DPP) and the waves (LDS), kept-point counts alongside;
+      //   walk 2  every lane replays its points from its exclusive offset and rounds each prefix once.
+      // E is odd, so that the lanes' key slots (stride E * 8 bytes) fall into different LDS banks.
       const int lane = lane_id(), wv = tid >> 6;
-      const unsigned long long lt_mask = (1ull << lane) - 1ull;
+      const int E = ((sz + NT - 1) / NT) | 1;
+      const int i0 = tid * E, i1 = min(sz, i0 + E);
       D2* const sd_wtot = reinterpret_cast<D2*>(s_wtot);
       D2* const sd_woff = reinterpret_cast<D2*>(s_woff);
-      D2* const sd_carry = reinterpret_cast<D2*>(s_carry);
-      if (NW > 1 && tid < 6) { sd_carry[tid].hi = 0; sd_carry[tid].lo = 0; }   // visible after the first chunk's barrier
-      for (int base = 0; base < sz; base += NT * EPT, par ^= 1) {
-        D2 v[6];    // sum of the lane's elements, then the in-wave inclusive prefix
-        D2 t1[6];   // terms of the lane's second element (EPT == 2)
+      unsigned long long prev = 0;
+      if (i0 > 0 && i0 < sz) prev = key_dec(in_lds ? skeys[i0 - 1] : gkeys[i0 - 1]);
+      if (NW > 1) __syncthreads();   // every lane holds its predecessor key before any slot is rewritten
+      D2 acc[6];
 #pragma unroll
-        for (int j = 0; j < 6; j++) { v[j].hi = 0; v[j].lo = 0; t1[j].hi = 0; t1[j].lo = 0; }
-        bool keep[EPT];
-        unsigned long long prev_key = 0;
-#pragma unroll
-        for (int e = 0; e < EPT; e++) {
-          const int i = base + tid * EPT + e;
-          keep[e] = false;
-          if (i < sz) {
-            const unsigned long long key = key_dec(in_lds ? skeys[i] : gkeys[i]);
-            const unsigned long long prev = (e > 0) ? prev_key : ((i > 0) ? key_dec(in_lds ? skeys[i - 1] : gkeys[i - 1]) : ~key);
-            prev_key = key;
-            keep[e] = (i == 0) || ((key >> 4) != (prev >> 4));
-            if (keep[e]) {
-              const int px = (int)((key >> 4) & 0x3FFF), py = (int)((key >> 18) & 0x3FFF);
-              const double x = px * .5 + 0.5, y = py * .5 + 0.5;
-              const int ix = (int)x, iy = (int)y;
-              double Wt = 1;
-              if (ix > 0 && ix + 1 < W && iy > 0 && iy + 1 < H) {
-                const int grad_x = (int)gray[(size_t)iy * gpitch + ix + 1] - (int)gray[(size_t)iy * gpitch + ix - 1];
-                const int grad_y = (int)gray[(size_t)(iy + 1) * gpitch + ix] - (int)gray[(size_t)(iy - 1) * gpitch + ix];
-                Wt = __dsqrt_rn((double)(grad_x * grad_x + grad_y * grad_y)) + 1;
-              }
-              const double tt[6] = {Wt * x, Wt * y, Wt * x * x, Wt * x * y, Wt * y * y, Wt};
-#pragma unroll
-              for (int j = 0; j < 6; j++) {
-                const D2 t = split_term(tt[j]);
-                v[j].hi += t.hi; v[j].lo += t.lo;
-                if (e == 1) t1[j] = t;
-              }
-            }
+      for (int j = 0; j < 6; j++) { acc[j].hi = 0; acc[j].lo = 0; }
+      int kept = 0;
+      for (int i = i0; i < i1; i++) {
+        const unsigned long long key = key_dec(in_lds ? skeys[i] : gkeys[i]);
+        const bool keep = (i == 0) || ((key >> 4) != (prev >> 4));
+        prev = key;
+        const uint32_t px = (uint32_t)((key >> 4) & 0x3FFF), py = (uint32_t)((key >> 18) & 0x3FFF);
+        uint32_t G = 0;   // squared gradient magnitude; 0 also stands for "no gradient taken" (weight 1 either way)
+        if (keep) {
+          const double x = (int)px * .5 + 0.5, y = (int)py * .5 + 0.5;
+          const int ix = (int)x, iy = (int)y;
+          if (ix > 0 && ix + 1 < W && iy > 0 && iy + 1 < H) {
+            const int grad_x = (int)gray[(size_t)iy * gpitch + ix + 1] - (int)gray[(size_t)iy * gpitch + ix - 1];
+            const int grad_y = (int)gray[(size_t)(iy + 1) * gpitch + ix] - (int)gray[(size_t)(iy - 1) * gpitch + ix];
+            G = (uint32_t)(grad_x * grad_x + grad_y * grad_y);
           }
-        }
-        unsigned long long kmask[EPT];
-        int before = 0, wcount = 0;
-#pragma unroll
-        for (int e = 0; e < EPT; e++) {
-          kmask[e] = __ballot(keep[e]);
-          before += (int)__popcll(kmask[e] & lt_mask);
-          wcount += (int)__popcll(kmask[e]);
-        }
-#pragma unroll
-        for (int j = 0; j < 6; j++) { v[j].hi = wave_scan_f64(v[j].hi); v[j].lo = wave_scan_f64(v[j].lo); }
-        int pos = cnt_carry + before;   // slot of the lane's first kept element
-        D2 w[6];     // workgroup-wide prefix including the lane's last element (hi exact, |lo| <= 1 + 2^-7)
-        if (NW > 1) {
-          if (lane == 63) {
-#pragma unroll
-            for (int j = 0; j < 6; j++) sd_wtot[wv * 6 + j] = v[j];
-            s_wcnt[wv] = wcount;
-          }
-          __syncthreads();
-          if (tid < NW * 6) {
-            const int ww = tid / 6, j = tid - ww * 6;
-            D2 run = sd_carry[par * 6 + j];
-            for (int w2 = 0; w2 < ww; w2++) run = split_add_renorm(run, sd_wtot[w2 * 6 + j]);
-            sd_woff[tid] = run;
-            if (ww == NW - 1) sd_carry[(par ^ 1) * 6 + j] = split_add_renorm(run, sd_wtot[ww * 6 + j]);
-          } else if (tid < NW * 7) {
-            const int ww = tid - NW * 6;
-            int run = 0;
-            for (int w2 = 0; w2 < ww; w2++) run += s_wcnt[w2];
-            s_coff[ww] = run;
-            if (ww == NW - 1) s_coff[NW] = run + s_wcnt[ww];
-          }
-          __syncthreads();
-#pragma unroll
-          for (int j = 0; j < 6; j++) { const D2 o = sd_woff[wv * 6 + j]; w[j].hi = v[j].hi + o.hi; w[j].lo = v[j].lo + o.lo; }
-          pos += s_coff[wv];
-          cnt_carry += s_coff[NW];
-        } else {
+          const double Wt = __dsqrt_rn((double)(int)G) + 1;
+          const double tt[6] = {Wt * x, Wt * y, Wt * x * x, Wt * x * y, Wt * y * y, Wt};
 #pragma unroll
           for (int j = 0; j < 6; j++) {
-            w[j].hi = v[j].hi + carry[j].hi; w[j].lo = v[j].lo + carry[j].lo;
-            D2 tot;
-            tot.hi = readlane_f64(v[j].hi, 63); tot.lo = readlane_f64(v[j].lo, 63);
-            carry[j] = split_add_renorm(carry[j], tot);
+            const D2 t = split_term(tt[j]);
+            acc[j].hi += t.hi; acc[j].lo += t.lo;
           }
-          cnt_carry += wcount;
+          kept++;
         }
-        if (EPT == 2) {
-          // second element: prefix w; first element: w minus the second element's terms
-          if (keep[1]) {
-            double* o = lf + (size_t)(pos + (keep[0] ? 1 : 0)) * 6;
+        const unsigned long long stash = ((unsigned long long)(keep ? 1u : 0u) << 63) | ((unsigned long long)G << 28) |
+                                         ((unsigned long long)py << 14) | (unsigned long long)px;
+        if (in_lds) skeys[i] = stash; else gkeys[i] = stash;
+      }
+      // lane totals onto the grid (|lo| <= 2^-7), then the inclusive scans
+      D2 incl[6];
 #pragma unroll
-            for (int j = 0; j < 6; j++) o[j] = w[j].hi + w[j].lo;
-          }
-          if (keep[0]) {
-            double* o = lf + (size_t)pos * 6;
+      for (int j = 0; j < 6; j++) {
+        const double c = (acc[j].lo + AT_SPLIT_C) - AT_SPLIT_C;
+        acc[j].hi += c; acc[j].lo -= c;
+        incl[j].hi = wave_scan_f64(acc[j].hi);
+        incl[j].lo = wave_scan_f64(acc[j].lo);
+      }
+      int kincl = kept;
+#define OP(C, M) kincl += __builtin_amdgcn_update_dpp(0, kincl, C, M, 0xF, true);
+      AT_DPP_STEPS(OP)
+#undef OP
+      D2 off[6];
+      int pos = kincl - kept;
+      if (NW > 1) {
+        if (lane == 63) {
 #pragma unroll
-            for (int j = 0; j < 6; j++) o[j] = (w[j].hi - t1[j].hi) + (w[j].lo - t1[j].lo);
-          }
-        } else if (keep[0]) {
+          for (int j = 0; j < 6; j++) sd_wtot[wv * 6 + j] = incl[j];
+          s_wcnt[wv] = kincl;
+        }
+        __syncthreads();
+        if (tid < NW * 6) {
+          const int ww = tid / 6, j = tid - ww * 6;
+          D2 run; run.hi = 0; run.lo = 0;
+          for (int w2 = 0; w2 < ww; w2++) run = split_add_renorm(run, sd_wtot[w2 * 6 + j]);
+          sd_woff[tid] = run;
+        } else if (tid < NW * 7) {
+          const int ww = tid - NW * 6;
+          int run = 0;
+          for (int w2 = 0; w2 < ww; w2++) run += s_wcnt[w2];
+          s_coff[ww] = run;
+          if (ww == NW - 1) s_coff[NW] = run + s_wcnt[ww];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          const D2 o = sd_woff[wv * 6 + j];
+          off[j].hi = (incl[j].hi - acc[j].hi) + o.hi;
+          off[j].lo = (incl[j].lo - acc[j].lo) + o.lo;
+        }
+        pos += s_coff[wv];
+        szd = s_coff[NW];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 6; j++) { off[j].hi = incl[j].hi - acc[j].hi; off[j].lo = incl[j].lo - acc[j].lo; }
+        szd = __builtin_amdgcn_readlane(kincl, 63);
+      }
+      // walk 2: replay the lane's points from its exclusive offset
+      for (int i = i0; i < i1; i++) {
+        const unsigned long long st = in_lds ? skeys[i] : gkeys[i];
+        if (st >> 63) {
+          const double x = (int)(st & 0x3FFF) * .5 + 0.5, y = (int)((st >> 14) & 0x3FFF) * .5 + 0.5;
+          const double Wt = __dsqrt_rn((double)(int)((st >> 28) & 0x3FFFF)) + 1;
+          const double tt[6] = {Wt * x, Wt * y, Wt * x * x, Wt * x * y, Wt * y * y, Wt};
           double* o = lf + (size_t)pos * 6;
 #pragma unroll
-          for (int j = 0; j < 6; j++) o[j] = w[j].hi + w[j].lo;
+          for (int j = 0; j < 6; j++) {
+            const D2 t = split_term(tt[j]);
+            off[j].hi += t.hi; off[j].lo += t.lo;
+            o[j] = off[j].hi + off[j].lo;
+          }
+          pos++;
         }
       }
-      szd = cnt_carry;
     } else {
       // EPT consecutive elements per lane: the DPP scan, the barrier and the carry traffic are paid once
       // per EPT elements; the lane's own elements are separated again after the scan by subtraction
