@@ -360,8 +360,8 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
     const unsigned cus = (unsigned)D->num_cus;
     auto minu = [](unsigned a, unsigned b) { return a < b ? a : b; };
     FqClass* c = D->cls;
-    c[0] = {64, 256, 0, 256, minu(16u * cus, 4096u * (unsigned)B), 256, 16};
-    c[1] = {128, 1024, 256, 1024, minu(8u * cus, 1024u * (unsigned)B), 1024, 8};
+    c[0] = {64, 256, 0, 256, minu((unsigned)FQ_GRID_64 * cus, 4096u * (unsigned)B), 256, 16};
+    c[1] = {128, 1024, 256, 1024, minu((unsigned)FQ_GRID_128 * cus, 1024u * (unsigned)B), 1024, 8};
     c[2] = {256, 4096, 1024, 4096, minu(4u * cus, 256u * (unsigned)B), 4096, 2};
     c[3] = {256, 8192, 4096, 8192, minu(2u * cus, 64u * (unsigned)B), 8192, 1};
     c[4] = {512, 16384, 8192, 0x7FFFFFFF, minu(cus, 16u * (unsigned)B), P.max_cluster_points, 1};

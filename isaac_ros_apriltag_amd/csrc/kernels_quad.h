@@ -449,10 +449,15 @@ template <int NT, bool SPLIT>
 #define FQ_TABLE_DOUBLES 290   // six 45-entry pair tables, 4 lines x 4 parameters, 4 line mse
 #define FQ_PIDX(a, b) ((((a) * (19 - (a))) >> 1) + (b) - (a) - 1)   // a < b < 10 -> 0..44
 #ifndef FQ_WPE_64
-#define FQ_WPE_64 5
-#define FQ_WPE_128 5
+#define FQ_WPE_64 4
+#define FQ_WPE_128 4
 #define FQ_WPE_256 4
 #define FQ_WPE_512 2
+#endif
+// persistent workgroups per CU of the two small classes (they fill FQ_WPE waves per SIMD when alone on a CU)
+#ifndef FQ_GRID_64
+#define FQ_GRID_64 16
+#define FQ_GRID_128 8
 #endif
 // second launch-bound argument = minimum waves per SIMD the register allocation must allow
 __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 : NT == 256 ? FQ_WPE_256 : FQ_WPE_512)) void k_fit_quads(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
@@ -885,6 +890,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     // for clusters that do not fit it
     double* ea = in_lds ? reinterpret_cast<double*>(skeys) : gerrs_a;
     // (indices wrap with compare/subtract: integer division by a run-time value costs ~40 instructions)
+    // (two interleaved fits per trip for instruction-level parallelism measured no gain)
     for (int i = tid; i < szd; i += NT) {
       double e;
       const int i0 = (i >= ksz) ? i - ksz : i - ksz + szd;
