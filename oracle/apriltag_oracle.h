@@ -9,9 +9,15 @@
  * and AprilRobotics' apriltag is not vendored/installed.  This file restates
  * the published AprilTag-3 algorithm (Olson 2011; Wang & Olson 2016; AprilRobotics/apriltag 3.x,
  * BSD-2) from its public description; it is pinned against the reference's golden vector
- * (isaac_ros_apriltag/test/isaac_ros_apriltag_pol_test.py:113-175) and against the analytic ground
- * truth of the in-repo renderer.  Where the public algorithm accumulates in a data-dependent order
- * (hash iteration), this restatement fixes a canonical order; those places are marked CANONICAL.
+ * (isaac_ros_apriltag/test/isaac_ros_apriltag_pol_test.py:113-175), against the analytic ground
+ * truth of the in-repo renderer, and its tag tables against the published generator's procedure
+ * (tools/gen_tag_family.c reproduces tag16h5, tag25h9 and the 587 codes of tag36h11).  Where the public
+ * algorithm accumulates in a data-dependent order (hash iteration), this restatement fixes a canonical
+ * order; those places are marked CANONICAL.  The steps it formulates differently from upstream can be
+ * switched to upstream's formulation (ato_params_t.variant) so that the distance is measured, not
+ * assumed (tests/test_oracle_variants_cpu.py).  An optional cross-check against a real libapriltag.so
+ * exists (oracle/aprilrobotics_xcheck.py); none was available, so parity with AprilRobotics' binary
+ * remains unpinned.
  */
 #ifndef APRILTAG_ORACLE_H_
 #define APRILTAG_ORACLE_H_
