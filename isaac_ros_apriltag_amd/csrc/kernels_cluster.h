@@ -133,7 +133,9 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   // remembered as a bit of emask plus the byte index of its table entry (0xFF: the table was full), so
   // that pass 2 does not walk the neighbourhood again
   // (Aggregating the table inserts and counter atomics of pass 1 over the wave -- one leader per distinct key -- was
-  // measured slower, 9.6 vs 6.1 ms: a 64-pixel row step meets too many distinct component pairs.)
+  // measured slower, 9.6 vs 6.1 ms: a 64-pixel row step meets too many distinct component pairs.  Taking the rank
+  // of an emission from the value the counting atomic returns (so that pass 2 needs no atomics and no block scan) was
+  // slower too, 7.8 ms: the returning LDS atomics on the few hot pair counters stall the wave, the list costs occupancy.)
   uint32_t cnt = 0;
   uint32_t emask = 0;
   uint32_t eidx[4] = {0, 0, 0, 0};
