@@ -8,7 +8,8 @@
 //   k_cc_local   one 64x64 tile per 256-thread block, entirely in LDS: wave-ballot run labelling
 //                of each 64-pixel row (no atomics), lock-free atomicMin union of rows, flatten,
 //                per-run size counting; writes global labels (index of the tile-local root), the
-//                local size at root pixels, and appends the tile's roots to a per-frame root list.
+//                local size at root pixels, and appends the roots of components that touch the tile's
+//                perimeter (the only ones that can merge with another tile) to a per-frame root list.
 //   k_cc_border  unions across tile borders with global atomicMin (only first-overlap pixels).
 //   k_cc_sizes   over the root list only: every tile-local root is pointed at its final representative
 //                and its pixel count is added there.  Pixels keep the index of their tile-local root, so
@@ -155,6 +156,8 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
       const unsigned long long higher = (lane == 63) ? 0ull : (S & ~((2ull << lane) - 1ull));
       const int e = higher ? __ffsll((long long)higher) - 1 : 64;
       atomicAdd(&sl[root[k]], (uint32_t)(e - lane));
+      // a component can only ever merge with another tile's through a pixel on the tile's perimeter: flag it (bit 31)
+      if (r == 0 || r == CC_T - 1 || lane == 0 || e == 64) atomicOr(&sl[root[k]], 0x80000000u);
     }
   }
   __syncthreads();
@@ -168,9 +171,14 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   uint32_t* roots = roots_all + (size_t)frame * W * H;
   if (tid == 0) s_nroots = 0;
   __syncthreads();
+  // Only roots of components that touch the perimeter go to the root list: every other component is complete inside
+  // this tile (its label and size are final here), so the passes over the list (k_cc_sizes, k_cc_resolve) skip the
+  // interior specks that make up most components of a noisy frame.
   uint32_t myroots = 0;
-  for (int k = 0; k < 16; k++)
-    if (root[k] != AT_NO_LABEL && root[k] == (uint32_t)((wv * 16 + k) * CC_T + lane)) myroots++;
+  for (int k = 0; k < 16; k++) {
+    const uint32_t me = (uint32_t)((wv * 16 + k) * CC_T + lane);
+    if (root[k] != AT_NO_LABEL && root[k] == me && (sl[me] >> 31)) myroots++;
+  }
   uint32_t rpos = myroots ? atomicAdd(&s_nroots, myroots) : 0;
   __syncthreads();
   if (tid == 0) s_rbase = s_nroots ? atomicAdd(&counters[frame].nroots, s_nroots) : 0;
@@ -186,7 +194,11 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
       if (root[k] == AT_NO_LABEL) { label[gi] = AT_NO_LABEL; continue; }
       const uint32_t rr = root[k] / CC_T, rc = root[k] % CC_T;
       label[gi] = (uint32_t)((Y0 + rr) * W + X0 + rc);
-      if (root[k] == me) { csize[gi] = sl[me]; roots[rpos++] = (uint32_t)gi; }
+      if (root[k] == me) {
+        const uint32_t cs = sl[me];
+        csize[gi] = cs & 0x7FFFFFFFu;
+        if (cs >> 31) roots[rpos++] = (uint32_t)gi;
+      }
     }
   }
 }
@@ -199,20 +211,24 @@ __device__ __forceinline__ void cc_global_links(const uint8_t* thr, uint32_t* la
   const uint32_t v = thr[(size_t)gy * WS + gx];
   if (v == 127) return;
   const uint32_t me = (uint32_t)(gy * W + gx);
+  // The entry of a pixel that is not a tile-local root never changes in this kernel (only root entries are
+  // lowered by atomicMin), so the first hop of either endpoint -- pixel -> its tile-local root -- is a plain cached
+  // load; the device-scope loads of the find start at the roots.
+  auto link = [&](uint32_t other) { glb_union(label, label[me], label[other]); };
   const uint32_t vl = thr[(size_t)gy * WS + gx - 1];
-  if ((which & 1) && vl == v) glb_union(label, me, me - 1);
+  if ((which & 1) && vl == v) link(me - 1);
   if (gy == 0) return;
   const uint32_t vu = thr[(size_t)(gy - 1) * WS + gx];
   const uint32_t vul = thr[(size_t)(gy - 1) * WS + gx - 1];
   const bool left_src = gx - 1 >= 1;
-  if ((which & 2) && vu == v && !(left_src && vl == v && vul == v)) glb_union(label, me, me - W);
+  if ((which & 2) && vu == v && !(left_src && vl == v && vul == v)) link(me - W);
   if (v == 255) {
-    if ((which & 4) && vul == 255 && vu != 255 && !(left_src && vl == 255)) glb_union(label, me, me - W - 1);
+    if ((which & 4) && vul == 255 && vu != 255 && !(left_src && vl == 255)) link(me - W - 1);
     if (which & 8) {
       const uint32_t vur = thr[(size_t)(gy - 1) * WS + gx + 1];
       const uint32_t vr = thr[(size_t)gy * WS + gx + 1];
       const bool right_src = gx + 1 <= W - 2;
-      if (vur == 255 && !(right_src && (vu == 255 || vr == 255))) glb_union(label, me, me - W + 1);
+      if (vur == 255 && !(right_src && (vu == 255 || vr == 255))) link(me - W + 1);
     }
   }
 }

@@ -301,8 +301,10 @@ __global__ __launch_bounds__(1024) void k_cluster_select(const unsigned long lon
   const uint32_t slot = blockIdx.x * 1024 + threadIdx.x;
   const bool in_range = slot < P.hcap;
   const size_t hi = (size_t)frame * P.hcap + (in_range ? slot : 0);
-  const unsigned long long key = in_range ? hkeys_all[hi] : AT_EMPTY_KEY;
+  // a slot holds a key exactly when its count is non-zero (every insert is followed by an add of at least one point),
+  // so the 8-byte keys of the ~95 % empty slots are never read
   const uint32_t c = in_range ? hcnt_all[hi] : 0;
+  const unsigned long long key = c ? hkeys_all[hi] : AT_EMPTY_KEY;
   // a frame whose point staging overflowed has pair counts that exceed what was staged: it yields no
   // clusters at all (the overflow bit is reported), never an out-of-range range
   const bool frame_ok = (counters[frame].flags & 0x1u) == 0;
