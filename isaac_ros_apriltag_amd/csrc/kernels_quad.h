@@ -8,16 +8,19 @@
 // in a scratch slot owned by the workgroup (reused cluster after cluster, so it stays cache-resident) instead
 // of 48 bytes per boundary point of every frame.  Per cluster:
 //   bbox / gradient-dot: seven DPP wave reductions, one barrier -> slope keys, stored so that their order
-//   as IEEE doubles is the wanted order -> bitonic sort in LDS (first three levels in registers, then up
-//   to three network steps per pass, compare-exchange = v_min_f64 + v_max_f64) -> one sweep that drops
-//   duplicate points, widens the weighted moment terms to fixed point (sums are exact there), scans them
-//   (DPP wave scan, 96 bits inside a wave; wave totals combined in two levels through LDS) and rounds
-//   every prefix once (bit-identical to the CPU definition in any order) -> windowed line-fit errors,
-//   7-tap smoothing -> local maxima compacted into LDS -> wave 0 alone: top-10 selection (rank among
-//   <= 64 candidates, else 11 arg-max rounds) -> table of the 45 pairwise segment fits (all threads) ->
-//   wave 0 alone: best of the C(10,4) corner choices, 4 line fits, intersections, area/angle checks.
-// Per-phase shader-cycle counters exist behind -DAMDAT_FQ_PROFILE (tools/build_variants.py); the product
-// build carries none.
+//   as IEEE doubles is the wanted order -> bitonic sort in LDS on an array padded to a power of two with
+//   +infinity keys (first three levels in registers, then up to three network steps per pass, no bounds
+//   tests, compare-exchange = v_min_f64 + v_max_f64) -> moment sweep: duplicate points dropped, weighted
+//   moment terms summed EXACTLY and every prefix rounded once (bit-identical to the CPU definition in any
+//   order).  Fast path (images up to 2048 x 2048): sums carried as two doubles, two walks over
+//   lane-contiguous points with one scan per cluster; general path: 128-bit fixed point, one DPP scan per
+//   chunk.  -> windowed line-fit errors, 7-tap smoothing -> local maxima compacted into LDS -> wave 0
+//   alone: top-10 selection (rank among <= 64 candidates, else 11 arg-max rounds) -> table of the 45
+//   pairwise segment fits (all threads) -> wave 0 alone: best of the C(10,4) corner choices, 4 line fits,
+//   intersections, lane-parallel area / angle checks.
+// Tools-only builds: -DAMDAT_FQ_PROFILE (per-phase shader-cycle counters), -DAMDAT_FQ_STOP=n (drop every
+// cluster after phase n, for per-phase instruction counts); isaac_ros_apriltag_amd.build.build_amd_variant.
+// The product build carries neither.
 #pragma once
 #include "common.h"
 
