@@ -642,9 +642,11 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       //           with what walk 2 needs (kept flag, coordinates, squared gradient);
       //   scan    lane totals over the wave (DPP) and the waves (LDS), kept-point counts alongside;
       //   walk 2  every lane replays its points from its exclusive offset and rounds each prefix once.
-      // E is odd, so that the lanes' key slots (stride E * 8 bytes) fall into different LDS banks.
+      // From 8 points per lane on, E is made odd so that the lanes' key slots (stride E * 8 bytes) fall into different
+      // LDS banks.
       const int lane = lane_id(), wv = tid >> 6;
-      const int E = ((sz + NT - 1) / NT) | 1;
+      int E = (sz + NT - 1) / NT;
+      if (E >= 8) E |= 1;   // (small strides cost at most a 4-way conflict; an odd E of 3 or 5 would idle a third of the lanes)
       const int i0 = tid * E, i1 = min(sz, i0 + E);
       D2* const sd_wtot = reinterpret_cast<D2*>(s_wtot);
       D2* const sd_woff = reinterpret_cast<D2*>(s_woff);
