@@ -551,7 +551,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
   mark();
   {
     const int nrows = (P.H - 1) / CC_T, ncols = (P.W - 1) / CC_T;
-    const long total = (long)nrows * P.W + 2L * ncols * P.H;
+    const long total = (long)nrows * P.W + (long)ncols * P.H;
     if (total > 0)
       hipLaunchKernelGGL(k_cc_border, dim3((unsigned)((total + 255) / 256), 1, n), dim3(256), 0, s, D->d_thr, D->d_label, P);
   }

@@ -233,7 +233,29 @@ __device__ __forceinline__ void cc_global_links(const uint8_t* thr, uint32_t* la
   }
 }
 
-// grid.x covers [border rows: nrows*W pixels][left columns: ncols*H][right columns: ncols*H]
+// Links across the vertical border between column gx - 1 (last of the left tile) and gx (first of the right tile) in
+// row gy, with the rules of cc_global_links: the left link and the up-left link of pixel (gx, gy), and the up-right link
+// of pixel (gx - 1, gy).  All three read the same 2 x 2 block of the threshold image, so one thread takes them (on
+// tile-top rows only the left link: the row pass owns every upward link of those rows).
+__device__ __forceinline__ void cc_column_links(const uint8_t* thr, uint32_t* label, int W, int H, int WS, int gx, int gy) {
+  if (gy >= H) return;
+  const uint32_t vL = thr[(size_t)gy * WS + gx - 1], vR = thr[(size_t)gy * WS + gx];
+  const bool upward = (gy % CC_T) != 0;
+  uint32_t vLu = 127, vRu = 127;
+  if (upward) { vLu = thr[(size_t)(gy - 1) * WS + gx - 1]; vRu = thr[(size_t)(gy - 1) * WS + gx]; }
+  const uint32_t meR = (uint32_t)(gy * W + gx), meL = meR - 1;
+  auto link = [&](uint32_t a, uint32_t b2) { glb_union(label, label[a], label[b2]); };
+  if (gx <= W - 2 && vR != 127) {                      // (gx, gy) is a link source
+    if (vL == vR) link(meR, meL);
+    if (upward && vR == 255 && vLu == 255 && vRu != 255 && vL != 255) link(meR, meR - W - 1);
+  }
+  if (upward && vL == 255) {                            // (gx - 1, gy) is a source (1 <= gx - 1 <= W - 2 always)
+    const bool right_src = gx <= W - 2;
+    if (vRu == 255 && !(right_src && (vLu == 255 || vR == 255))) link(meL, meL - W + 1);
+  }
+}
+
+// grid.x covers [border rows: nrows*W pixels][tile columns: ncols*H]
 __global__ __launch_bounds__(256) void k_cc_border(const uint8_t* __restrict__ thr_all, uint32_t* __restrict__ label_all,
                                                    DetParams P) {
   const int frame = (int)blockIdx.z + P.frame0;
@@ -249,16 +271,7 @@ __global__ __launch_bounds__(256) void k_cc_border(const uint8_t* __restrict__ t
     return;
   }
   i -= nrows * W;
-  if (i < ncols * H) {  // first column of a tile: left link always, up-left unless on a tile-top row
-    const int gx = (i / H + 1) * CC_T, gy = i % H;
-    cc_global_links(thr, label, W, H, P.WS, gx, gy, (gy % CC_T) ? (1 | 4) : 1);
-    return;
-  }
-  i -= ncols * H;
-  if (i < ncols * H) {  // last column of a tile: up-right crosses into the next tile
-    const int gx = (i / H + 1) * CC_T - 1, gy = i % H;
-    if (gy % CC_T) cc_global_links(thr, label, W, H, P.WS, gx, gy, 8);
-  }
+  if (i < ncols * H) cc_column_links(thr, label, W, H, P.WS, (i / H + 1) * CC_T, i % H);
 }
 
 // one thread per tile-local root of the frame
