@@ -105,6 +105,24 @@ __device__ __forceinline__ uint32_t float_sortable(float f) {
 // and is exact (amdAprilTagsDebugMath op 2 checks it on the device against IEEE on 200 000 operands).
 __device__ __forceinline__ float at_sqrtf_rn(float x) { return sqrtf(x); }
 
+// Correctly rounded double square root of an integer below 2^18 (the squared gradient magnitudes of the line-fit
+// weights, at most 2 * 255^2): v_rsq_f32 seed (about 23 bits), one coupled Goldschmidt step (46 bits) and one
+// residual correction, which lands within 2^-88 of the root before the final rounding.  Less than half the
+// instructions of the generic double-precision expansion (no v_rsq_f64, no range scaling).  Equality with IEEE sqrt
+// holds for every one of the 2^18 arguments even when the seed is off by +-8 ulp (checked exhaustively on the host),
+// and tests/test_gpu_parity.py checks all of them on the device (amdAprilTagsDebugMath op 5).
+__device__ __forceinline__ double sqrt_u18(uint32_t G) {
+  const float gf = (float)G;
+  const float r0 = __builtin_amdgcn_rsqf(fmaxf(gf, 1e-30f));   // G = 0: s stays 0 through every step
+  const double g = (double)G, r = (double)r0;
+  double s = g * r, h = 0.5 * r;
+  const double e = __fma_rn(-h, s, 0.5);
+  s = __fma_rn(s, e, s);
+  h = __fma_rn(h, e, h);
+  const double d = __fma_rn(-s, s, g);
+  return __fma_rn(d, h, s);
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // wave-level inclusive scan (wave64)

@@ -176,6 +176,7 @@ __global__ void k_debug_math(int op, uint32_t n, const double* a, const double* 
   else if (op == 1) out[i] = a[i] / b[i];
   else if (op == 2) out[i] = (double)at_sqrtf_rn((float)a[i]);
   else if (op == 3) out[i] = (double)__fdiv_rn((float)a[i], (float)b[i]);
+  else if (op == 5) out[i] = sqrt_u18((uint32_t)a[i]);     // integer arguments below 2^18
   else out[i] = div_by(a[i], b[i], shared_recip(b[i]));   // the line fit's shared-reciprocal division
 }
 

@@ -597,7 +597,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
 
     // ---- slope keys + sort -----------------------------------------------------------------------
     const float cx = (float)cxd, cy = (float)cyd;
-    const bool in_lds = sz <= sort_cap;
+    // only the largest class (512 threads) can meet clusters beyond its LDS key array: every smaller instance
+    // addresses LDS unconditionally (no generic-address loads)
+    const bool in_lds = NT < 512 || sz <= sort_cap;
     for (int i = tid; i < sz; i += NT) {
       const uint32_t p = pts[i];
       const int x = (int)(p >> 18), y = (int)((p >> 4) & 0x3FFF);
@@ -671,7 +673,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
             const int grad_y = (int)gray[(size_t)(iy + 1) * gpitch + ix] - (int)gray[(size_t)(iy - 1) * gpitch + ix];
             G = (uint32_t)(grad_x * grad_x + grad_y * grad_y);
           }
-          const double Wt = __dsqrt_rn((double)(int)G) + 1;
+          const double Wt = sqrt_u18(G) + 1;
           const double tt[6] = {Wt * x, Wt * y, Wt * x * x, Wt * x * y, Wt * y * y, Wt};
 #pragma unroll
           for (int j = 0; j < 6; j++) {
@@ -737,7 +739,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
         const unsigned long long st = in_lds ? skeys[i] : gkeys[i];
         if (st >> 63) {
           const double x = (int)(st & 0x3FFF) * .5 + 0.5, y = (int)((st >> 14) & 0x3FFF) * .5 + 0.5;
-          const double Wt = __dsqrt_rn((double)(int)((st >> 28) & 0x3FFFF)) + 1;
+          const double Wt = sqrt_u18((uint32_t)(st >> 28) & 0x3FFFFu) + 1;
           const double tt[6] = {Wt * x, Wt * y, Wt * x * x, Wt * x * y, Wt * y * y, Wt};
           double* o = lf + (size_t)pos * 6;
 #pragma unroll

@@ -54,6 +54,9 @@ def test_device_arithmetic_is_ieee(built):
     nmr[::7] = W[::7] * np.rint(rng.standard_normal(W[::7].size) * 1000)          # exact quotients
     nmr[3::11] = W[3::11] * (np.rint(rng.standard_normal(W[3::11].size) * 1e6) + 0.5) * 2.0 ** -30   # near ties
     assert np.array_equal(capi.debug_math(4, nmr, W), nmr / W)
+    # the line-fit weights' integer square root (sqrt_u18), every possible argument
+    g = np.arange(1 << 18, dtype=np.float64)
+    assert np.array_equal(capi.debug_math(5, g, g), np.sqrt(g))
 
 
 @pytest.mark.parametrize("name,scene,families,decimate", [

@@ -27,6 +27,8 @@ def math_check():
     af, bf = a.astype(np.float32), b.astype(np.float32)
     r = capi.debug_math(2, a, b); e = np.sqrt(af).astype(np.float64); ok &= np.array_equal(r, e); print("sqrt f32 exact:", np.array_equal(r, e))
     r = capi.debug_math(3, a, b); e = (af / bf).astype(np.float64); ok &= np.array_equal(r, e); print("div f32 exact:", np.array_equal(r, e))
+    g = np.arange(1 << 18, dtype=np.float64)
+    r = capi.debug_math(5, g, g); ok &= np.array_equal(r, np.sqrt(g)); print("sqrt_u18 exact:", np.array_equal(r, np.sqrt(g)))
     return ok
 
 
