@@ -504,6 +504,7 @@ static int check_images(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTa
     if (!images[i].dev_ptr) return AMDAT_INVALID_ARGUMENT;
     if (images[i].width != D->cfg.width || images[i].height != D->cfg.height) return AMDAT_SIZE_MISMATCH;
     if (images[i].pitch < images[i].width) return AMDAT_INVALID_ARGUMENT;
+    if ((uint64_t)images[i].pitch * images[i].height > 0x7FFFFFFFull) return AMDAT_INVALID_ARGUMENT;   // 32-bit pixel offsets on the device
   }
   return AMDAT_SUCCESS;
 }

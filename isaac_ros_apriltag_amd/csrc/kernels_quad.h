@@ -551,6 +551,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     const FrameDesc fd = frames[frame];
     const uint8_t* gray = (P.decimate > 1) ? gray_all + (size_t)frame * P.H * P.WS : fd.img;
     const int gpitch = (P.decimate > 1) ? P.WS : (int)fd.pitch;
+    const __attribute__((address_space(1))) uint8_t* const ggray = (const __attribute__((address_space(1))) uint8_t*)gray;   // global, not generic
     const ClusterRec cl = clusters_all[(size_t)frame * P.ccap + (wi & 0xFFFFu)];
     const int sz = (int)cl.count;
     if (sz < 24 || sz > slot_cap) continue;   // (the work list only holds clusters of this class)
@@ -666,11 +667,14 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
         const uint32_t px = (uint32_t)((key >> 4) & 0x3FFF), py = (uint32_t)((key >> 18) & 0x3FFF);
         uint32_t G = 0;   // squared gradient magnitude; 0 also stands for "no gradient taken" (weight 1 either way)
         if (keep) {
-          const double x = (int)px * .5 + 0.5, y = (int)py * .5 + 0.5;
-          const int ix = (int)x, iy = (int)y;
-          if (ix > 0 && ix + 1 < W && iy > 0 && iy + 1 < H) {
-            const int grad_x = (int)gray[(size_t)iy * gpitch + ix + 1] - (int)gray[(size_t)iy * gpitch + ix - 1];
-            const int grad_y = (int)gray[(size_t)(iy + 1) * gpitch + ix] - (int)gray[(size_t)(iy - 1) * gpitch + ix];
+          // x = px / 2 + 1/2 exactly; its integer part and the image offset stay in 32-bit integers (a frame spans
+          // less than 2^31 bytes, checked at submission), the four neighbours are loaded before the first is used
+          const double x = (int)(px + 1) * .5, y = (int)(py + 1) * .5;
+          const int ix = (int)((px + 1) >> 1), iy = (int)((py + 1) >> 1);
+          if (((unsigned)(ix - 1) < (unsigned)(W - 2)) & ((unsigned)(iy - 1) < (unsigned)(H - 2))) {
+            const uint32_t o = (uint32_t)iy * (uint32_t)gpitch + (uint32_t)ix;
+            const int g_r = ggray[o + 1], g_l = ggray[o - 1], g_d = ggray[o + (uint32_t)gpitch], g_u = ggray[o - (uint32_t)gpitch];
+            const int grad_x = g_r - g_l, grad_y = g_d - g_u;
             G = (uint32_t)(grad_x * grad_x + grad_y * grad_y);
           }
           const double Wt = sqrt_u18(G) + 1;
@@ -738,7 +742,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       for (int i = i0; i < i1; i++) {
         const unsigned long long st = in_lds ? skeys[i] : gkeys[i];
         if (st >> 63) {
-          const double x = (int)(st & 0x3FFF) * .5 + 0.5, y = (int)((st >> 14) & 0x3FFF) * .5 + 0.5;
+          const double x = (int)(((uint32_t)st & 0x3FFFu) + 1u) * .5, y = (int)(((uint32_t)(st >> 14) & 0x3FFFu) + 1u) * .5;
           const double Wt = sqrt_u18((uint32_t)(st >> 28) & 0x3FFFFu) + 1;
           const double tt[6] = {Wt * x, Wt * y, Wt * x * x, Wt * x * y, Wt * y * y, Wt};
           double* o = lf + (size_t)pos * 6;
