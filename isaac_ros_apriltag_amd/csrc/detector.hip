@@ -586,7 +586,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
   mark();
   {
     // keys | pair-table region
-    auto lds_bytes = [](const FqClass& c) { return (size_t)c.sort_cap * 8 + (size_t)FQ_TABLE_DOUBLES * 8; };
+    auto lds_bytes = [](const FqClass& c) { return (size_t)FQ_KP(c.sort_cap) * 8 + (size_t)FQ_TABLE_DOUBLES * 8; };   // skewed key array
 
     // The classes are independent (they only append to the quad list), so they run concurrently.  The
     // runtime multiplexes streams onto four hardware queues, and two streams on one queue serialise, so exactly

@@ -319,7 +319,13 @@ __device__ __forceinline__ void bitonic_group(unsigned long long (&v)[8], bool f
 // PADDED: the array physically holds +infinity keys in [n, 2^lpow), so loads and stores need no bounds tests (a
 // group that lies entirely in the pad region is skipped with one comparison: the pads never move, every exchange
 // puts the smaller key at the lower index).
-template <int NT, int R, bool PADDED, typename KeyPtr>
+// SKEW: the array is the LDS key array, stored with one unused slot after every 32 keys (FQ_KP): a thread's 2^R keys
+// lie 2^lsp apart, so without the skew the lanes of a wave -- consecutive groups -- would meet in 2^lsp of the 32
+// eight-byte bank pairs whenever lsp < 5 (the last two passes of every merge level: 8- to 32-way conflicts, measured
+// as 60 % of the kernel's LDS cycles).  The physical index of a group's e-th key is FQ_KP(first key) plus a uniform
+// offset, because the keys of a group either share a 32-key row or lie whole rows apart.
+#define FQ_KP(i) ((i) + ((i) >> 5))
+template <int NT, int R, bool PADDED, bool SKEW, typename KeyPtr>
 __device__ __forceinline__ void bitonic_pass_r(KeyPtr A, int n, int lpow, int lk, int s) {
   // steps s .. s+R-1 of merge level lk (step 0 = flip of 2^lk blocks, step t = half-cleaner of stride 2^(lk-1-t))
   constexpr int M = 1 << R;
@@ -328,20 +334,30 @@ __device__ __forceinline__ void bitonic_pass_r(KeyPtr A, int n, int lpow, int lk
   // spacing of the group's elements: 2^lsp, where the last step's stride is 2^(lk-1-(s+R-1)) = 2^lsp
   const int lsp = lk - s - R;
   const int spm = (1 << lsp) - 1;
+  int soff[M];   // uniform: physical offset of the e-th key of a run that starts in a row's first 2^lsp slots
+#pragma unroll
+  for (int e = 0; e < M; e++) soff[e] = SKEW ? FQ_KP(e << lsp) : (e << lsp);
   for (int g = threadIdx.x; g < ngroups; g += NT) {
-    int idx[M];
+    int idx[M];    // physical indices
+    int lidx[M];   // logical indices (bounds tests of the unpadded variant; dead code otherwise)
     if (s == 0) {
       // lower side ascending, upper side mirrored: positions 0..M/2-1 are x_e, M/2..M-1 are y_(M/2-1-e')
       const int blk = g >> lsp, off = g & spm;
       const int lo = (blk << lk) + off, hi = (blk << lk) + (1 << lk) - 1 - off;
+      const int hi0 = hi - ((M / 2 - 1) << lsp);   // lowest key of the upper side
+      const int plo = SKEW ? FQ_KP(lo) : lo, phi0 = SKEW ? FQ_KP(hi0) : hi0;
 #pragma unroll
-      for (int e = 0; e < M / 2; e++) { idx[e] = lo + (e << lsp); idx[M - 1 - e] = hi - (e << lsp); }
+      for (int e = 0; e < M / 2; e++) {
+        idx[e] = plo + soff[e]; idx[M - 1 - e] = phi0 + soff[M / 2 - 1 - e];
+        lidx[e] = lo + (e << lsp); lidx[M - 1 - e] = hi - (e << lsp);
+      }
     } else {
       const int base = ((g >> lsp) << (lsp + R)) + (g & spm);
+      const int pbase = SKEW ? FQ_KP(base) : base;
 #pragma unroll
-      for (int e = 0; e < M; e++) idx[e] = base + (e << lsp);
+      for (int e = 0; e < M; e++) { idx[e] = pbase + soff[e]; lidx[e] = base + (e << lsp); }
     }
-    if (idx[1] >= n) continue;  // at most one real element: nothing to exchange
+    if (lidx[1] >= n) continue;  // at most one real element: nothing to exchange
     unsigned long long v[8];
     if (PADDED) {
 #pragma unroll
@@ -351,18 +367,18 @@ __device__ __forceinline__ void bitonic_pass_r(KeyPtr A, int n, int lpow, int lk
       for (int e = 0; e < M; e++) A[idx[e]] = v[e];
     } else {
 #pragma unroll
-      for (int e = 0; e < M; e++) v[e] = idx[e] < n ? A[idx[e]] : INF;
+      for (int e = 0; e < M; e++) v[e] = lidx[e] < n ? A[idx[e]] : INF;
       bitonic_group<R>(v, s == 0);
 #pragma unroll
       for (int e = 0; e < M; e++)
-        if (idx[e] < n) A[idx[e]] = v[e];
+        if (lidx[e] < n) A[idx[e]] = v[e];
     }
   }
   __syncthreads();
 }
 
 // merge levels 1..3 in one pass: every thread sorts 8 consecutive elements in registers
-template <int NT, bool PADDED, typename KeyPtr>
+template <int NT, bool PADDED, bool SKEW, typename KeyPtr>
 __device__ __forceinline__ void bitonic_first8(KeyPtr A, int n, int lpow) {
   auto ce = [](unsigned long long& lo, unsigned long long& hi) {
     const double a = __longlong_as_double((long long)lo), b = __longlong_as_double((long long)hi);
@@ -376,9 +392,10 @@ __device__ __forceinline__ void bitonic_first8(KeyPtr A, int n, int lpow) {
   for (int g = threadIdx.x; g < ngroups; g += NT) {
     const int base = g << 3;
     if (base + 1 >= n) continue;
+    const int pb = SKEW ? FQ_KP(base) : base;   // eight keys of one 32-key row
     unsigned long long v[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) v[e] = (PADDED || base + e < n) ? A[base + e] : AT_KEY_PAD;
+    for (int e = 0; e < 8; e++) v[e] = (PADDED || base + e < n) ? A[pb + e] : AT_KEY_PAD;
 #pragma unroll
     for (int lk = 1; lk <= 3; lk++) {
       const int k = 1 << lk;
@@ -396,22 +413,22 @@ __device__ __forceinline__ void bitonic_first8(KeyPtr A, int n, int lpow) {
     }
 #pragma unroll
     for (int e = 0; e < 8; e++)
-      if (PADDED || base + e < n) A[base + e] = v[e];
+      if (PADDED || base + e < n) A[pb + e] = v[e];
   }
   __syncthreads();
 }
 
-template <int NT, bool PADDED, typename KeyPtr>
+template <int NT, bool PADDED, bool SKEW, typename KeyPtr>
 __device__ __forceinline__ void bitonic_sort_block2(KeyPtr A, int n, int lpow) {
   int lk0 = 1;
-  if (lpow >= 3) { bitonic_first8<NT, PADDED>(A, n, lpow); lk0 = 4; }
+  if (lpow >= 3) { bitonic_first8<NT, PADDED, SKEW>(A, n, lpow); lk0 = 4; }
   for (int lk = lk0; lk <= lpow; lk++) {
     int s = 0;
     while (s < lk) {
       const int left = lk - s;
-      if (left >= 3) { bitonic_pass_r<NT, 3, PADDED>(A, n, lpow, lk, s); s += 3; }
-      else if (left == 2) { bitonic_pass_r<NT, 2, PADDED>(A, n, lpow, lk, s); s += 2; }
-      else { bitonic_pass_r<NT, 1, PADDED>(A, n, lpow, lk, s); s += 1; }
+      if (left >= 3) { bitonic_pass_r<NT, 3, PADDED, SKEW>(A, n, lpow, lk, s); s += 3; }
+      else if (left == 2) { bitonic_pass_r<NT, 2, PADDED, SKEW>(A, n, lpow, lk, s); s += 2; }
+      else { bitonic_pass_r<NT, 1, PADDED, SKEW>(A, n, lpow, lk, s); s += 1; }
     }
   }
 }
@@ -473,7 +490,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
                                                    int pop, DetParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fq_smem[];
   unsigned long long* skeys = reinterpret_cast<unsigned long long*>(fq_smem);
-  double* chunk = reinterpret_cast<double*>(fq_smem + (size_t)sort_cap * 8);
+  double* chunk = reinterpret_cast<double*>(fq_smem + (size_t)FQ_KP(sort_cap) * 8);   // (the key array is skewed)
   // pair tables alias the chunk buffer (used after the cumulative sums are finished)
   // six tables over the 45 index pairs a < b < 10 (triangular index FQ_PIDX)
   double* s_ferr = chunk; double* s_fmse = chunk + 45; double* s_fnx = chunk + 90; double* s_fny = chunk + 135;
@@ -613,7 +630,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       const float slope = quadrant + __fdiv_rn(dy, dx);
       const unsigned long long key = key_enc(((unsigned long long)float_sortable(slope) << 32) | ((unsigned long long)y << 18) |
                                              ((unsigned long long)x << 4) | (unsigned long long)(p & 15u));
-      if (in_lds) skeys[i] = key; else gkeys[i] = key;
+      if (in_lds) skeys[FQ_KP(i)] = key; else gkeys[i] = key;
     }
     int lpow = 0;
     while ((1 << lpow) < sz) lpow++;
@@ -621,11 +638,11 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     // without per-element bounds tests
     const bool padded = in_lds && (1 << lpow) <= sort_cap;
     if (padded)
-      for (int i = sz + tid; i < (1 << lpow); i += NT) skeys[i] = AT_KEY_PAD;
+      for (int i = sz + tid; i < (1 << lpow); i += NT) skeys[FQ_KP(i)] = AT_KEY_PAD;
     __syncthreads();
-    if (padded) bitonic_sort_block2<NT, true>(skeys, sz, lpow);
-    else if (in_lds) bitonic_sort_block2<NT, false>(skeys, sz, lpow);
-    else bitonic_sort_block2<NT, false>(gkeys, sz, lpow);
+    if (padded) bitonic_sort_block2<NT, true, true>(skeys, sz, lpow);
+    else if (in_lds) bitonic_sort_block2<NT, false, true>(skeys, sz, lpow);
+    else bitonic_sort_block2<NT, false, false>(gkeys, sz, lpow);
     FQ_TICK(2)
     FQ_STOP_AT(2)
 
@@ -654,14 +671,14 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       D2* const sd_wtot = reinterpret_cast<D2*>(s_wtot);
       D2* const sd_woff = reinterpret_cast<D2*>(s_woff);
       unsigned long long prev = 0;
-      if (i0 > 0 && i0 < sz) prev = key_dec(in_lds ? skeys[i0 - 1] : gkeys[i0 - 1]);
+      if (i0 > 0 && i0 < sz) prev = key_dec(in_lds ? skeys[FQ_KP(i0 - 1)] : gkeys[i0 - 1]);
       if (NW > 1) __syncthreads();   // every lane holds its predecessor key before any slot is rewritten
       D2 acc[6];
 #pragma unroll
       for (int j = 0; j < 6; j++) { acc[j].hi = 0; acc[j].lo = 0; }
       int kept = 0;
       for (int i = i0; i < i1; i++) {
-        const unsigned long long key = key_dec(in_lds ? skeys[i] : gkeys[i]);
+        const unsigned long long key = key_dec(in_lds ? skeys[FQ_KP(i)] : gkeys[i]);
         const bool keep = (i == 0) || ((key >> 4) != (prev >> 4));
         prev = key;
         const uint32_t px = (uint32_t)((key >> 4) & 0x3FFF), py = (uint32_t)((key >> 18) & 0x3FFF);
@@ -688,7 +705,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
         }
         const unsigned long long stash = ((unsigned long long)(keep ? 1u : 0u) << 63) | ((unsigned long long)G << 28) |
                                          ((unsigned long long)py << 14) | (unsigned long long)px;
-        if (in_lds) skeys[i] = stash; else gkeys[i] = stash;
+        if (in_lds) skeys[FQ_KP(i)] = stash; else gkeys[i] = stash;
       }
       // lane totals onto the grid (|lo| <= 2^-7), then the inclusive scans
       D2 incl[6];
@@ -740,7 +757,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       }
       // walk 2: replay the lane's points from its exclusive offset
       for (int i = i0; i < i1; i++) {
-        const unsigned long long st = in_lds ? skeys[i] : gkeys[i];
+        const unsigned long long st = in_lds ? skeys[FQ_KP(i)] : gkeys[i];
         if (st >> 63) {
           const double x = (int)(((uint32_t)st & 0x3FFFu) + 1u) * .5, y = (int)(((uint32_t)(st >> 14) & 0x3FFFu) + 1u) * .5;
           const double Wt = sqrt_u18((uint32_t)(st >> 28) & 0x3FFFFu) + 1;
@@ -779,8 +796,8 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
           const int i = base + tid * EPT + e;
           keep[e] = false;
           if (i < sz) {
-            const unsigned long long key = key_dec(in_lds ? skeys[i] : gkeys[i]);
-            const unsigned long long prev = (e > 0) ? prev_key : ((i > 0) ? key_dec(in_lds ? skeys[i - 1] : gkeys[i - 1]) : ~key);
+            const unsigned long long key = key_dec(in_lds ? skeys[FQ_KP(i)] : gkeys[i]);
+            const unsigned long long prev = (e > 0) ? prev_key : ((i > 0) ? key_dec(in_lds ? skeys[FQ_KP(i - 1)] : gkeys[i - 1]) : ~key);
             prev_key = key;
             keep[e] = (i == 0) || ((key >> 4) != (prev >> 4));
             if (keep[e]) {
