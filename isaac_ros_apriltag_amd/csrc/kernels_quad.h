@@ -1,7 +1,7 @@
 // kernels_quad.h -- S5 quad fitting (inside cuAprilTagsDetect, reference
-// src/apriltag_node.cpp:491-493).  One workgroup per cluster, five launch classes by cluster size
-// (one wave for <= 256 points ... 512 threads above 8192) so that small clusters do not pay for idle
-// waves and the slope sort always runs in LDS (2 KB ... 144 KB of keys).  Every class is one launch of
+// src/apriltag_node.cpp:491-493).  One workgroup per cluster, four launch classes by cluster size
+// (one wave for <= 256 points ... 1024 threads above 4096) so that small clusters do not pay for idle
+// waves and the slope sort always runs in LDS (2 KB ... 145 KB of keys).  Every class is one launch of
 // PERSISTENT workgroups: k_worklist has bucketed the clusters of all frames of the submission into one
 // compact work list per class, and a workgroup pops the next cluster with one atomic until its list is
 // empty -- no workgroup walks clusters of another class, and the cumulative-moment array of a cluster lives
@@ -472,15 +472,15 @@ template <int NT, bool SPLIT>
 #define FQ_WPE_64 4
 #define FQ_WPE_128 4
 #define FQ_WPE_256 4
-#define FQ_WPE_512 2
 #endif
 // persistent workgroups per CU of the two small classes (they fill FQ_WPE waves per SIMD when alone on a CU)
+#define FQ_NT_BIG 1024   // threads of the largest class: one workgroup fills a CU (16 waves, 4 per SIMD)
 #ifndef FQ_GRID_64
 #define FQ_GRID_64 16
 #define FQ_GRID_128 8
 #endif
 // second launch-bound argument = minimum waves per SIMD the register allocation must allow
-__global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 : NT == 256 ? FQ_WPE_256 : FQ_WPE_512)) void k_fit_quads(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
+__global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 : NT == 256 ? FQ_WPE_256 : 4)) void k_fit_quads(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
                                                    const uint32_t* __restrict__ pts_all, const ClusterRec* __restrict__ clusters_all,
                                                    const uint32_t* __restrict__ work, const uint32_t* __restrict__ work_n, uint32_t work_cap,
                                                    uint32_t* __restrict__ work_cursor, double* __restrict__ lf_scratch,
@@ -615,9 +615,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
 
     // ---- slope keys + sort -----------------------------------------------------------------------
     const float cx = (float)cxd, cy = (float)cyd;
-    // only the largest class (512 threads) can meet clusters beyond its LDS key array: every smaller instance
+    // only the largest class (FQ_NT_BIG threads) can meet clusters beyond its LDS key array: every smaller instance
     // addresses LDS unconditionally (no generic-address loads)
-    const bool in_lds = NT < 512 || sz <= sort_cap;
+    const bool in_lds = NT < FQ_NT_BIG || sz <= sort_cap;
     for (int i = tid; i < sz; i += NT) {
       const uint32_t p = pts[i];
       const int x = (int)(p >> 18), y = (int)((p >> 4) & 0x3FFF);
