@@ -180,18 +180,6 @@ __global__ void k_debug_math(int op, uint32_t n, const double* a, const double* 
   else out[i] = div_by(a[i], b[i], shared_recip(b[i]));   // the line fit's shared-reciprocal division
 }
 
-// Head start for the whole-CU workgroups of the largest quad-fit class: the other classes' streams run this one-wave
-// spin (wall clock, 100 MHz) before their kernels, so that the large class, launched at the same instant on the
-// submission stream (its first wave was measured up to 140 us after the others'), has its workgroups placed on empty
-// CUs first (persistent workgroups of the small classes would
-// otherwise take every CU's registers and LDS and leave it to the end of the stage, alone at a quarter of the
-// chip's occupancy).
-__global__ void k_head_start(const uint32_t* __restrict__ big_items, unsigned ticks) {
-  if (*big_items == 0) return;   // no large cluster in this submission: nothing to wait for
-  const unsigned long long t0 = wall_clock64();
-  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
-}
-
 // colour -> mono8 with the fixed-point BT.601 weights cv_bridge/OpenCV use for the reference's mono8
 // test input (test/isaac_ros_apriltag_mono8_test.py): Y = (4899 R + 9617 G + 1868 B + 8192) >> 14
 template <int NCH, int RIDX, int BIDX>
@@ -369,10 +357,12 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   // ---- size classes of the quad fit ------------------------------------------------------------------
   // one wave per small cluster, bigger workgroups and LDS key arrays above; persistent grids sized to the
   // chip (CUs x workgroups that fit one CU) but not beyond what a submission of B frames can feed.
-  // Everything above 4096 points goes to one class of 1024-thread workgroups, one per CU: its key array needs most
-  // of a CU's LDS anyway, and 16 waves at the 128-register budget of the other classes keep that CU as busy as four
-  // small workgroups would (with 512 threads and no room for a neighbour the large clusters ran at half occupancy,
-  // mostly at the end of the stage: 17.0 ms for 4 % of the stage's instructions).
+  // The two large classes need most of a CU's LDS for their key arrays, so they cannot share a CU with the other
+  // classes' persistent workgroups: they run first and alone, at the 128-register budget of the other classes --
+  // clusters above 8192 points in 1024-thread workgroups (16 waves, one workgroup per CU), then 4096..8192 points in
+  // 512-thread workgroups, two per CU.  (With 512 threads at twice the registers and no room for a neighbour the
+  // largest clusters used to run at a quarter of the chip's occupancy, mostly at the end of the stage: 17 ms of wall
+  // time for 4 % of the stage's instructions.)
   {
     const unsigned cus = (unsigned)D->num_cus;
     auto minu = [](unsigned a, unsigned b) { return a < b ? a : b; };
@@ -380,12 +370,10 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
     c[0] = {64, 256, 0, 256, minu((unsigned)FQ_GRID_64 * cus, 4096u * (unsigned)B), 256, 16};
     c[1] = {128, 1024, 256, 1024, minu((unsigned)FQ_GRID_128 * cus, 1024u * (unsigned)B), 1024, 8};
     c[2] = {256, 4096, 1024, 4096, minu(4u * cus, 256u * (unsigned)B), 4096, 2};
-    c[3] = {FQ_NT_BIG, 16384, 4096, 0x7FFFFFFF, minu(cus, 64u * (unsigned)B), P.max_cluster_points, 1};
-    // the largest cluster a frame can hold is max_cluster_points = 3(2W+2H): when that is at most 18432
-    // points (1080p: 18000) the last class keeps all of them in LDS (144 KB of keys + the table region
-    // still fit the 160 KB of a CU) instead of sorting the rare >16384-point cluster in global scratch
-    if (P.max_cluster_points > 16384 && P.max_cluster_points <= 18432) c[3].sort_cap = (P.max_cluster_points + 63) & ~63;
-    if (c[3].slot_cap < 4097) c[3].slot_cap = 4097;
+    c[3] = {512, 8192, 4096, 8192, minu(2u * cus, 64u * (unsigned)B), 8192, 1};
+    c[4] = {FQ_NT_BIG, 16384, 8192, 0x7FFFFFFF, minu(cus, 16u * (unsigned)B), P.max_cluster_points, 1};
+    if (P.max_cluster_points > 16384 && P.max_cluster_points <= 18432) c[4].sort_cap = (P.max_cluster_points + 63) & ~63;
+    if (c[4].slot_cap < 8193) c[4].slot_cap = 8193;
     uint32_t off = 0;
     for (int k = 0; k < FQ_NCLS; k++) {
       D->work_layout.lo[k] = c[k].lo < 23 ? 23 : c[k].lo;
@@ -422,8 +410,8 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
     FqClass& c = D->cls[k];
     if (P.max_cluster_points <= c.lo) continue;
     alloc((void**)&c.d_lf, (size_t)c.grid * c.slot_cap * 48);
-    // smoothed errors stay in registers up to FQ_SMOOTH_REGS points per thread; larger clusters need a second array
-    if (c.slot_cap > FQ_SMOOTH_REGS * c.nt || c.slot_cap > c.sort_cap) alloc((void**)&c.d_errs, (size_t)c.grid * c.slot_cap * 16);
+    // smoothed errors stay in registers up to FQ_SMOOTH_REGS_OF(threads) points per thread; larger clusters need a second array
+    if (c.slot_cap > FQ_SMOOTH_REGS_OF(c.nt) * c.nt || c.slot_cap > c.sort_cap) alloc((void**)&c.d_errs, (size_t)c.grid * c.slot_cap * 16);
   }
   if (D->cls[FQ_NCLS - 1].slot_cap > D->cls[FQ_NCLS - 1].sort_cap) {   // clusters beyond the LDS key array exist
     const FqClass& c = D->cls[FQ_NCLS - 1];
@@ -452,7 +440,8 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   for (auto& e : D->ev_join) if (ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
   // dynamic LDS beyond 64 KB has to be allowed per kernel (once per device; not allowed while a stream is being captured)
   if (ok) {
-      const void* fns[8] = {reinterpret_cast<const void*>(k_fit_quads<FQ_NT_BIG, false>), reinterpret_cast<const void*>(k_fit_quads<256, false>),
+      const void* fns[10] = {reinterpret_cast<const void*>(k_fit_quads<512, false>), reinterpret_cast<const void*>(k_fit_quads<512, true>),
+                            reinterpret_cast<const void*>(k_fit_quads<FQ_NT_BIG, false>), reinterpret_cast<const void*>(k_fit_quads<256, false>),
                             reinterpret_cast<const void*>(k_fit_quads<128, false>), reinterpret_cast<const void*>(k_fit_quads<64, false>),
                             reinterpret_cast<const void*>(k_fit_quads<FQ_NT_BIG, true>), reinterpret_cast<const void*>(k_fit_quads<256, true>),
                             reinterpret_cast<const void*>(k_fit_quads<128, true>), reinterpret_cast<const void*>(k_fit_quads<64, true>)};
@@ -603,34 +592,20 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
     // keys | pair-table region
     auto lds_bytes = [](const FqClass& c) { return (size_t)FQ_KP(c.sort_cap) * 8 + (size_t)FQ_TABLE_DOUBLES * 8; };   // skewed key array
 
-    // The classes are independent (they only append to the quad list), so they run concurrently, one stream each
-    // (the runtime multiplexes streams onto four hardware queues; two streams on one queue serialise).  Every
-    // class's persistent grid can fill the chip's register file by itself, so whichever workgroups are placed first
-    // stay until their list is empty and the stage is work-conserving whatever the order (17.97 - 18.34 ms over five
-    // stream assignments) -- except for the large class, whose whole-CU workgroups only find room on an empty CU:
-    // it gets a head start (k_head_start) and runs first, at full occupancy.
-    HIP_TRY(hipEventRecord(D->ev_fork, s));
-    static const int order[FQ_NCLS] = {3, 2, 0, 1};
-    static const int smap[FQ_NCLS] = {0, 2, 1, -1};   // class -> auxiliary stream (-1: the submission stream)
-    bool used[3] = {false, false, false};
-    // (a small submission is about latency: no head start there)
-    const bool big_first = n >= 32u && P.max_cluster_points > D->cls[FQ_NCLS - 1].lo && D->cls[FQ_NCLS - 1].d_lf;
-    // a submission of n < max_batch frames needs no more workgroups than its share of the persistent grid
-    for (int oi = 0; oi < FQ_NCLS; oi++) {
-      const int c = order[oi];
+    // The classes are independent (they only append to the quad list).  Every class's persistent grid can fill the
+    // chip's register file by itself, so whichever workgroups are placed first stay until their list is empty, and the
+    // stage is work-conserving whatever the order of the three small classes (17.97 - 18.34 ms over five stream
+    // assignments).  The two large classes are different: their workgroups only find room on (half-)empty CUs.  Next
+    // to the small classes they were placed last and ran at the end of the stage at a quarter of the chip's
+    // occupancy, so a throughput-sized submission runs them first, one after the other on the submission stream, and
+    // the small classes start when both are done: 16.9 -> 15.8 ms.  (Queuing the largest class on a stream of its own
+    // next to the second one cost 0.9 ms: its queue sat stalled until the scheduler looked at it again.)
+    // A small submission is about latency: all classes start together.
+    auto launch_class = [&](int c, hipStream_t sc) {
       const FqClass& cl = D->cls[c];
-      if (P.max_cluster_points <= cl.lo || !cl.d_lf) continue;
-      const dim3 grid(cl.grid);
+      if (P.max_cluster_points <= cl.lo || !cl.d_lf) return;
+      const dim3 grid(cl.grid);   // (a submission of n < max_batch frames still gets the handle's persistent grid)
       const size_t lds = lds_bytes(cl);
-      hipStream_t sc = s;
-      if (smap[c] >= 0) {
-        sc = D->aux_stream[smap[c]];
-        if (!used[smap[c]]) {
-          HIP_TRY(hipStreamWaitEvent(sc, D->ev_fork, 0));
-          if (big_first) hipLaunchKernelGGL(k_head_start, dim3(1), dim3(64), 0, sc, D->d_workctl + (FQ_NCLS - 1), 20000u);   // 200 us
-        }
-        used[smap[c]] = true;
-      }
       const bool big = c == FQ_NCLS - 1;
       // a small submission spreads its clusters over the workgroups one by one (latency); large ones pop in chunks
       const int pop = cl.pop < (int)(n / 16u) ? cl.pop : ((int)(n / 16u) < 1 ? 1 : (int)(n / 16u));
@@ -643,13 +618,33 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
       if (cl.nt == 64) { FQ_LAUNCH(64) }
       else if (cl.nt == 128) { FQ_LAUNCH(128) }
       else if (cl.nt == 256) { FQ_LAUNCH(256) }
+      else if (cl.nt == 512) { FQ_LAUNCH(512) }
       else { FQ_LAUNCH(FQ_NT_BIG) }
 #undef FQ_LAUNCH
 #undef FQ_ARGS
+    };
+    hipStream_t* aux = D->aux_stream;
+    const bool large_first = n >= 32u;
+    HIP_TRY(hipEventRecord(D->ev_fork, s));
+    if (large_first) {
+      launch_class(3, s);
+      launch_class(4, s);
+      HIP_TRY(hipEventRecord(D->ev_fork, s));   // both large classes are done
+    }
+    for (int a = 0; a < 3; a++) HIP_TRY(hipStreamWaitEvent(aux[a], D->ev_fork, 0));
+    // (which small class shares the chip with which was measured over seven assignments: 16.0 - 16.9 ms; best when
+    // the 256-thread class is the one that ends up running last)
+    if (large_first) {
+      for (int c = 0; c < 3; c++) launch_class(c, aux[c]);
+    } else {   // the longest chains side by side: the largest clusters | 4096..8192 then the one-wave class | the other two
+      launch_class(4, s);
+      launch_class(3, aux[0]);
+      launch_class(2, aux[1]);
+      launch_class(1, aux[2]);
+      launch_class(0, aux[0]);
     }
     for (int a = 0; a < 3; a++) {
-      if (!used[a]) continue;
-      HIP_TRY(hipEventRecord(D->ev_join[a], D->aux_stream[a]));
+      HIP_TRY(hipEventRecord(D->ev_join[a], aux[a]));
       HIP_TRY(hipStreamWaitEvent(s, D->ev_join[a], 0));
     }
   }

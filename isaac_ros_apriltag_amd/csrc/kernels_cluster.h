@@ -340,7 +340,7 @@ __global__ __launch_bounds__(1024) void k_cluster_select(const unsigned long lon
 // Work lists of the quad fit: the kept clusters of all frames of the submission, bucketed by size class
 // (class c holds lo[c] < count <= hi[c]).  An item is (frame << 16) | cluster index.  Appends are aggregated per
 // block in LDS, so every class counter sees one global atomic per block.
-#define FQ_NCLS 4
+#define FQ_NCLS 5
 struct FqWorkLayout {
   int lo[FQ_NCLS], hi[FQ_NCLS];
   uint32_t off[FQ_NCLS], cap[FQ_NCLS];   // item range of class c inside the work array

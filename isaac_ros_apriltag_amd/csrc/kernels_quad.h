@@ -1,6 +1,6 @@
 // kernels_quad.h -- S5 quad fitting (inside cuAprilTagsDetect, reference
-// src/apriltag_node.cpp:491-493).  One workgroup per cluster, four launch classes by cluster size
-// (one wave for <= 256 points ... 1024 threads above 4096) so that small clusters do not pay for idle
+// src/apriltag_node.cpp:491-493).  One workgroup per cluster, five launch classes by cluster size
+// (one wave for <= 256 points ... 1024 threads above 8192) so that small clusters do not pay for idle
 // waves and the slope sort always runs in LDS (2 KB ... 145 KB of keys).  Every class is one launch of
 // PERSISTENT workgroups: k_worklist has bucketed the clusters of all frames of the submission into one
 // compact work list per class, and a workgroup pops the next cluster with one atomic until its list is
@@ -465,7 +465,7 @@ template <int NT, bool SPLIT>
 #define FQ_EPT(NT) ((NT) >= 256 ? 2 : 1)   // elements per lane in the moment sweep
 #endif
 #define FQ_SEL_REGS 8          // maxima candidates per lane held in registers during the top-10 selection
-#define FQ_SMOOTH_REGS 16      // smoothed errors per thread kept in registers (clusters up to 16 x threads)
+#define FQ_SMOOTH_REGS_OF(NT) ((NT) >= 1024 ? 8 : 16)   // smoothed errors per thread kept in registers (clusters up to that many x threads)
 #define FQ_TABLE_DOUBLES 290   // six 45-entry pair tables, 4 lines x 4 parameters, 4 line mse
 #define FQ_PIDX(a, b) ((((a) * (19 - (a))) >> 1) + (b) - (a) - 1)   // a < b < 10 -> 0..44
 #ifndef FQ_WPE_64
@@ -933,6 +933,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     auto wrap = [szd](int k) { return k < 0 ? k + szd : (k >= szd ? k - szd : k); };
     double* cand_val = in_lds ? reinterpret_cast<double*>(skeys) : ea;
     int* cand_idx = in_lds ? reinterpret_cast<int*>(skeys + (sort_cap >> 1)) : reinterpret_cast<int*>(ea + (szd >> 1) + 1);
+    constexpr int FQ_SMOOTH_REGS = FQ_SMOOTH_REGS_OF(NT);
     if (in_lds && szd <= FQ_SMOOTH_REGS * NT) {
       // Up to FQ_SMOOTH_REGS points per thread: the smoothed errors are formed in registers, written back
       // over the raw ones, compared with their neighbours, and only then does the same LDS array take the
