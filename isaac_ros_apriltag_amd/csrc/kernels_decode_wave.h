@@ -13,7 +13,11 @@
 
 #define DW_MAXS 64  // samples per chunk
 
-__global__ __launch_bounds__(64) void k_decode_wave(const FrameDesc* __restrict__ frames, const QuadRec* __restrict__ quads_all,
+// 6 waves per SIMD (80 registers, a few spilled): the per-quad work is chains of dependent double-precision operations in
+// the CPU definition's order, so the stage's rate is set by how many quads are in flight (1.16 -> 0.80 ms per 256 noisy
+// frames together with the larger grid; 5 and 7 waves measured slower)
+#define DW_WPE 6
+__global__ __launch_bounds__(64, DW_WPE) void k_decode_wave(const FrameDesc* __restrict__ frames, const QuadRec* __restrict__ quads_all,
                                                     DetRec* __restrict__ dets_all, FrameCounters* __restrict__ counters,
                                                     DetParams P) {
   __shared__ double s_bx[DW_MAXS], s_by[DW_MAXS];
