@@ -573,7 +573,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
   hipLaunchKernelGGL(k_points, dim3((P.W + PT_TW - 1) / PT_TW, (P.H + PT_TH - 1) / PT_TH, n), dim3(256), 0, s, D->d_thr,
                      D->d_label, D->d_csize, D->d_hkeys, D->d_hcnt, D->d_stage, D->d_rank, D->d_counters, P);
   mark();
-  hipLaunchKernelGGL(k_cluster_select, dim3((P.hcap + 1023) / 1024, 1, n), dim3(1024), 0, s, D->d_hkeys, D->d_hcnt, D->d_hoff,
+  hipLaunchKernelGGL(k_cluster_select, dim3((P.hcap + 1023) / 1024, 1, n), dim3(256), 0, s, D->d_hkeys, D->d_hcnt, D->d_hoff,
                      D->d_clusters, D->d_counters, P);
   {
     unsigned gw = (P.ccap + 255) / 256;

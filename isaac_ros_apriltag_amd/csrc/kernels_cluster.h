@@ -291,50 +291,62 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
 
 // one thread per hash slot; 1024-thread blocks so that the two allocation counters see one atomic each
 // per block
-__global__ __launch_bounds__(1024) void k_cluster_select(const unsigned long long* __restrict__ hkeys_all,
-                                                         const uint32_t* __restrict__ hcnt_all, uint32_t* __restrict__ hoff_all,
-                                                         ClusterRec* __restrict__ clusters_all,
-                                                         FrameCounters* __restrict__ counters, DetParams P) {
-  __shared__ uint32_t wsum[16], wcnt[16];
+__global__ __launch_bounds__(256) void k_cluster_select(const unsigned long long* __restrict__ hkeys_all,
+                                                        const uint32_t* __restrict__ hcnt_all, uint32_t* __restrict__ hoff_all,
+                                                        ClusterRec* __restrict__ clusters_all,
+                                                        FrameCounters* __restrict__ counters, DetParams P) {
+  // 1024 table slots per block, four consecutive ones per thread (16-byte loads and stores; hcap is a power of two >= 256)
+  __shared__ uint32_t wsum[4], wcnt[4];
   __shared__ uint32_t s_pbase, s_cbase;
   const int frame = (int)blockIdx.z + P.frame0;
-  const uint32_t slot = blockIdx.x * 1024 + threadIdx.x;
-  const bool in_range = slot < P.hcap;
-  const size_t hi = (size_t)frame * P.hcap + (in_range ? slot : 0);
+  const uint32_t slot0 = blockIdx.x * 1024 + threadIdx.x * 4;
+  const bool in_range = slot0 < P.hcap;
+  const size_t hi = (size_t)frame * P.hcap + (in_range ? slot0 : 0);
   // a slot holds a key exactly when its count is non-zero (every insert is followed by an add of at least one point),
   // so the 8-byte keys of the ~95 % empty slots are never read
-  const uint32_t c = in_range ? hcnt_all[hi] : 0;
-  const unsigned long long key = c ? hkeys_all[hi] : AT_EMPTY_KEY;
+  uint4 c4 = make_uint4(0, 0, 0, 0);
+  if (in_range) c4 = *reinterpret_cast<const uint4*>(hcnt_all + hi);
+  const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
   // a frame whose point staging overflowed has pair counts that exceed what was staged: it yields no
   // clusters at all (the overflow bit is reported), never an out-of-range range
   const bool frame_ok = (counters[frame].flags & 0x1u) == 0;
-  const bool keep = frame_ok && key != AT_EMPTY_KEY && (int)c >= P.min_cluster_points && (int)c <= P.max_cluster_points;
-  const unsigned long long mask = __ballot(keep);
-  const uint32_t inc = wave_incl_scan(keep ? c : 0u);
+  unsigned long long key[4];
+  bool keep[4];
+  uint32_t tsum = 0, tcnt = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    key[j] = c[j] ? hkeys_all[hi + j] : AT_EMPTY_KEY;
+    keep[j] = frame_ok && key[j] != AT_EMPTY_KEY && (int)c[j] >= P.min_cluster_points && (int)c[j] <= P.max_cluster_points;
+    if (keep[j]) { tsum += c[j]; tcnt++; }
+  }
+  const uint32_t inc = wave_incl_scan(tsum), cinc = wave_incl_scan(tcnt);
   const int lane = lane_id(), wv = threadIdx.x >> 6;
-  if (lane == 63) { wsum[wv] = inc; wcnt[wv] = (uint32_t)__popcll(mask); }
+  if (lane == 63) { wsum[wv] = inc; wcnt[wv] = cinc; }
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t ps = 0, cs = 0;
-    for (int w = 0; w < 16; w++) { const uint32_t a = wsum[w], b = wcnt[w]; wsum[w] = ps; wcnt[w] = cs; ps += a; cs += b; }
+    for (int w = 0; w < 4; w++) { const uint32_t a = wsum[w], b = wcnt[w]; wsum[w] = ps; wcnt[w] = cs; ps += a; cs += b; }
     s_pbase = ps ? atomicAdd(&counters[frame].npoints_kept, ps) : 0;
     s_cbase = cs ? atomicAdd(&counters[frame].nclusters, cs) : 0;
   }
   __syncthreads();
-  uint32_t off = AT_INVALID_SLOT;
-  if (keep) {
-    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    const uint32_t ci = s_cbase + wcnt[wv] + rank;
+  uint32_t off[4] = {AT_INVALID_SLOT, AT_INVALID_SLOT, AT_INVALID_SLOT, AT_INVALID_SLOT};
+  uint32_t po = s_pbase + wsum[wv] + inc - tsum, ci = s_cbase + wcnt[wv] + cinc - tcnt;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (!keep[j]) continue;
     if (ci < P.ccap) {
-      off = s_pbase + wsum[wv] + inc - c;
+      off[j] = po;
       ClusterRec rec;
-      rec.key = key; rec.start = off; rec.count = c;
+      rec.key = key[j]; rec.start = po; rec.count = c[j];
       clusters_all[(size_t)frame * P.ccap + ci] = rec;
     } else {
       atomicOr(&counters[frame].flags, 0x4u);
     }
+    po += c[j];
+    ci++;
   }
-  if (in_range) hoff_all[hi] = off;
+  if (in_range) *reinterpret_cast<uint4*>(hoff_all + hi) = make_uint4(off[0], off[1], off[2], off[3]);
 }
 
 // Work lists of the quad fit: the kept clusters of all frames of the submission, bucketed by size class
