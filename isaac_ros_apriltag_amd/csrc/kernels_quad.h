@@ -598,7 +598,10 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       __syncthreads();
       xmin = s_box[0][0]; xmax = s_box[0][1]; ymin = s_box[0][2]; ymax = s_box[0][3];
       sxg = s_dot[0][0]; sgx = s_dot[0][1]; sgy = s_dot[0][2];
-#pragma unroll
+      // (not unrolled for the 16-wave instance: the unrolled loads cost it 34 spilled registers, and a kernel that uses
+      // scratch started 0.13 ms late)
+      constexpr int kUnrollWaves = NW > 8 ? 1 : NW;
+#pragma unroll kUnrollWaves
       for (int w = 1; w < NW; w++) {
         xmin = min(xmin, s_box[w][0]); xmax = max(xmax, s_box[w][1]); ymin = min(ymin, s_box[w][2]); ymax = max(ymax, s_box[w][3]);
         sxg += s_dot[w][0]; sgx += s_dot[w][1]; sgy += s_dot[w][2];
