@@ -22,9 +22,11 @@
 
 #define CC_T 64  // tile edge
 
-__device__ __forceinline__ uint32_t lds_find(volatile uint32_t* L, uint32_t i) {
+// (relaxed workgroup-scope atomic loads, not volatile ones: a volatile access keeps the generic address space and
+// compiles to flat_load ... sc0 sc1 through the shared aperture instead of ds_read_b32)
+__device__ __forceinline__ uint32_t lds_find(const uint32_t* L, uint32_t i) {
   uint32_t p;
-  while ((p = L[i]) != i) i = p;
+  while ((p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != i) i = p;
   return i;
 }
 __device__ __forceinline__ void lds_union(uint32_t* L, uint32_t a, uint32_t b) {

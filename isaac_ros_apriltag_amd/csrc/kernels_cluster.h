@@ -44,7 +44,7 @@ __device__ __forceinline__ uint32_t hash_insert(unsigned long long* hkeys, uint3
 __device__ __forceinline__ int ltab_insert(unsigned long long* tkey, uint64_t key) {
   uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 56) & (PT_TB - 1);
   for (int probe = 0; probe < PT_TB; probe++) {
-    const unsigned long long cur = *reinterpret_cast<volatile unsigned long long*>(&tkey[h]);
+    const unsigned long long cur = __hip_atomic_load(&tkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_read_b64 (volatile: a flat load)
     if (cur == key) return (int)h;
     if (cur == AT_EMPTY_KEY) {
       const unsigned long long old = atomicCAS(&tkey[h], AT_EMPTY_KEY, (unsigned long long)key);

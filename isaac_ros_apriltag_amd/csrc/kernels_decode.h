@@ -48,7 +48,8 @@ __device__ __forceinline__ double graymodel_interp_dev(const GrayModel& g, doubl
   return g.C0 * x + g.C1 * y + g.C2;
 }
 
-__device__ __forceinline__ double value_for_pixel_dev(const uint8_t* im, int w, int h, int pitch, double px, double py) {
+template <typename ImgPtr>
+__device__ __forceinline__ double value_for_pixel_dev(ImgPtr im, int w, int h, int pitch, double px, double py) {
   const int x1 = (int)floor(px - 0.5), x2 = (int)ceil(px - 0.5);
   const double x = px - 0.5 - x1;
   const int y1 = (int)floor(py - 0.5), y2 = (int)ceil(py - 0.5);

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(64, DW_WPE) void k_decode_wave(const FrameDesc* __r
   uint32_t nq = counters[frame].nquads;
   if (nq > P.qcap) nq = P.qcap;
   const FrameDesc fd = frames[frame];
-  const uint8_t* im = fd.img;
+  // the caller's image pointer is global by contract; out of the descriptor the compiler would have to assume generic
+  const __attribute__((address_space(1))) uint8_t* im = (const __attribute__((address_space(1))) uint8_t*)fd.img;
   const int w = P.W0, h = P.H0, pitch = (int)fd.pitch;
 
   for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {

@@ -13,9 +13,14 @@
 
 #define TH_LDS_STRIDE 260  // bytes per LDS tile row (65 dwords): 256 tiles + one halo tile each side
 
+// The caller's image pointer comes out of the frame descriptor, so the compiler cannot know its address space and
+// would emit flat loads; the pointer is global by contract (include/apriltag_amd.h: device memory).
+typedef const __attribute__((address_space(1))) uint8_t* th_gimg_t;
+typedef uint32_t th_u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 is a class: no copy out of an address space)
+typedef const __attribute__((address_space(1))) th_u32x4* th_gimg4_t;
 // one working-image pixel through the decimating gather (slow path: halos, edges, unaligned input)
 template <int DEC>
-__device__ __forceinline__ uint32_t th_px(const uint8_t* img, uint32_t pitch, int W0, int H0, int x, int y) {
+__device__ __forceinline__ uint32_t th_px(th_gimg_t img, uint32_t pitch, int W0, int H0, int x, int y) {
   int sx = x * DEC, sy = y * DEC;
   if (sx >= W0 || sy >= H0) return 0;
   return img[(size_t)sy * pitch + sx];
@@ -23,21 +28,21 @@ __device__ __forceinline__ uint32_t th_px(const uint8_t* img, uint32_t pitch, in
 
 // loads 16 consecutive working pixels of row y starting at x0 (multiple of 16) into 4 dwords
 template <int DEC>
-__device__ __forceinline__ void th_load16(const uint8_t* img, uint32_t pitch, int W0, int H0, bool aligned,
+__device__ __forceinline__ void th_load16(th_gimg_t img, uint32_t pitch, int W0, int H0, bool aligned,
                                           int x0, int y, uint32_t out[4]) {
   int sy = y * DEC;
   if (sy >= H0 || x0 * DEC >= W0) { out[0] = out[1] = out[2] = out[3] = 0; return; }
-  const uint8_t* row = img + (size_t)sy * pitch;
+  th_gimg_t row = img + (size_t)sy * pitch;
   if (DEC == 1) {
     if (aligned && x0 + 16 <= W0) {
-      uint4 v = *reinterpret_cast<const uint4*>(row + x0);
+      const th_u32x4 v = *(th_gimg4_t)(row + x0);
       out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
       return;
     }
   } else if (DEC == 2) {
     if (aligned && 2 * x0 + 32 <= W0) {
-      uint4 a = *reinterpret_cast<const uint4*>(row + 2 * x0);
-      uint4 b = *reinterpret_cast<const uint4*>(row + 2 * x0 + 16);
+      const th_u32x4 a = *(th_gimg4_t)(row + 2 * x0);
+      const th_u32x4 b = *(th_gimg4_t)(row + 2 * x0 + 16);
       // keep the even bytes of each dword pair
       out[0] = (a.x & 0xFF) | ((a.x >> 8) & 0xFF00) | ((a.y & 0xFF) << 16) | ((a.y << 8) & 0xFF000000u);
       out[1] = (a.z & 0xFF) | ((a.z >> 8) & 0xFF00) | ((a.w & 0xFF) << 16) | ((a.w << 8) & 0xFF000000u);
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__
   for (int v = 0; v < 2; v++) {
     const int uy = (TY0 + 2 * ty4 + v) * 4;
 #pragma unroll
-    for (int r = 0; r < 4; r++) th_load16<DEC>(fd.img, fd.pitch, P.W0, P.H0, aligned, ux, uy + r, u[v][r]);
+    for (int r = 0; r < 4; r++) th_load16<DEC>((th_gimg_t)fd.img, fd.pitch, P.W0, P.H0, aligned, ux, uy + r, u[v][r]);
   }
 #pragma unroll
   for (int v = 0; v < 2; v++) {
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__
     const bool rowok = tY >= 0 && tY < P.th;
     if (rowok) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) th_load16<DEC>(fd.img, fd.pitch, P.W0, P.H0, aligned, (TX0 + 4 * c) * 4, tY * 4 + r, h[r]);
+      for (int r = 0; r < 4; r++) th_load16<DEC>((th_gimg_t)fd.img, fd.pitch, P.W0, P.H0, aligned, (TX0 + 4 * c) * 4, tY * 4 + r, h[r]);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__
     if (tX >= 0 && tX < P.tw && tY >= 0 && tY < P.th) {
       for (int r = 0; r < 4; r++)
         for (int c = 0; c < 4; c++) {
-          uint32_t v = th_px<DEC>(fd.img, fd.pitch, P.W0, P.H0, tX * 4 + c, tY * 4 + r);
+          uint32_t v = th_px<DEC>((th_gimg_t)fd.img, fd.pitch, P.W0, P.H0, tX * 4 + c, tY * 4 + r);
           mn = min(mn, v);
           mx = max(mx, v);
         }
@@ -261,12 +266,12 @@ __global__ __launch_bounds__(256) void k_threshold_leftover(const FrameDesc* __r
     for (int tx = max(tX - 1, 0); tx <= min(tX + 1, P.tw - 1); tx++)
       for (int r = 0; r < 4; r++)
         for (int c = 0; c < 4; c++) {
-          uint32_t v = th_px<DEC>(fd.img, fd.pitch, P.W0, P.H0, tx * 4 + c, ty * 4 + r);
+          uint32_t v = th_px<DEC>((th_gimg_t)fd.img, fd.pitch, P.W0, P.H0, tx * 4 + c, ty * 4 + r);
           mn = min(mn, v);
           mx = max(mx, v);
         }
   uint32_t thresh = mn + (mx - mn) / 2;
-  uint32_t v = th_px<DEC>(fd.img, fd.pitch, P.W0, P.H0, x, y);
+  uint32_t v = th_px<DEC>((th_gimg_t)fd.img, fd.pitch, P.W0, P.H0, x, y);
   thr_all[(size_t)frame * P.H * P.WS + (size_t)y * P.WS + x] = v > thresh ? 255 : 0;
   if (DEC > 1) gray_all[(size_t)frame * P.H * P.WS + (size_t)y * P.WS + x] = (uint8_t)v;
 }

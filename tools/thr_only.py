@@ -2,7 +2,9 @@
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-from isaac_ros_apriltag_amd import synth
+from isaac_ros_apriltag_amd import synth, capi
+if os.environ.get("AMDAT_LIB"):   # measurement variant (isaac_ros_apriltag_amd.build.build_amd_variant)
+    capi.LIB_PATH = os.path.join(ROOT, "isaac_ros_apriltag_amd", "libapriltag_amd_%s.so" % os.environ["AMDAT_LIB"])
 from isaac_ros_apriltag_amd.detector import AprilTagDetector
 dec = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 frames = np.stack([synth.scene_c2(seed=1234 + i)[0] for i in range(8)])
