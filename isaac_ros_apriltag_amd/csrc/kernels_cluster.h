@@ -41,8 +41,14 @@ __device__ __forceinline__ uint32_t hash_insert(unsigned long long* hkeys, uint3
 #define PT_ELIST 2048   // emissions of one tile kept in the LDS list of pass 2 (the tile has 1024 pixels)
 
 // per-block table in LDS: returns entry index or -1 when full
+// (slot = top byte of a 32-bit multiplicative hash of the two labels: two quarter-rate multiplies instead of the four
+// of the frame table's 64-bit golden-ratio multiply, paid here once per emitted point)
+__device__ __forceinline__ uint32_t ltab_hash(uint64_t key) {
+  const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+  return (lo * 0x9E3779B1u + hi * 0x85EBCA77u) >> 24;
+}
 __device__ __forceinline__ int ltab_insert(unsigned long long* tkey, uint64_t key) {
-  uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 56) & (PT_TB - 1);
+  uint32_t h = ltab_hash(key);
   for (int probe = 0; probe < PT_TB; probe++) {
     const unsigned long long cur = __hip_atomic_load(&tkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_read_b64 (volatile: a flat load)
     if (cur == key) return (int)h;
@@ -55,7 +61,7 @@ __device__ __forceinline__ int ltab_insert(unsigned long long* tkey, uint64_t ke
   return -1;
 }
 __device__ __forceinline__ int ltab_find(const unsigned long long* tkey, uint64_t key) {
-  uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 56) & (PT_TB - 1);
+  uint32_t h = ltab_hash(key);
   for (int probe = 0; probe < PT_TB; probe++) {
     const unsigned long long cur = tkey[h];
     if (cur == key) return (int)h;
