@@ -2,10 +2,13 @@
 // (inside cuAprilTagsDetect, reference src/apriltag_node.cpp:491-493).
 //
 //   k_points          every pixel of a 64x16 tile looks at its 4 forward neighbours (LDS halo tile of
-//                     {value, label-if-component>=25}); points are counted per component pair in a
-//                     per-block LDS table, then once per (block, pair) in the per-frame open-addressing
-//                     hash table (64-bit CAS on the key, 32-bit add on the count, whose return value is
-//                     the block's base rank in the cluster); points are compacted with a block scan.
+//                     {value, label-if-component>=25}) and only notes which of them emit (a 16-bit mask per
+//                     thread); the emitters are compacted into a block-wide LDS list, and everything that costs
+//                     -- the per-block component-pair table in LDS (insert, count, rank from the counting
+//                     atomic's return value), then one insert + one add per (block, pair) in the per-frame
+//                     open-addressing hash table (64-bit CAS on the key, 32-bit add on the count, whose return
+//                     value is the block's base rank in the cluster), then the staging stores -- runs DENSE over
+//                     that list, every lane on a real emission.
 //   k_cluster_select  keeps pairs with min_cluster_points <= count <= 3*(2W+2H), allocates their point
 //                     ranges with one atomic per 1024-slot block (ballot/scan), emits the cluster list.
 //   k_scatter         moves the staged points to range start + rank -- no atomics (order inside a
@@ -135,58 +138,81 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   const int lx = tid & 63;
   const int gx = X0 + lx;
   const int DX[4] = {1, 0, -1, 1}, DY[4] = {0, 1, 1, 1};
-  // pass 1: count per pair in the block table; every emitting (pixel, direction) of this thread is
-  // remembered as a bit of emask plus the byte index of its table entry (0xFF: the table was full), so
-  // that pass 2 does not walk the neighbourhood again
-  // (Aggregating the table inserts and counter atomics of pass 1 over the wave -- one leader per distinct key -- was
-  // measured slower, 9.6 vs 6.1 ms: a 64-pixel row step meets too many distinct component pairs.  Taking the rank
-  // of an emission from the value the counting atomic returns (so that pass 2 needs no atomics and no block scan) was
-  // slower too, 7.8 ms: the returning LDS atomics on the few hot pair counters stall the wave, the list costs occupancy.)
+  // pass 1: which (pixel, direction) of this thread emits -- a 16-bit mask and a count, nothing else.  The component-pair
+  // table is NOT touched here: about one test in five emits, so table work inside this loop runs on a fifth of the
+  // lanes and as long as the busiest lane; it is done on the compacted list instead (pass 2), where every lane has an
+  // emission.
+  // (History of this pass: aggregating the table inserts and counter atomics over the wave -- one leader per distinct
+  // key -- was measured slower, 9.6 vs 6.1 ms: a 64-pixel row step meets too many distinct component pairs.  Taking
+  // the rank from the counting atomic's return value INSIDE this sparse loop was slower too, 7.8 ms.)
   uint32_t cnt = 0;
   uint32_t emask = 0;
-  uint32_t eidx[4] = {0, 0, 0, 0};
-  {
-    uint64_t last_key = AT_EMPTY_KEY;
-    int last_e = -1;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int ly = (tid >> 6) + 4 * k;
-      const int gy = Y0 + ly;
-      if (gx < 1 || gx > W - 2 || gy < 1 || gy > H - 2) continue;
-      const int c = ly * PT_LW + lx + 1;
-      const uint32_t r0 = slab[c];
-      if (r0 == AT_NO_LABEL) continue;
-      const int v0 = sv[c];
-      // upstream's connected_last: the left neighbour (a valid source itself) emitted its (1,1) point,
-      // which is this pixel's (-1,1) half-pixel location
-      const bool left_emits = gx - 1 >= 1 && slab[c - 1] != AT_NO_LABEL && slab[c + PT_LW] != AT_NO_LABEL &&
-                              (int)sv[c - 1] + (int)sv[c + PT_LW] == 255;
+  for (int k = 0; k < 4; k++) {
+    const int ly = (tid >> 6) + 4 * k;
+    const int gy = Y0 + ly;
+    if (gx < 1 || gx > W - 2 || gy < 1 || gy > H - 2) continue;
+    const int c = ly * PT_LW + lx + 1;
+    if (slab[c] == AT_NO_LABEL) continue;
+    const int v0 = sv[c];
+    // upstream's connected_last: the left neighbour (a valid source itself) emitted its (1,1) point,
+    // which is this pixel's (-1,1) half-pixel location
+    const bool left_emits = gx - 1 >= 1 && slab[c - 1] != AT_NO_LABEL && slab[c + PT_LW] != AT_NO_LABEL &&
+                            (int)sv[c - 1] + (int)sv[c + PT_LW] == 255;
 #pragma unroll
-      for (int d = 0; d < 4; d++) {
-        if (d == 2 && left_emits) continue;
-        const int n = c + DY[d] * PT_LW + DX[d];
-        const uint32_t r1 = slab[n];
-        if (r1 == AT_NO_LABEL || v0 + (int)sv[n] != 255) continue;
-        const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
-        if (key != last_key) { last_key = key; last_e = ltab_insert(tkey, key); }
-        if (last_e >= 0 && last_e < 255) atomicAdd(&tcnt[last_e], 1u);
-        emask |= 1u << (k * 4 + d);
-        eidx[k] |= (uint32_t)((last_e >= 0 && last_e < 255) ? last_e : 255) << (8 * d);
-        cnt++;
-      }
+    for (int d = 0; d < 4; d++) {
+      if (d == 2 && left_emits) continue;
+      const int n = c + DY[d] * PT_LW + DX[d];
+      if (slab[n] == AT_NO_LABEL || v0 + (int)sv[n] != 255) continue;
+      emask |= 1u << (k * 4 + d);
+      cnt++;
     }
   }
   uint32_t total;
   const uint32_t off = block_excl_scan256(cnt, sscan, &total);  // contains __syncthreads
   if (total == 0) return;
 #if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 2   // (pass 1's results are written out so that they stay live)
-  if (P.max_nmaxima == 10) { rank_all[(size_t)frame * P.pcap + blockIdx.x * 256 + tid] = emask ^ eidx[0] ^ eidx[1] ^ eidx[2] ^ eidx[3] ^ off; return; }
+  if (P.max_nmaxima == 10) { rank_all[(size_t)frame * P.pcap + blockIdx.x * 256 + tid] = emask ^ off; return; }
 #endif
   unsigned long long* hkeys = hkeys_all + (size_t)frame * P.hcap;
   uint32_t* hcnt = hcnt_all + (size_t)frame * P.hcap;
   if (tid == 0) sbase = atomicAdd(&counters[frame].npoints_raw, total);
+  // the emitters go to a block-wide list in LDS at the thread's scan offset: record = pixel (10 bits) | direction (2);
+  // emissions beyond the list capacity (more than two per pixel of the tile on average) are kept by their thread
   {
-    // one global insert + one global add per distinct pair of this block
+    uint32_t q = off, m = emask;
+    while (m && q < PT_ELIST) {
+      const int sidx = __ffs((int)m) - 1;
+      m &= m - 1;
+      elist[q++] = (uint32_t)(((tid >> 6) + 4 * (sidx >> 2)) * 64 + lx) | ((uint32_t)(sidx & 3) << 10);
+    }
+  }
+  __syncthreads();
+  // pass 2, DENSE over the list (entry q belongs to thread q mod 256): pair key -> block table entry e (one insert), and
+  // the emission's rank inside its (block, pair) group from the value the counting atomic returns -- on a full wave of
+  // real emissions the returning LDS atomic costs what a leader loop over the wave's distinct entries does, and the
+  // insert is paid once per emission instead of once per (pixel, direction) slot.  Record |= e << 12 | rank << 20
+  // (e = 255: the table was full, the pair goes straight to the frame table in pass 3).
+  const uint32_t nlist = total < PT_ELIST ? total : PT_ELIST;
+  for (uint32_t q = tid; q < nlist; q += 256) {
+    const uint32_t rec = elist[q];
+    const int ly = (int)(rec & 1023u) >> 6, plx = (int)(rec & 63u), d = (int)((rec >> 10) & 3u);
+    const int c = ly * PT_LW + plx + 1;
+    const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
+    const uint32_t r0 = slab[c], r1 = slab[c + ddy * PT_LW + ddx];
+    const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
+    const int e = ltab_insert(tkey, key);
+    uint32_t ee = 255u, rk = 0u;
+    if (e >= 0 && e < 255) { ee = (uint32_t)e; rk = atomicAdd(&tcnt[e], 1u); }
+    elist[q] = rec | (ee << 12) | (rk << 20);
+  }
+  __syncthreads();
+#if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 3
+  if (P.max_nmaxima == 10) { rank_all[(size_t)frame * P.pcap + blockIdx.x * 256 + tid] = emask ^ off ^ elist[tid] ^ sbase; return; }
+#endif
+  {
+    // one global insert + one global add per distinct pair of this block; the add's return value is the base rank of
+    // the block's points inside the cluster
     const unsigned long long key = tkey[tid];
     if (key != AT_EMPTY_KEY) {
       const uint32_t slot = hash_insert(hkeys, P.hcap, P.hshift, key);
@@ -195,29 +221,20 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
       else atomicOr(&counters[frame].flags, 0x2u);
       tslot[tid] = slot;
       tbase[tid] = base;
-      tcnt[tid] = 0;
     }
   }
   __syncthreads();
-#if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 3
-  if (P.max_nmaxima == 10) { rank_all[(size_t)frame * P.pcap + blockIdx.x * 256 + tid] = emask ^ eidx[0] ^ eidx[1] ^ eidx[2] ^ eidx[3] ^ off ^ sbase; return; }
-#endif
   const uint32_t base = sbase;
   if (base + total > P.pcap) {
     if (tid == 0) atomicOr(&counters[frame].flags, 0x1u);
   }
-  // pass 2: emit {slot, point} and the rank inside the cluster.  The emitters pass 1 remembered are first written
-  // to a block-wide list in LDS (at the thread's scan offset), then the list is consumed DENSELY: entry q belongs to
-  // thread q mod 256, so every lane of every wave has an emission to work on (the per-thread loop over a 16-bit
-  // mask ran at under half the lanes and as long as the busiest lane), the staging stores of a wave are 64
-  // consecutive records, and the rank inside the (block, pair) group is handed out with one LDS atomic per distinct
-  // pair and wave instead of one per point.  Emissions beyond the list capacity (more than two per pixel of the
-  // tile on average) take the per-thread path.
+  // pass 3: emit {slot, point} and the rank inside the cluster, dense over the list again: the staging stores of a wave
+  // are 64 consecutive records.
   uint2* stage = stage_all + (size_t)frame * P.pcap;
   uint32_t* rank = rank_all + (size_t)frame * P.pcap;
-  auto emit_direct = [&](uint32_t rec, uint32_t pos) {
+  auto emit = [&](uint32_t rec, uint32_t pos) {
     const int ly = (int)(rec & 1023u) >> 6, plx = (int)(rec & 63u), d = (int)((rec >> 10) & 3u);
-    const uint32_t e = rec >> 12;
+    const uint32_t e = (rec >> 12) & 255u;
     const int c = ly * PT_LW + plx + 1;
     const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
     const int n = c + ddy * PT_LW + ddx;
@@ -225,8 +242,8 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     uint32_t slot, rk = 0;
     if (e != 255u) {
       slot = tslot[e];
-      if (slot != AT_INVALID_SLOT) rk = tbase[e] + atomicAdd(&tcnt[e], 1u);
-    } else {  // block table was full: this pair goes straight to the frame table
+      if (slot != AT_INVALID_SLOT) rk = tbase[e] + (rec >> 20);
+    } else {  // not counted in the block table: this point goes straight to the frame table
       const uint32_t r0 = slab[c], r1 = slab[n];
       const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
       slot = hash_insert(hkeys, P.hcap, P.hshift, key);
@@ -238,59 +255,15 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
       rank[pos] = rk;
     }
   };
-  {
+  for (uint32_t q = tid; q < nlist; q += 256) emit(elist[q], base + q);
+  if (off + cnt > PT_ELIST) {   // this thread's emissions beyond the list
     uint32_t q = off, m = emask;
     while (m) {
       const int sidx = __ffs((int)m) - 1;
       m &= m - 1;
-      const int k = sidx >> 2, d = sidx & 3;
-      const uint32_t e = (eidx[k] >> (8 * d)) & 255u;
-      const uint32_t rec = (uint32_t)(((tid >> 6) + 4 * k) * 64 + lx) | ((uint32_t)d << 10) | (e << 12);
-      if (q < PT_ELIST) elist[q] = rec;
-      else emit_direct(rec, base + q);
+      if (q >= PT_ELIST)
+        emit((uint32_t)(((tid >> 6) + 4 * (sidx >> 2)) * 64 + lx) | ((uint32_t)(sidx & 3) << 10) | (255u << 12), base + q);
       q++;
-    }
-  }
-  __syncthreads();
-  const uint32_t nlist = total < PT_ELIST ? total : PT_ELIST;
-  const int lane = lane_id();
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  for (uint32_t q0 = 0; q0 < nlist; q0 += 256) {
-    const uint32_t q = q0 + tid;
-    const bool act = q < nlist;
-    const uint32_t rec = act ? elist[q] : 0u;
-    const uint32_t e = rec >> 12;
-    // rank inside the (block, pair) group: one LDS atomic per distinct table entry present in the wave
-    uint32_t rk_local = 0;
-    bool pending = act && e != 255u;
-    unsigned long long todo = __ballot(pending);
-    while (todo) {
-      const int leader = (int)__ffsll((long long)todo) - 1;
-      const uint32_t le = (uint32_t)__builtin_amdgcn_readlane((int)e, leader);
-      const unsigned long long same = __ballot(pending && e == le);
-      uint32_t b = 0;
-      if (lane == leader) b = atomicAdd(&tcnt[le], (uint32_t)__popcll(same));
-      b = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
-      if (pending && e == le) { rk_local = b + (uint32_t)__popcll(same & lt_mask); pending = false; }
-      todo &= ~same;
-    }
-    if (act) {
-      if (e == 255u) {
-        emit_direct(rec, base + q);
-      } else {
-        const int ly = (int)(rec & 1023u) >> 6, plx = (int)(rec & 63u), d = (int)((rec >> 10) & 3u);
-        const int c = ly * PT_LW + plx + 1;
-        const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
-        const int n = c + ddy * PT_LW + ddx;
-        const int v0 = sv[c], v1 = sv[n];
-        const uint32_t slot = tslot[e];
-        const uint32_t rk = (slot != AT_INVALID_SLOT) ? tbase[e] + rk_local : 0u;
-        const uint32_t pos = base + q;
-        if (pos < P.pcap) {
-          stage[pos] = make_uint2(slot, pack_point(2 * (X0 + plx) + ddx, 2 * (Y0 + ly) + ddy, ddx * (v1 - v0), ddy * (v1 - v0)));
-          rank[pos] = rk;
-        }
-      }
     }
   }
 }
