@@ -21,6 +21,8 @@
 #include "common.h"
 
 #define CC_T 64  // tile edge
+#define CC_UROWS 4   // (2 rows: 3.38 ms, 4: 3.34, 8: 4.6 -- the list costs a workgroup slot per CU)
+#define CC_UREQ (CC_UROWS * 3 * 64)   // link requests of CC_UROWS rows of one wave (at most three per pixel)
 
 // (relaxed workgroup-scope atomic loads, not volatile ones: a volatile access keeps the generic address space and
 // compiles to flat_load ... sc0 sc1 through the shared aperture instead of ds_read_b32)
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   __shared__ __attribute__((aligned(16))) uint8_t st[CC_T * CC_T];
   __shared__ uint32_t sl[CC_T * CC_T];
   __shared__ uint32_t s_nroots, s_rbase;
+  __shared__ uint16_t s_ureq[4 * CC_UREQ];
   const int frame = (int)blockIdx.z + P.frame0;
   const int X0 = blockIdx.x * CC_T, Y0 = blockIdx.y * CC_T;
   const int W = P.W, H = P.H;
@@ -113,24 +116,53 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   if (P.max_nmaxima == 10) return;
 #endif
   // ---- 2. unions with the row above (only the first pixel of every overlap) -------------------
-  for (int k = 0; k < 16; k++) {
-    const int r = wv * 16 + k;
-    if (r == 0) continue;
-    const uint32_t v = st[r * CC_T + lane];
-    if (v == 127 || !src_ok) continue;
-    const uint32_t me = (uint32_t)(r * CC_T + lane);
-    const uint32_t vu = st[(r - 1) * CC_T + lane];
-    const uint32_t vl = lane > 0 ? st[r * CC_T + lane - 1] : 127;
-    const uint32_t vul = lane > 0 ? st[(r - 1) * CC_T + lane - 1] : 127;
-    const bool left_src = gx - 1 >= 1;  // (x-1) is itself a valid link source
-    if (vu == v && !(lane > 0 && left_src && vl == v && vul == v)) lds_union(sl, me, me - CC_T);
-    if (v == 255) {
-      if (lane > 0 && vul == 255 && vu != 255 && !(left_src && vl == 255)) lds_union(sl, me, me - CC_T - 1);
-      if (lane < 63) {
-        const uint32_t vur = st[(r - 1) * CC_T + lane + 1];
-        const uint32_t vr = st[r * CC_T + lane + 1];
-        const bool right_src = gx + 1 <= W - 2;
-        if (vur == 255 && !(right_src && (vu == 255 || vr == 255))) lds_union(sl, me, me - CC_T + 1);
+  // A lane has at most three links to the row above (up, up-left, up-right) and most lanes have none, so the link
+  // requests of four rows at a time are compacted into a wave-private list (ballot + popcount, no atomics) and the
+  // unions -- root chases and atomicMin retries -- run DENSE over it, every lane on a real link.  (Calling the union
+  // under the three conditions directly ran each call on the few lanes that had that link and as long as the
+  // longest chase among them.)  Entry = pixel << 2 | partner (0: up, 1: up-left, 2: up-right).
+  {
+    uint16_t* ureq = s_ureq + wv * CC_UREQ;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int k0 = 0; k0 < 16; k0 += CC_UROWS) {
+      uint32_t nreq = 0;   // uniform
+#pragma unroll
+      for (int kk = 0; kk < CC_UROWS; kk++) {
+        const int r = wv * 16 + k0 + kk;
+        bool up = false, upl = false, upr = false;
+        const uint32_t me = (uint32_t)(r * CC_T + lane);
+        if (r > 0) {
+          const uint32_t v = st[r * CC_T + lane];
+          if (v != 127 && src_ok) {
+            const uint32_t vu = st[(r - 1) * CC_T + lane];
+            const uint32_t vl = lane > 0 ? st[r * CC_T + lane - 1] : 127;
+            const uint32_t vul = lane > 0 ? st[(r - 1) * CC_T + lane - 1] : 127;
+            const bool left_src = gx - 1 >= 1;  // (x-1) is itself a valid link source
+            up = vu == v && !(lane > 0 && left_src && vl == v && vul == v);
+            if (v == 255) {
+              upl = lane > 0 && vul == 255 && vu != 255 && !(left_src && vl == 255);
+              if (lane < 63) {
+                const uint32_t vur = st[(r - 1) * CC_T + lane + 1];
+                const uint32_t vr = st[r * CC_T + lane + 1];
+                const bool right_src = gx + 1 <= W - 2;
+                upr = vur == 255 && !(right_src && (vu == 255 || vr == 255));
+              }
+            }
+          }
+        }
+        const unsigned long long m0 = __ballot(up), m1 = __ballot(upl), m2 = __ballot(upr);
+        if (up) ureq[nreq + (uint32_t)__popcll(m0 & lt_mask)] = (uint16_t)(me << 2);
+        nreq += (uint32_t)__popcll(m0);
+        if (upl) ureq[nreq + (uint32_t)__popcll(m1 & lt_mask)] = (uint16_t)((me << 2) | 1u);
+        nreq += (uint32_t)__popcll(m1);
+        if (upr) ureq[nreq + (uint32_t)__popcll(m2 & lt_mask)] = (uint16_t)((me << 2) | 2u);
+        nreq += (uint32_t)__popcll(m2);
+      }
+      // (wave-private list: the wave's own LDS writes are visible to its later reads in program order)
+      for (uint32_t i = (uint32_t)lane; i < nreq; i += 64) {
+        const uint32_t q = ureq[i];
+        const uint32_t me = q >> 2, t = q & 3u;
+        lds_union(sl, me, me - CC_T - (t == 1u ? 1u : 0u) + (t == 2u ? 1u : 0u));
       }
     }
   }
