@@ -280,7 +280,8 @@ __device__ __forceinline__ void cc_column_links(const uint8_t* thr, uint32_t* la
   const uint32_t meR = (uint32_t)(gy * W + gx), meL = meR - 1;
   auto link = [&](uint32_t a, uint32_t b2) { glb_union(label, label[a], label[b2]); };
   if (gx <= W - 2 && vR != 127) {                      // (gx, gy) is a link source
-    if (vL == vR) link(meR, meL);
+    // (the same link one row up, with both pixels joined to their upper neighbours inside their tiles, already implies it)
+    if (vL == vR && !(upward && vLu == vR && vRu == vR)) link(meR, meL);
     if (upward && vR == 255 && vLu == 255 && vRu != 255 && vL != 255) link(meR, meR - W - 1);
   }
   if (upward && vL == 255) {                            // (gx - 1, gy) is a source (1 <= gx - 1 <= W - 2 always)
