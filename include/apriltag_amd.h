@@ -76,7 +76,7 @@ typedef struct {
   uint32_t width;
   uint32_t height;
   const uint8_t* dev_ptr; /* mono8, device memory */
-  size_t pitch;           /* bytes per row */
+  size_t pitch;           /* bytes per row; pitch * height must stay below 2^31 (AMDAT_INVALID_ARGUMENT otherwise) */
 } amdAprilTagsImageInput_t;
 
 typedef struct {

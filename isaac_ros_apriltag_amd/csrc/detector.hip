@@ -367,9 +367,17 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
     const unsigned cus = (unsigned)D->num_cus;
     auto minu = [](unsigned a, unsigned b) { return a < b ? a : b; };
     FqClass* c = D->cls;
-    c[0] = {64, 256, 0, 256, minu((unsigned)FQ_GRID_64 * cus, 4096u * (unsigned)B), 256, 16};
-    c[1] = {128, 1024, 256, 1024, minu((unsigned)FQ_GRID_128 * cus, 1024u * (unsigned)B), 1024, 8};
-    c[2] = {256, 4096, 1024, 4096, minu(4u * cus, 256u * (unsigned)B), 4096, 2};
+    // Class boundaries: the one-wave class has no workgroup barriers at all and runs closest to the VALU issue rate
+    // (82 % against 53-57 % for the 128- and 256-thread classes), so it takes clusters up to 768 points, the most its
+    // 16 workgroups per CU can hold in LDS (9 KB each); measured 16.1 ms (256 / 1024) -> 15.5 (512 / 1024) -> 15.35
+    // (768 / 2048); 896 and 1024 are slower again (fewer resident workgroups).
+#ifndef FQ_B01
+#define FQ_B01 768
+#define FQ_B12 2048
+#endif
+    c[0] = {64, FQ_B01, 0, FQ_B01, minu((unsigned)FQ_GRID_64 * cus, 4096u * (unsigned)B), FQ_B01, 16};
+    c[1] = {128, FQ_B12, FQ_B01, FQ_B12, minu((unsigned)FQ_GRID_128 * cus, 1024u * (unsigned)B), FQ_B12, 8};
+    c[2] = {256, 4096, FQ_B12, 4096, minu(4u * cus, 256u * (unsigned)B), 4096, 2};
     c[3] = {512, 8192, 4096, 8192, minu(2u * cus, 64u * (unsigned)B), 8192, 1};
     c[4] = {FQ_NT_BIG, 16384, 8192, 0x7FFFFFFF, minu(cus, 16u * (unsigned)B), P.max_cluster_points, 1};
     if (P.max_cluster_points > 16384 && P.max_cluster_points <= 18432) c[4].sort_cap = (P.max_cluster_points + 63) & ~63;

@@ -1,7 +1,7 @@
 // kernels_quad.h -- S5 quad fitting (inside cuAprilTagsDetect, reference
 // src/apriltag_node.cpp:491-493).  One workgroup per cluster, five launch classes by cluster size
-// (one wave for <= 256 points ... 1024 threads above 8192) so that small clusters do not pay for idle
-// waves and the slope sort always runs in LDS (2 KB ... 145 KB of keys).  Every class is one launch of
+// (one wave for <= 768 points ... 1024 threads above 8192) so that small clusters do not pay for idle
+// waves and the slope sort always runs in LDS (6 KB ... 145 KB of keys).  Every class is one launch of
 // PERSISTENT workgroups: k_worklist has bucketed the clusters of all frames of the submission into one
 // compact work list per class, and a workgroup pops the next cluster with one atomic until its list is
 // empty -- no workgroup walks clusters of another class, and the cumulative-moment array of a cluster lives

@@ -295,6 +295,9 @@ def test_error_behaviour(built):
     imgs[0].dev_ptr = None
     assert L.amdAprilTagsDetectBatch(det._h, 1, imgs, None, out, cnt, 64, None) == 1      # null image
     imgs[0].dev_ptr = t.data_ptr()
+    imgs[0].pitch = 1 << 23                                                               # frame spans more than 2^31 bytes
+    assert L.amdAprilTagsDetectBatch(det._h, 1, imgs, None, out, cnt, 64, None) == 1
+    imgs[0].pitch = 640
     assert L.amdAprilTagsDetect(det._h, imgs, out, cnt, 64, None) == 0 and cnt[0] == 1
     # capacity overflow is reported, never UB
     small = AprilTagDetector(640, 480, intrinsics=_k4(K), max_batch=1, max_points=1000)
