@@ -375,9 +375,16 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
 #define FQ_B01 768
 #define FQ_B12 2048
 #endif
-    c[0] = {64, FQ_B01, 0, FQ_B01, minu((unsigned)FQ_GRID_64 * cus, 4096u * (unsigned)B), FQ_B01, 16};
-    c[1] = {128, FQ_B12, FQ_B01, FQ_B12, minu((unsigned)FQ_GRID_128 * cus, 1024u * (unsigned)B), FQ_B12, 8};
-    c[2] = {256, 4096, FQ_B12, 4096, minu(4u * cus, 256u * (unsigned)B), 4096, 2};
+    // Clusters per pop: one atomic per cluster saturates the list cursor (one-wave class: 18.7 ms), chunks of 16 / 8 / 2
+    // leave workgroups with up to 16 clusters of work while others have drained the list (15.4 ms); 4 / 2 / 1: 15.0.
+#ifndef FQ_POP0
+#define FQ_POP0 4
+#define FQ_POP1 2
+#define FQ_POP2 1
+#endif
+    c[0] = {64, FQ_B01, 0, FQ_B01, minu((unsigned)FQ_GRID_64 * cus, 4096u * (unsigned)B), FQ_B01, FQ_POP0};
+    c[1] = {128, FQ_B12, FQ_B01, FQ_B12, minu((unsigned)FQ_GRID_128 * cus, 1024u * (unsigned)B), FQ_B12, FQ_POP1};
+    c[2] = {256, 4096, FQ_B12, 4096, minu(4u * cus, 256u * (unsigned)B), 4096, FQ_POP2};
     c[3] = {512, 8192, 4096, 8192, minu(2u * cus, 64u * (unsigned)B), 8192, 1};
     c[4] = {FQ_NT_BIG, 16384, 8192, 0x7FFFFFFF, minu(cus, 16u * (unsigned)B), P.max_cluster_points, 1};
     if (P.max_cluster_points > 16384 && P.max_cluster_points <= 18432) c[4].sort_cap = (P.max_cluster_points + 63) & ~63;

@@ -665,11 +665,12 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       //           with what walk 2 needs (kept flag, coordinates, squared gradient);
       //   scan    lane totals over the wave (DPP) and the waves (LDS), kept-point counts alongside;
       //   walk 2  every lane replays its points from its exclusive offset and rounds each prefix once.
-      // From 8 points per lane on, E is made odd so that the lanes' key slots (stride E * 8 bytes) fall into different
-      // LDS banks.
+      // (The lanes' key slots lie E keys apart; the skew of the key array -- one slot per 32 keys -- spreads any stride
+      // over the banks, so E needs no rounding to an odd number: in LDS key k of lane t sits at E*t + k + ((E*t + k) >> 5).
+      // Only the global-scratch path of the largest class keeps the odd stride, for its 64-byte segments.)
       const int lane = lane_id(), wv = tid >> 6;
       int E = (sz + NT - 1) / NT;
-      if (E >= 8) E |= 1;   // (small strides cost at most a 4-way conflict; an odd E of 3 or 5 would idle a third of the lanes)
+      if (!in_lds && E >= 8) E |= 1;
       const int i0 = tid * E, i1 = min(sz, i0 + E);
       D2* const sd_wtot = reinterpret_cast<D2*>(s_wtot);
       D2* const sd_woff = reinterpret_cast<D2*>(s_woff);
