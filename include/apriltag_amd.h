@@ -235,8 +235,8 @@ typedef enum {
 int amdAprilTagsDebugCopy(amdAprilTagsHandle handle, uint32_t frame, amdAprilTagsDebugBuffer what,
                           void* host_dst, size_t capacity, size_t* bytes);
 /* Device-arithmetic self check: op 0 = sqrt(f64), 1 = a/b (f64), 2 = sqrtf(f32 bits in low word),
- * 3 = a/b (f32), 4 = a/b (f64) through the shared-reciprocal sequence the line fit uses.  n pairs in, n
- * results out (host pointers). */
+ * 3 = a/b (f32), 4 = a/b (f64) through the shared-reciprocal sequence the line fit uses, 5 = square root of the
+ * integer a < 2^18 through the line-fit weights' f32-seeded sequence.  n pairs in, n results out (host pointers). */
 int amdAprilTagsDebugMath(int op, uint32_t n, const double* a, const double* b, double* out);
 
 #ifdef __cplusplus
