@@ -671,6 +671,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       const int lane = lane_id(), wv = tid >> 6;
       int E = (sz + NT - 1) / NT;
       if (!in_lds && E >= 8) E |= 1;
+      if (in_lds && (E & 31) == 31) E++;   // the one stride the skew folds back onto a single bank pair (31 + 31/32 keys)
       const int i0 = tid * E, i1 = min(sz, i0 + E);
       D2* const sd_wtot = reinterpret_cast<D2*>(s_wtot);
       D2* const sd_woff = reinterpret_cast<D2*>(s_woff);
