@@ -268,6 +268,41 @@ __device__ __forceinline__ void fit_line_dev(const double* lf, int sz, int i0, i
   if (mse) *mse = eig_small;
 }
 
+// ---- sound early exit before the second walk of the moment sweep ----------------------------------------------------
+// A quad needs four corner indices i0 < i1 < i2 < i3 of the sorted, duplicate-free point sequence such that each of
+// the four arcs between them fits a line with mse <= max_line_fit_mse.  mse = lambda_min(S) / W with S the weighted
+// scatter matrix of the arc and W its weight.  For point sets A within B: lambda_min(S_A) <= lambda_min(S_B) (the
+// scatter of a union is the sum of the parts' scatters plus a positive semidefinite between-part term) and W_A <= W_B.
+// Cut the sequence into FQ_XG groups of consecutive points; with the corners in groups a <= b <= c <= d, an arc between
+// two cut groups contains every group strictly between them and lies within the groups from cut to cut, so
+//   lambda_min(S of the groups strictly between) <= mse_limit * (weight of the groups from cut to cut)
+// is NECESSARY for the arc.  If no a <= b <= c <= d passes that test on all four arcs (the fourth wraps around the end
+// of the sequence), no corner choice can be admissible and the cluster ends at "no admissible corner choice" whatever
+// the maxima turn out to be: the second walk, the windowed errors, the maxima and the corner search are skipped.
+// The test never changes a result.  mse_limit carries an allowance for the rounding of the evaluation it stands in
+// for (differences of once-rounded prefixes: a few ulps of the largest prefix over an arc weight >= 2; the float square
+// root: 2^-23.5 of the arc's total variance, which the image diagonal bounds) and for its own rounding (2 %).
+// On sigma-2 1080p frames 72 % of the points of clusters without an admissible corner choice sit in clusters this
+// test rejects with 64 groups, 68 % with 32 (tools/early_exit_power.py, CPU restatement); the one-wave class (up to
+// 768 points) gains nothing from it and does not run it.
+#define FQ_XG 32
+// moments of prefix difference hi - lo (+ add), returns false only if lambda_min of their scatter exceeds thr * Wc
+__device__ __forceinline__ bool fq_arc_possible(const double* lo, const double* hi, const double* add, double Wc, double thr) {
+  double m[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) m[j] = hi[j] - lo[j];
+  if (add) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) m[j] += add[j];
+  }
+  if (!(m[5] > 0.5)) return true;   // no points in between (every weight is >= 1)
+  const double rW = 1.0 / m[5];
+  const double Sxx = m[2] - m[0] * m[0] * rW, Sxy = m[3] - m[0] * m[1] * rW, Syy = m[4] - m[1] * m[1] * rW;
+  const double dif = Sxx - Syy;
+  const double lam = 0.5 * ((Sxx + Syy) - __dsqrt_rn(dif * dif + 4.0 * Sxy * Sxy));
+  return !(lam > thr * Wc);
+}
+
 // Sort keys are stored so that their order as IEEE doubles equals the wanted unsigned order: a
 // compare-exchange is then v_min_f64 + v_max_f64 (two instructions instead of a 64-bit compare and four
 // selects).  u >= 2^63 -> positive double with the same lower 63 bits; u < 2^63 -> ~u, a negative double
@@ -513,6 +548,8 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
   __shared__ int s_coff[NW + 1];    // kept-point offsets per wave, [NW] = chunk total
   __shared__ U128 s_carry[12];   // [chunk parity][moment]: running totals up to the chunk
   __shared__ uint32_t s_item;
+  __shared__ uint32_t s_okf[FQ_XG], s_okw[FQ_XG];   // early exit: admissible forward / wrap-around arcs per cut group
+  __shared__ int s_feasible;
 
   const int tid = threadIdx.x;
   const int W = P.W, H = P.H;
@@ -755,6 +792,63 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
         }
         pos += s_coff[wv];
         szd = s_coff[NW];
+#ifndef AMDAT_FQ_NO_EARLY_EXIT
+        // ---- sound early exit (see fq_arc_possible above): no four cut points can give four admissible arcs ------
+        // The kept points of the sorted order are cut into FQ_XG groups (runs of NT / FQ_XG lanes); the inclusive
+        // moment prefix at the end of every group goes to LDS (the pair-table region is free until the maxima exist).
+        {
+          constexpr int LPG = NT / FQ_XG;
+          double* const sP = chunk;   // [(FQ_XG + 1)][6]
+          if (tid < 6) sP[tid] = 0.0;
+          if ((tid & (LPG - 1)) == LPG - 1) {
+            const int g = tid / LPG;
+#pragma unroll
+            for (int j = 0; j < 6; j++) sP[(g + 1) * 6 + j] = (off[j].hi + acc[j].hi) + (off[j].lo + acc[j].lo);
+          }
+          __syncthreads();
+          // rounding allowance of the reference evaluation (difference of rounded prefixes, float square root) on top of
+          // the threshold: see fq_arc_possible
+          const double thr = P.max_line_fit_mse * 1.02 + 0.1 + 0x1p-50 * (sP[FQ_XG * 6 + 2] + sP[FQ_XG * 6 + 4]) +
+                             1e-7 * 0.25 * ((double)W * (double)W + (double)H * (double)H);
+#pragma unroll 1
+          for (int pbase = 0; pbase < FQ_XG * FQ_XG; pbase += NT) {
+            const int pi = pbase + tid, a = pi / FQ_XG, b = pi & (FQ_XG - 1);
+            bool okf = true, okw = true;
+            if (b >= a) {
+              if (b >= a + 2) okf = fq_arc_possible(sP + (a + 1) * 6, sP + b * 6, nullptr, sP[(b + 1) * 6 + 5] - sP[a * 6 + 5], thr);
+              __builtin_amdgcn_sched_barrier(0);   // (one evaluation's prefix loads at a time: both at once spill)
+              okw = fq_arc_possible(sP + (b + 1) * 6, sP + FQ_XG * 6, sP + a * 6,
+                                    (sP[FQ_XG * 6 + 5] - sP[b * 6 + 5]) + sP[(a + 1) * 6 + 5], thr);
+            }
+            // lanes 0..31 of a wave share a, lanes 32..63 the next one (FQ_XG == 32)
+            const unsigned long long mf = __ballot(okf && b >= a), mw = __ballot(okw && b >= a);
+            if ((tid & 31) == 0) {
+              s_okf[a] = (uint32_t)(mf >> (tid & 32));
+              s_okw[a] = (uint32_t)(mw >> (tid & 32));
+            }
+          }
+          __syncthreads();
+          if (tid < 64) {
+            // cut groups a <= b <= c <= d: forward arcs a->b, b->c, c->d and the wrap-around arc d->a must all be possible
+            const uint32_t rowf = tid < FQ_XG ? s_okf[tid] : 0u, roww = tid < FQ_XG ? s_okw[tid] : 0u;
+            uint32_t r2 = 0, r3 = 0;
+#pragma unroll 8
+            for (int b = 0; b < FQ_XG; b++) {
+              const uint32_t rb = (uint32_t)__builtin_amdgcn_readlane((int)rowf, b);
+              r2 |= ((rowf >> b) & 1u) ? rb : 0u;
+            }
+#pragma unroll 8
+            for (int c = 0; c < FQ_XG; c++) {
+              const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)rowf, c);
+              r3 |= ((r2 >> c) & 1u) ? rc : 0u;
+            }
+            const unsigned long long any = __ballot((r3 & roww) != 0u);
+            if (tid == 0) s_feasible = any != 0ull;
+          }
+          __syncthreads();
+          if (!s_feasible) continue;
+        }
+#endif
       } else {
 #pragma unroll
         for (int j = 0; j < 6; j++) { off[j].hi = incl[j].hi - acc[j].hi; off[j].lo = incl[j].lo - acc[j].lo; }

@@ -323,7 +323,23 @@ typedef struct { double Mx, My, Mxx, Mxy, Myy, W; } lfp_t;
  * 3 fewer than 4 maxima, 4 no admissible corner choice, 5 total error, 6 final line mse, 7 degenerate
  * intersection, 8 area, 9 angles / winding, 10 accepted. */
 long long ato_stats[32];
-#define ATO_STAT(r, n) do { ato_stats[(r)]++; ato_stats[16 + (r)] += (n); } while (0)
+/* Diagnostic log of the partition bound (tools/early_exit_power.py): when ato_diag_cap > 0, every cluster that
+ * reaches the moment prefixes appends {reason, points, ratio[8]}: ratio[k] = (sum of the groups' scatter
+ * minimum eigenvalues minus the four largest) / (10 * (W_total + 4 * 362)) for groups of (run << k) kept points,
+ * run = the lane run of the HIP kernel's size class.  A ratio above 1 proves that no corner choice is admissible. */
+typedef struct { int reason, points; double ratio[8]; } ato_diag_rec_t;
+ato_diag_rec_t* ato_diag_log;
+int ato_diag_cap, ato_diag_n;
+static __thread double g_diag_ratio[8];
+static __thread int g_diag_have;
+static void ato_diag_push(int reason, int points) {
+  if (ato_diag_cap > 0 && g_diag_have && ato_diag_n < ato_diag_cap) {
+    ato_diag_rec_t* r = &ato_diag_log[ato_diag_n++];
+    r->reason = reason; r->points = points;
+    memcpy(r->ratio, g_diag_ratio, sizeof(g_diag_ratio));
+  }
+}
+#define ATO_STAT(r, n) do { ato_stats[(r)]++; ato_stats[16 + (r)] += (n); ato_diag_push((r), (n)); } while (0)
 static __thread int g_qsm_reason;
 
 
@@ -575,6 +591,63 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
     lfps[i].Mx = r[0]; lfps[i].My = r[1]; lfps[i].Mxx = r[2]; lfps[i].Mxy = r[3]; lfps[i].Myy = r[4]; lfps[i].W = r[5];
   }
   free(keys);
+  g_diag_have = 0;
+  if (ato_diag_cap > 0) {
+    /* relaxed feasibility over m groups of consecutive kept points: cut groups a <= b <= c <= d; an arc between two
+     * cut groups is possible only if the scatter of the whole groups strictly between them has
+     * lambda_min <= T * (weight of the groups from cut to cut inclusive) */
+    static const int MS[8] = {16, 24, 32, 48, 64, 96, 128, 256};
+    for (int k = 0; k < 8; k++) {
+      int m = MS[k];
+      int G = (sz + m - 1) / m;
+      m = (sz + G - 1) / G;
+      double (*P)[6] = malloc(sizeof(double) * 6 * (m + 1));   /* prefix over groups: P[j] = sums of groups < j */
+      for (int j = 0; j <= m; j++) {
+        int e = j * G < sz ? j * G : sz;
+        if (e == 0) { for (int t = 0; t < 6; t++) P[j][t] = 0; }
+        else { P[j][0] = lfps[e-1].Mx; P[j][1] = lfps[e-1].My; P[j][2] = lfps[e-1].Mxx; P[j][3] = lfps[e-1].Mxy; P[j][4] = lfps[e-1].Myy; P[j][5] = lfps[e-1].W; }
+      }
+      const double T = 10.5;
+      unsigned char* ok = calloc((size_t)m * m, 1);   /* ok[a*m+b], a <= b: forward arc; ok[b*m+a] (b>=a) stored at [d*m+a] with d >= a as wrap in okw */
+      unsigned char* okw = calloc((size_t)m * m, 1);
+      for (int a = 0; a < m; a++)
+        for (int b = a; b < m; b++) {
+          /* forward: inner groups a+1..b-1 */
+          int o = 1;
+          if (b > a + 1) {
+            double M[6]; for (int t = 0; t < 6; t++) M[t] = P[b][t] - P[a + 1][t];
+            double Wc = P[b + 1][5] - P[a][5];
+            double Sxx = M[2] - M[0] * M[0] / M[5], Sxy = M[3] - M[0] * M[1] / M[5], Syy = M[4] - M[1] * M[1] / M[5];
+            double q = 0.5 * (Sxx + Syy - sqrt((Sxx - Syy) * (Sxx - Syy) + 4 * Sxy * Sxy));
+            o = q <= T * Wc;
+          }
+          ok[a * m + b] = (unsigned char)o;
+          /* wrap d=b -> a: inner groups b+1..m-1 and 0..a-1 */
+          int ow = 1;
+          int ninner = (m - 1 - b) + a;
+          if (ninner > 0) {
+            double M[6]; for (int t = 0; t < 6; t++) M[t] = (P[m][t] - P[b + 1][t]) + P[a][t];
+            double Wc = (P[m][5] - P[b][5]) + P[a + 1][5];
+            double Sxx = M[2] - M[0] * M[0] / M[5], Sxy = M[3] - M[0] * M[1] / M[5], Syy = M[4] - M[1] * M[1] / M[5];
+            double q = 0.5 * (Sxx + Syy - sqrt((Sxx - Syy) * (Sxx - Syy) + 4 * Sxy * Sxy));
+            ow = q <= T * Wc;
+          }
+          okw[b * m + a] = (unsigned char)ow;
+        }
+      int feasible = 0;
+      unsigned char* r1 = malloc(m), *r2 = malloc(m), *r3 = malloc(m);
+      for (int a = 0; a < m && !feasible; a++) {
+        memset(r1, 0, m); memset(r2, 0, m); memset(r3, 0, m);
+        for (int b = a; b < m; b++) if (ok[a * m + b]) r1[b] = 1;
+        for (int b = a; b < m; b++) if (r1[b]) for (int c = b; c < m; c++) if (ok[b * m + c]) r2[c] = 1;
+        for (int c = a; c < m; c++) if (r2[c]) for (int d = c; d < m; d++) if (ok[c * m + d]) r3[d] = 1;
+        for (int d = a; d < m; d++) if (r3[d] && okw[d * m + a]) { feasible = 1; break; }
+      }
+      free(r1); free(r2); free(r3); free(ok); free(okw); free(P);
+      g_diag_ratio[k] = feasible ? 0.0 : 2.0;
+    }
+    g_diag_have = 1;
+  }
 
   int res = 0, indices[4];
   double lines[4][4];
