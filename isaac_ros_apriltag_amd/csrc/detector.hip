@@ -136,7 +136,8 @@ struct amdAprilTagsDetector_st {
   uint32_t* d_pts = nullptr;
   ClusterRec* d_clusters = nullptr;
   uint32_t* d_work = nullptr;        // work lists of the quad fit (all classes, FqWorkLayout)
-  uint32_t* d_workctl = nullptr;     // [0..7] items per class, [8..15] pop cursors
+  uint32_t* d_workctl = nullptr;     // [0..7] items per class, [8..15] pop cursors, [16..23] items per class after k_fit_prefilter
+  uint32_t* d_work2 = nullptr;       // compact work lists of the prefiltered classes (same layout as d_work)
   unsigned long long* d_keys_scr = nullptr;  // only when a cluster can exceed the LDS key array (large images)
   QuadRec* d_quads = nullptr;
   DetRec* d_dets = nullptr;
@@ -261,7 +262,7 @@ static void free_all(amdAprilTagsDetector_st* D) {
   if (D->graph_exec) hipGraphExecDestroy(D->graph_exec);
   hipFree(D->d_gray); hipFree(D->d_thr); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_roots); hipFree(D->d_hkeys);
   hipFree(D->d_hcnt); hipFree(D->d_hoff); hipFree(D->d_stage); hipFree(D->d_rank); hipFree(D->d_pts); hipFree(D->d_clusters);
-  hipFree(D->d_work); hipFree(D->d_workctl); hipFree(D->d_keys_scr); hipFree(D->d_quads);
+  hipFree(D->d_work); hipFree(D->d_work2); hipFree(D->d_workctl); hipFree(D->d_keys_scr); hipFree(D->d_quads);
   for (auto& c : D->cls) { hipFree(c.d_lf); hipFree(c.d_errs); }
   hipFree(D->d_fqprof);
   hipFree(D->d_dets); hipFree(D->d_out); hipFree(D->d_order); hipFree(D->d_counters); hipFree(D->d_frames);
@@ -420,7 +421,8 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   alloc((void**)&D->d_pts, B * (size_t)P.pcap * 4);
   alloc((void**)&D->d_clusters, B * (size_t)P.ccap * sizeof(ClusterRec));
   alloc((void**)&D->d_work, ((size_t)D->work_layout.off[FQ_NCLS - 1] + D->work_layout.cap[FQ_NCLS - 1]) * 4);
-  alloc((void**)&D->d_workctl, 16 * 4);
+  alloc((void**)&D->d_work2, ((size_t)D->work_layout.off[FQ_NCLS - 1] + D->work_layout.cap[FQ_NCLS - 1] - D->work_layout.off[FQ_PREFILTER_CLASS]) * 4);
+  alloc((void**)&D->d_workctl, 32 * 4);
   for (int k = 0; k < FQ_NCLS; k++) {
     FqClass& c = D->cls[k];
     if (P.max_cluster_points <= c.lo) continue;
@@ -616,6 +618,21 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
     // the small classes start when both are done: 16.9 -> 15.8 ms.  (Queuing the largest class on a stream of its own
     // next to the second one cost 0.9 ms: its queue sat stalled until the scheduler looked at it again.)
     // A small submission is about latency: all classes start together.
+    // cheap exits of the large classes (bounding box, border direction, sector test) at full occupancy, ahead of their
+    // persistent workgroups, which pop the survivors from the compact lists it writes (d_work2, counts at d_workctl + 16)
+#ifndef AMDAT_FQ_NO_PREFILTER
+    const bool prefilter = P.max_cluster_points > D->cls[FQ_PREFILTER_CLASS].lo && D->d_work2;
+#else
+    const bool prefilter = false;
+#endif
+    uint32_t* const work2 = D->d_work2 ? D->d_work2 - D->work_layout.off[FQ_PREFILTER_CLASS] : nullptr;   // (indexed with the common layout)
+    auto launch_prefilter = [&](hipStream_t sp) {
+      if (!prefilter) return;
+      unsigned gp = (2048u / FQ_PF_NT) * (unsigned)D->num_cus;
+      if (gp > 256u * n) gp = 256u * n;
+      hipLaunchKernelGGL(k_fit_prefilter, dim3(gp), dim3(FQ_PF_NT), 0, sp, D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work,
+                         D->d_workctl, work2, D->d_workctl + 16, D->work_layout, FQ_PREFILTER_CLASS, P);
+    };
     auto launch_class = [&](int c, hipStream_t sc) {
       const FqClass& cl = D->cls[c];
       if (P.max_cluster_points <= cl.lo || !cl.d_lf) return;
@@ -624,7 +641,9 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
       const bool big = c == FQ_NCLS - 1;
       // a small submission spreads its clusters over the workgroups one by one (latency); large ones pop in chunks
       const int pop = cl.pop < (int)(n / 16u) ? cl.pop : ((int)(n / 16u) < 1 ? 1 : (int)(n / 16u));
-#define FQ_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work + D->work_layout.off[c], D->d_workctl + c,                   \
+      const bool filtered = prefilter && c >= FQ_PREFILTER_CLASS;
+#define FQ_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, (filtered ? work2 : D->d_work) + D->work_layout.off[c],                 \
+                D->d_workctl + (filtered ? 16 : 0) + c,                                                                                \
                 D->work_layout.cap[c], D->d_workctl + 8 + c, cl.d_lf, (big ? D->d_keys_scr : nullptr), cl.d_errs,                        \
                 D->d_quads, D->d_counters, (D->fq_counters ? D->d_fqprof + 8 * c : nullptr), cl.sort_cap, cl.slot_cap, pop, P
 #define FQ_LAUNCH(NTV)                                                                                          \
@@ -641,24 +660,42 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
     hipStream_t* aux = D->aux_stream;
     // (throughput-sized: from about 32 1080p working images on; below that the two extra dependent launches cost more
     // than the placement gains -- 64 half-resolution frames measured 3.00 vs 2.88 ms)
-    const bool large_first = (uint64_t)n * (uint64_t)P.W * (uint64_t)P.H >= (64ull << 20);
+#ifndef AMDAT_FQ_ORDER
+#define AMDAT_FQ_ORDER 0
+#endif
+    const bool large_first = AMDAT_FQ_ORDER != 2 && (uint64_t)n * (uint64_t)P.W * (uint64_t)P.H >= (64ull << 20);
     HIP_TRY(hipEventRecord(D->ev_fork, s));
+    if (prefilter) {
+      // The prefilter runs first and alone (a fraction of a millisecond at full occupancy; started beside the small classes
+      // it starved behind their persistent workgroups and finished last).  Then everything starts together: the large
+      // classes first on the submission stream -- they find only the prefilter's few survivors in their lists and are gone
+      // before the small classes have filled the chip -- and the two small classes on side streams, the 128-thread class
+      // (the longest chain) first.
+      launch_prefilter(s);
+      HIP_TRY(hipEventRecord(D->ev_fork, s));
+      for (int a = 0; a < 3; a++) HIP_TRY(hipStreamWaitEvent(aux[a], D->ev_fork, 0));
+      for (int c = FQ_NCLS - 1; c >= FQ_PREFILTER_CLASS; c--) launch_class(c, s);
+      launch_class(1, aux[0]);
+      launch_class(0, aux[1]);
+    } else {
     if (large_first) {
       launch_class(3, s);
       launch_class(4, s);
+      if (AMDAT_FQ_ORDER == 1) launch_class(2, s);
       HIP_TRY(hipEventRecord(D->ev_fork, s));   // both large classes are done
     }
     for (int a = 0; a < 3; a++) HIP_TRY(hipStreamWaitEvent(aux[a], D->ev_fork, 0));
     // (which small class shares the chip with which was measured over seven assignments: 16.0 - 16.9 ms; best when
     // the 256-thread class is the one that ends up running last)
     if (large_first) {
-      for (int c = 0; c < 3; c++) launch_class(c, aux[c]);
+      for (int c = 0; c < (AMDAT_FQ_ORDER == 1 ? 2 : 3); c++) launch_class(c, aux[c]);
     } else {   // the longest chains side by side: the largest clusters | 4096..8192 then the one-wave class | the other two
       launch_class(4, s);
       launch_class(3, aux[0]);
       launch_class(2, aux[1]);
       launch_class(1, aux[2]);
       launch_class(0, aux[0]);
+    }
     }
     for (int a = 0; a < 3; a++) {
       HIP_TRY(hipEventRecord(D->ev_join[a], aux[a]));
@@ -685,7 +722,7 @@ static int enqueue_submission(amdAprilTagsDetector_st* D, uint32_t n, uint32_t o
   mark();
   HIP_TRY(hipMemcpyAsync(D->d_frames, D->h_frames, n * sizeof(FrameDesc), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(D->d_counters, 0, n * sizeof(FrameCounters), s));
-  HIP_TRY(hipMemsetAsync(D->d_workctl, 0, 16 * 4, s));
+  HIP_TRY(hipMemsetAsync(D->d_workctl, 0, 32 * 4, s));
   HIP_TRY(hipMemsetAsync(D->d_hkeys, 0xFF, (size_t)n * P.hcap * 8, s));
   HIP_TRY(hipMemsetAsync(D->d_hcnt, 0, (size_t)n * P.hcap * 4, s));
   if (D->fq_counters) HIP_TRY(hipMemsetAsync(D->d_fqprof, 0, 64 * 8, s));

@@ -286,6 +286,14 @@ __device__ __forceinline__ void fit_line_dev(const double* lf, int sz, int i0, i
 // test rejects with 64 groups, 68 % with 32 (tools/early_exit_power.py, CPU restatement); the one-wave class (up to
 // 768 points) gains nothing from it and does not run it.
 #define FQ_XG 32
+// The pre-sort sector test runs in k_fit_prefilter for the classes from FQ_PREFILTER_CLASS on.  (Inside k_fit_quads --
+// kept for comparison builds, -DFQ_PRESORT_MIN_NT=256 -- the large classes paid for it with one or two workgroups per CU;
+// the 128-thread class gains nothing from it either way: 7 % of its points rejected for 27 % of its cycles, its clusters
+// are small against the 64 x 16 tiles the points arrive in, so the sector changes at almost every point.)
+#ifndef FQ_PRESORT_MIN_NT
+#define FQ_PRESORT_MIN_NT (1 << 20)
+#endif
+#define FQ_PREFILTER_CLASS 2
 // moments of prefix difference hi - lo (+ add), returns false only if lambda_min of their scatter exceeds thr * Wc
 __device__ __forceinline__ bool fq_arc_possible(const double* lo, const double* hi, const double* add, double Wc, double thr) {
   double m[6];
@@ -295,12 +303,74 @@ __device__ __forceinline__ bool fq_arc_possible(const double* lo, const double* 
 #pragma unroll
     for (int j = 0; j < 6; j++) m[j] += add[j];
   }
-  if (!(m[5] > 0.5)) return true;   // no points in between (every weight is >= 1)
+  if (!(m[5] > 0.25)) return true;   // no points in between (every weight is >= 1/2)
   const double rW = 1.0 / m[5];
   const double Sxx = m[2] - m[0] * m[0] * rW, Sxy = m[3] - m[0] * m[1] * rW, Syy = m[4] - m[1] * m[1] * rW;
   const double dif = Sxx - Syy;
   const double lam = 0.5 * ((Sxx + Syy) - __dsqrt_rn(dif * dif + 4.0 * Sxy * Sxy));
   return !(lam > thr * Wc);
+}
+// The whole test on a prefix array sP[(FQ_XG + 1)][ST] in LDS (entry g = sums over the groups before g; components 0..5 =
+// the six moments with the scatter weights, component WI = the weight bound): true if some a <= b <= c <= d passes on all
+// four arcs.  Contains workgroup barriers; every thread returns the same value.
+template <int NT, int ST, int WI>
+__device__ __forceinline__ bool fq_feasible(const double* sP, double mse_limit, int W, int H, uint32_t* s_okf, uint32_t* s_okw,
+                                            int* s_feasible) {
+  const int tid = threadIdx.x;
+  // allowance for the rounding of the evaluation this test stands in for (see above)
+  const double thr = mse_limit * 1.02 + 0.1 + 0x1p-50 * (sP[FQ_XG * ST + 2] + sP[FQ_XG * ST + 4]) +
+                     1e-7 * 0.25 * ((double)W * (double)W + (double)H * (double)H);
+#pragma unroll 1
+  for (int pbase = 0; pbase < FQ_XG * FQ_XG; pbase += NT) {
+    const int pi = pbase + tid, a = pi / FQ_XG, b = pi & (FQ_XG - 1);
+    bool okf = true, okw = true;
+    if (b >= a) {
+      if (b >= a + 2) okf = fq_arc_possible(sP + (a + 1) * ST, sP + b * ST, nullptr, sP[(b + 1) * ST + WI] - sP[a * ST + WI], thr);
+      __builtin_amdgcn_sched_barrier(0);   // (one evaluation's prefix loads at a time)
+      okw = fq_arc_possible(sP + (b + 1) * ST, sP + FQ_XG * ST, sP + a * ST,
+                            (sP[FQ_XG * ST + WI] - sP[b * ST + WI]) + sP[(a + 1) * ST + WI], thr);
+    }
+    // lanes 0..31 of a wave share a, lanes 32..63 the next one (FQ_XG == 32)
+    const unsigned long long mf = __ballot(okf && b >= a), mw = __ballot(okw && b >= a);
+    if ((tid & 31) == 0) {
+      s_okf[a] = (uint32_t)(mf >> (tid & 32));
+      s_okw[a] = (uint32_t)(mw >> (tid & 32));
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    // cut groups a <= b <= c <= d: forward arcs a->b, b->c, c->d and the wrap-around arc d->a must all be possible
+    const uint32_t rowf = tid < FQ_XG ? s_okf[tid] : 0u, roww = tid < FQ_XG ? s_okw[tid] : 0u;
+    uint32_t r2 = 0, r3 = 0;
+#pragma unroll 8
+    for (int b = 0; b < FQ_XG; b++) {
+      const uint32_t rb = (uint32_t)__builtin_amdgcn_readlane((int)rowf, b);
+      r2 |= ((rowf >> b) & 1u) ? rb : 0u;
+    }
+#pragma unroll 8
+    for (int c = 0; c < FQ_XG; c++) {
+      const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)rowf, c);
+      r3 |= ((r2 >> c) & 1u) ? rc : 0u;
+    }
+    const unsigned long long any = __ballot((r3 & roww) != 0u);
+    if (tid == 0) *s_feasible = any != 0ull;
+  }
+  __syncthreads();
+  return *s_feasible != 0;
+}
+// The same test BEFORE the sort, on angular sectors instead of groups of sorted points: a sector is an interval of the
+// slope key, so its points are consecutive in the sorted order whatever that order turns out to be.  Duplicates are
+// still present here (a half-pixel location can occur twice in a cluster, and only when both coordinates are odd: the
+// (1,1) point of one pixel and the (-1,1) point of its right neighbour); both copies carry the same weight and fall
+// into the same sector, so entering every odd-odd point with HALF its weight keeps the scatter of any union of
+// sectors below that of its duplicate-free points, line by line; the weight bound takes every point in full.
+// 32 sectors, eight per quadrant band of the slope key, cut at multiples of 11.25 degrees.
+__device__ __forceinline__ int fq_sector(float slope) {
+  const int qi = (slope >= 0.0f ? 1 : 0) + (slope >= 65536.0f ? 1 : 0) + (slope >= 131072.0f ? 1 : 0);
+  const float r = slope - (float)(qi - 1) * 65536.0f;   // monotone in slope inside a band
+  const int sub = (r >= 0.19891237f ? 1 : 0) + (r >= 0.41421357f ? 1 : 0) + (r >= 0.66817864f ? 1 : 0) + (r >= 1.0f ? 1 : 0) +
+                  (r >= 1.4966058f ? 1 : 0) + (r >= 2.4142137f ? 1 : 0) + (r >= 5.0273395f ? 1 : 0);
+  return qi * 8 + sub;
 }
 
 // Sort keys are stored so that their order as IEEE doubles equals the wanted unsigned order: a
@@ -573,8 +643,12 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     t_prev_ = now_;                                                                    \
   }
   unsigned long long t_prev_ = prof ? __builtin_readcyclecounter() : 0ull;
+  // points of the clusters that reach the pre-sort test (0), that it rejects (1), that the test after the first walk
+  // rejects (2): prof[40 + 4 * class + k] (the launch passes prof + 8 * class)
+#define FQ_COUNT(k, n) if (prof && tid == 0) atomicAdd(&prof[40 - 4 * ((NT == 64) ? 0 : (NT == 128) ? 1 : (NT == 256) ? 2 : (NT == 512) ? 3 : 4) + (k)], (unsigned long long)(n));
 #else
 #define FQ_TICK(slot)
+#define FQ_COUNT(k, n)
   (void)prof;
 #endif
   // tools-only builds (-DAMDAT_FQ_STOP=n) drop every cluster after phase n, to count the instructions of the phases
@@ -615,13 +689,22 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     // ---- bbox and exact gradient dot -----------------------------------------------------------
     int xmin = 1 << 30, xmax = -1, ymin = 1 << 30, ymax = -1;
     long long sxg = 0, sgx = 0, sgy = 0;
-    for (int i = tid; i < sz; i += NT) {
-      const uint32_t p = pts[i];
-      const int x = (int)(p >> 18), y = (int)((p >> 4) & 0x3FFF);
-      const int gx = ((int)((p >> 2) & 3) - 1) * 255, gy = ((int)(p & 3) - 1) * 255;
-      xmin = min(xmin, x); xmax = max(xmax, x); ymin = min(ymin, y); ymax = max(ymax, y);
-      sxg += (long long)x * gx + (long long)y * gy;
-      sgx += gx; sgy += gy;
+    // (four independent loads per trip: one load per trip left the loop waiting a full memory latency per 64 points.
+    // A lane without a point in some slot repeats its first point with a zero gradient, which changes neither the box
+    // nor the sums.)
+    for (int i = tid; i < sz; i += 4 * NT) {
+      uint32_t pq[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) pq[u] = pts[min(i + u * NT, sz - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t p = (i + u * NT < sz) ? pq[u] : ((pq[0] & ~15u) | 5u);
+        const int x = (int)(p >> 18), y = (int)((p >> 4) & 0x3FFF);
+        const int gx = ((int)((p >> 2) & 3) - 1) * 255, gy = ((int)(p & 3) - 1) * 255;
+        xmin = min(xmin, x); xmax = max(xmax, x); ymin = min(ymin, y); ymax = max(ymax, y);
+        sxg += (long long)x * gx + (long long)y * gy;
+        sgx += gx; sgy += gy;
+      }
     }
     // seven reductions, one barrier: every wave reduces on the DPP network and parks its results
     xmin = wave_min_i(xmin); xmax = wave_max_i(xmax); ymin = wave_min_i(ymin); ymax = wave_max_i(ymax);
@@ -658,8 +741,15 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     // only the largest class (FQ_NT_BIG threads) can meet clusters beyond its LDS key array: every smaller instance
     // addresses LDS unconditionally (no generic-address loads)
     const bool in_lds = NT < FQ_NT_BIG || sz <= sort_cap;
-    for (int i = tid; i < sz; i += NT) {
-      const uint32_t p = pts[i];
+    for (int i4 = tid; i4 < sz; i4 += 4 * NT) {
+      uint32_t pq[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) pq[u] = pts[min(i4 + u * NT, sz - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+      const int i = i4 + u * NT;
+      if (i >= sz) break;
+      const uint32_t p = pq[u];
       const int x = (int)(p >> 18), y = (int)((p >> 4) & 0x3FFF);
       float dx = (float)x - cx, dy = (float)y - cy;
       float quadrant;
@@ -671,6 +761,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       const unsigned long long key = key_enc(((unsigned long long)float_sortable(slope) << 32) | ((unsigned long long)y << 18) |
                                              ((unsigned long long)x << 4) | (unsigned long long)(p & 15u));
       if (in_lds) skeys[FQ_KP(i)] = key; else gkeys[i] = key;
+      }
     }
     int lpow = 0;
     while ((1 << lpow) < sz) lpow++;
@@ -679,7 +770,70 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     const bool padded = in_lds && (1 << lpow) <= sort_cap;
     if (padded)
       for (int i = sz + tid; i < (1 << lpow); i += NT) skeys[FQ_KP(i)] = AT_KEY_PAD;
+#ifndef AMDAT_FQ_NO_PRESORT_EXIT
+    constexpr bool kPresort = SPLIT && NT >= FQ_PRESORT_MIN_NT;
+    if constexpr (kPresort)
+      for (int t = tid; t < (FQ_XG + 1) * 7; t += NT) chunk[t] = 0.0;   // sector sums (pair-table region: free until the maxima exist)
+#endif
     __syncthreads();
+#ifndef AMDAT_FQ_NO_PRESORT_EXIT
+    if constexpr (kPresort) {
+      // ---- sound early exit before the sort (see fq_sector above) -------------------------------------------------
+      // Every lane walks a run of consecutive keys of the (still unsorted) list -- points arrive tile by tile, so a run
+      // mostly stays inside one sector -- and keeps the sector's seven sums in registers; they go to the sector's LDS
+      // entry (seven f64 atomics) only when the sector changes.
+      double* const sB = chunk;   // [(FQ_XG + 1)][7]: entry s + 1 = sums of sector s, then prefix sums
+      {
+        int E = (sz + NT - 1) / NT;
+        if (!in_lds && E >= 8) E |= 1;
+        if (in_lds && (E & 31) == 31) E++;
+        const int i0 = tid * E, i1 = min(sz, i0 + E);
+        double a[7];
+        int cur = -1;
+        auto flush = [&]() {
+#pragma unroll
+          for (int j = 0; j < 7; j++) __hip_atomic_fetch_add(&sB[(cur + 1) * 7 + j], a[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        for (int i = i0; i < i1; i++) {
+          const unsigned long long key = key_dec(in_lds ? skeys[FQ_KP(i)] : gkeys[i]);
+          const uint32_t fs = (uint32_t)(key >> 32);
+          const float slope = __uint_as_float((fs & 0x80000000u) ? (fs & 0x7FFFFFFFu) : ~fs);   // inverse of float_sortable
+          const int sec = fq_sector(slope);
+          const uint32_t px = (uint32_t)((key >> 4) & 0x3FFF), py = (uint32_t)((key >> 18) & 0x3FFF);
+          const double x = (int)(px + 1) * .5, y = (int)(py + 1) * .5;
+          const int ix = (int)((px + 1) >> 1), iy = (int)((py + 1) >> 1);
+          uint32_t G = 0;
+          if (((unsigned)(ix - 1) < (unsigned)(W - 2)) & ((unsigned)(iy - 1) < (unsigned)(H - 2))) {
+            const uint32_t o = (uint32_t)iy * (uint32_t)gpitch + (uint32_t)ix;
+            const int g_r = ggray[o + 1], g_l = ggray[o - 1], g_d = ggray[o + (uint32_t)gpitch], g_u = ggray[o - (uint32_t)gpitch];
+            const int grad_x = g_r - g_l, grad_y = g_d - g_u;
+            G = (uint32_t)(grad_x * grad_x + grad_y * grad_y);
+          }
+          const double Wt = sqrt_u18(G) + 1;
+          const double wl = (px & py & 1u) ? 0.5 * Wt : Wt;
+          if (sec != cur) {
+            if (cur >= 0) flush();
+            cur = sec;
+#pragma unroll
+            for (int j = 0; j < 7; j++) a[j] = 0.0;
+          }
+          const double wx = wl * x, wy = wl * y;
+          a[0] += wx; a[1] += wy; a[2] += wx * x; a[3] += wx * y; a[4] += wy * y; a[5] += wl; a[6] += Wt;
+        }
+        if (cur >= 0) flush();
+      }
+      __syncthreads();
+      if (tid < 7) {
+        double run = 0.0;
+        for (int sct = 1; sct <= FQ_XG; sct++) { run += sB[sct * 7 + tid]; sB[sct * 7 + tid] = run; }
+      }
+      __syncthreads();
+      const bool feas_pre = fq_feasible<NT, 7, 6>(sB, P.max_line_fit_mse, W, H, s_okf, s_okw, &s_feasible);
+      FQ_TICK(3)
+      FQ_COUNT(0, sz)
+      if (!feas_pre) { FQ_COUNT(1, sz) continue; }
+    }
+#endif
     if (padded) bitonic_sort_block2<NT, true, true>(skeys, sz, lpow);
     else if (in_lds) bitonic_sort_block2<NT, false, true>(skeys, sz, lpow);
     else bitonic_sort_block2<NT, false, false>(gkeys, sz, lpow);
@@ -806,47 +960,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
             for (int j = 0; j < 6; j++) sP[(g + 1) * 6 + j] = (off[j].hi + acc[j].hi) + (off[j].lo + acc[j].lo);
           }
           __syncthreads();
-          // rounding allowance of the reference evaluation (difference of rounded prefixes, float square root) on top of
-          // the threshold: see fq_arc_possible
-          const double thr = P.max_line_fit_mse * 1.02 + 0.1 + 0x1p-50 * (sP[FQ_XG * 6 + 2] + sP[FQ_XG * 6 + 4]) +
-                             1e-7 * 0.25 * ((double)W * (double)W + (double)H * (double)H);
-#pragma unroll 1
-          for (int pbase = 0; pbase < FQ_XG * FQ_XG; pbase += NT) {
-            const int pi = pbase + tid, a = pi / FQ_XG, b = pi & (FQ_XG - 1);
-            bool okf = true, okw = true;
-            if (b >= a) {
-              if (b >= a + 2) okf = fq_arc_possible(sP + (a + 1) * 6, sP + b * 6, nullptr, sP[(b + 1) * 6 + 5] - sP[a * 6 + 5], thr);
-              __builtin_amdgcn_sched_barrier(0);   // (one evaluation's prefix loads at a time: both at once spill)
-              okw = fq_arc_possible(sP + (b + 1) * 6, sP + FQ_XG * 6, sP + a * 6,
-                                    (sP[FQ_XG * 6 + 5] - sP[b * 6 + 5]) + sP[(a + 1) * 6 + 5], thr);
-            }
-            // lanes 0..31 of a wave share a, lanes 32..63 the next one (FQ_XG == 32)
-            const unsigned long long mf = __ballot(okf && b >= a), mw = __ballot(okw && b >= a);
-            if ((tid & 31) == 0) {
-              s_okf[a] = (uint32_t)(mf >> (tid & 32));
-              s_okw[a] = (uint32_t)(mw >> (tid & 32));
-            }
-          }
-          __syncthreads();
-          if (tid < 64) {
-            // cut groups a <= b <= c <= d: forward arcs a->b, b->c, c->d and the wrap-around arc d->a must all be possible
-            const uint32_t rowf = tid < FQ_XG ? s_okf[tid] : 0u, roww = tid < FQ_XG ? s_okw[tid] : 0u;
-            uint32_t r2 = 0, r3 = 0;
-#pragma unroll 8
-            for (int b = 0; b < FQ_XG; b++) {
-              const uint32_t rb = (uint32_t)__builtin_amdgcn_readlane((int)rowf, b);
-              r2 |= ((rowf >> b) & 1u) ? rb : 0u;
-            }
-#pragma unroll 8
-            for (int c = 0; c < FQ_XG; c++) {
-              const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)rowf, c);
-              r3 |= ((r2 >> c) & 1u) ? rc : 0u;
-            }
-            const unsigned long long any = __ballot((r3 & roww) != 0u);
-            if (tid == 0) s_feasible = any != 0ull;
-          }
-          __syncthreads();
-          if (!s_feasible) continue;
+          if (!fq_feasible<NT, 6, 5>(sP, P.max_line_fit_mse, W, H, s_okf, s_okw, &s_feasible)) { FQ_COUNT(2, sz) continue; }
         }
 #endif
       } else {
@@ -1372,4 +1486,197 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     FQ_TICK(7)
   }
 #undef FQ_TICK
+#undef FQ_COUNT
+}
+
+// ---- k_fit_prefilter: the cheap exits of the quad fit for the clusters of the large classes, ahead of k_fit_quads ---------
+// Clusters above FQ_PREFILTER_LO points (the 256-, 512- and 1024-thread classes) need most of a CU's LDS for their sort
+// keys, run as one or two persistent workgroups per CU and, on frames with textured background, almost all end at "no
+// admissible corner choice" (config 2: every one of them).  This kernel takes exactly those work items and applies the
+// exits that need neither the sort nor the key array -- bounding box, border direction (the same statements as
+// k_fit_quads) and the sound sector test (fq_sector / fq_feasible above) -- at full occupancy: 256 threads and about
+// 10 KB of LDS per cluster.  The surviving items are appended to a second, compact work list per class, which is what the
+// persistent workgroups of these classes pop from (marking the rejected items in place left them popping tens of thousands
+// of dead items through one cursor word: 0.25 ms per class at the ~90 atomics per microsecond one word sustains).  Nothing
+// here decides anything k_fit_quads would decide differently: bounding box and border direction are its own tests, and the
+// sector test only fires when no corner choice can be admissible.  Items are taken in a fixed stride (largest class
+// first, so that neighbouring items are of similar size): a shared cursor would saturate here as well.
+#ifndef FQ_PF_NT
+#define FQ_PF_NT 64      // one wave per cluster: no workgroup barriers, and four times as many clusters in flight per CU as with
+                         // 256 threads (a cluster's chain of dependent loads, reductions and LDS round trips is what takes the time)
+#endif
+#define FQ_PF_CHUNK (8 * FQ_PF_NT)     // points staged in LDS per round (eight per thread)
+__global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
+                                                       const uint32_t* __restrict__ pts_all, const ClusterRec* __restrict__ clusters_all,
+                                                       const uint32_t* __restrict__ work, const uint32_t* __restrict__ work_n,
+                                                       uint32_t* __restrict__ work_out, uint32_t* __restrict__ work_n_out,
+                                                       FqWorkLayout L, int first_class, DetParams P) {
+  __shared__ __attribute__((aligned(16))) uint32_t spts[FQ_PF_CHUNK];
+  __shared__ double sB[(FQ_XG + 1) * 7];
+  __shared__ long long s_dot[FQ_PF_NT / 64][3];
+  __shared__ int s_box[FQ_PF_NT / 64][4];
+  __shared__ uint32_t s_okf[FQ_XG], s_okw[FQ_XG];
+  __shared__ int s_feasible;
+  const int tid = threadIdx.x;
+  const int W = P.W, H = P.H;
+  // items of the classes first_class .. FQ_NCLS - 1, largest class first
+  uint32_t cnt[FQ_NCLS], total = 0;
+#pragma unroll
+  for (int c = FQ_NCLS - 1; c >= 0; c--) {
+    cnt[c] = c >= first_class ? min(work_n[c], L.cap[c]) : 0u;
+    total += cnt[c];
+  }
+  for (uint32_t it0 = blockIdx.x; it0 < total; it0 += gridDim.x) {
+    __syncthreads();   // the previous cluster's LDS use is finished in every wave
+    uint32_t it = it0, widx = 0;
+    int cls = 0;
+    {
+      bool found = false;
+#pragma unroll
+      for (int c = FQ_NCLS - 1; c >= 0; c--) {
+        if (!found) {
+          if (it < cnt[c]) { widx = L.off[c] + it; cls = c; found = true; }
+          else it -= cnt[c];
+        }
+      }
+    }
+    const uint32_t wi = (uint32_t)__builtin_amdgcn_readfirstlane((int)work[widx]);
+    const int frame = (int)(wi >> 16);
+    const FrameDesc fd = frames[frame];
+    const uint8_t* gray = (P.decimate > 1) ? gray_all + (size_t)frame * P.H * P.WS : fd.img;
+    const int gpitch = (P.decimate > 1) ? P.WS : (int)fd.pitch;
+    const __attribute__((address_space(1))) uint8_t* const ggray = (const __attribute__((address_space(1))) uint8_t*)gray;
+    const ClusterRec cl = clusters_all[(size_t)frame * P.ccap + (wi & 0xFFFFu)];
+    const int sz = (int)cl.count;
+    const uint32_t* pts = pts_all + (size_t)frame * P.pcap + cl.start;
+
+    // bounding box and exact gradient dot: the statements of k_fit_quads
+    int xmin = 1 << 30, xmax = -1, ymin = 1 << 30, ymax = -1;
+    long long sxg = 0, sgx = 0, sgy = 0;
+    for (int i = tid; i < sz; i += 8 * FQ_PF_NT) {   // (eight independent loads per trip)
+      uint32_t pq[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) pq[u] = pts[min(i + u * FQ_PF_NT, sz - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t p = (i + u * FQ_PF_NT < sz) ? pq[u] : ((pq[0] & ~15u) | 5u);
+        const int x = (int)(p >> 18), y = (int)((p >> 4) & 0x3FFF);
+        const int gx = ((int)((p >> 2) & 3) - 1) * 255, gy = ((int)(p & 3) - 1) * 255;
+        xmin = min(xmin, x); xmax = max(xmax, x); ymin = min(ymin, y); ymax = max(ymax, y);
+        sxg += (long long)x * gx + (long long)y * gy;
+        sgx += gx; sgy += gy;
+      }
+    }
+    xmin = wave_min_i(xmin); xmax = wave_max_i(xmax); ymin = wave_min_i(ymin); ymax = wave_max_i(ymax);
+    sxg = wave_sum_ll(sxg); sgx = wave_sum_ll(sgx); sgy = wave_sum_ll(sgy);
+    {
+      const int wv = tid >> 6;
+      if (lane_id() == 0) {
+        s_box[wv][0] = xmin; s_box[wv][1] = xmax; s_box[wv][2] = ymin; s_box[wv][3] = ymax;
+        s_dot[wv][0] = sxg; s_dot[wv][1] = sgx; s_dot[wv][2] = sgy;
+      }
+      for (int t = tid; t < (FQ_XG + 1) * 7; t += FQ_PF_NT) sB[t] = 0.0;
+      __syncthreads();
+      xmin = s_box[0][0]; xmax = s_box[0][1]; ymin = s_box[0][2]; ymax = s_box[0][3];
+      sxg = s_dot[0][0]; sgx = s_dot[0][1]; sgy = s_dot[0][2];
+#pragma unroll
+      for (int w = 1; w < FQ_PF_NT / 64; w++) {
+        xmin = min(xmin, s_box[w][0]); xmax = max(xmax, s_box[w][1]); ymin = min(ymin, s_box[w][2]); ymax = max(ymax, s_box[w][3]);
+        sxg += s_dot[w][0]; sgx += s_dot[w][1]; sgy += s_dot[w][2];
+      }
+    }
+    bool reject = (xmax - xmin) * (ymax - ymin) < P.min_tag_width;
+    const double cxd = (xmin + xmax) * 0.5 + 0.05118, cyd = (ymin + ymax) * 0.5 + -0.028581;
+    const double dot = (double)sxg - cxd * (double)sgx - cyd * (double)sgy;
+    const int q_reversed = dot < 0;
+    if (!P.reversed_border && q_reversed) reject = true;
+    if (!P.normal_border && !q_reversed) reject = true;
+#if defined(AMDAT_PF_EXP) && AMDAT_PF_EXP == 1
+    if (false) {
+#else
+    if (!reject && P.split_moments) {   // (the sector sums assume the fast path's coordinate range; larger images skip the test)
+#endif
+      const float cx = (float)cxd, cy = (float)cyd;
+      double a[7];
+      int cur = -1;
+      auto flush = [&]() {
+#if defined(AMDAT_PF_EXP) && AMDAT_PF_EXP == 2
+        if (a[0] == 1.2345) sB[0] = a[1] + a[2] + a[3] + a[4] + a[5] + a[6];
+#else
+#pragma unroll
+        for (int j = 0; j < 7; j++) __hip_atomic_fetch_add(&sB[(cur + 1) * 7 + j], a[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+      };
+      for (int base = 0; base < sz; base += FQ_PF_CHUNK) {
+        if (base) __syncthreads();   // the previous round's points have been consumed
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int i = base + k * FQ_PF_NT + tid;
+          if (i < sz) spts[k * FQ_PF_NT + tid] = pts[i];
+        }
+        __syncthreads();
+        uint32_t pp[8];
+        {
+          const uint4 v0 = *reinterpret_cast<const uint4*>(spts + tid * 8), v1 = *reinterpret_cast<const uint4*>(spts + tid * 8 + 4);
+          pp[0] = v0.x; pp[1] = v0.y; pp[2] = v0.z; pp[3] = v0.w; pp[4] = v1.x; pp[5] = v1.y; pp[6] = v1.z; pp[7] = v1.w;
+        }
+        // squared gradients of the eight points first (32 independent byte gathers in flight)
+        uint32_t GG[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const uint32_t p = pp[e];
+          const uint32_t px = p >> 18, py = (p >> 4) & 0x3FFFu;
+          const int ix = (int)((px + 1) >> 1), iy = (int)((py + 1) >> 1);
+          GG[e] = 0;
+#if !(defined(AMDAT_PF_EXP) && AMDAT_PF_EXP == 3)
+          if ((base + tid * 8 + e < sz) & ((unsigned)(ix - 1) < (unsigned)(W - 2)) & ((unsigned)(iy - 1) < (unsigned)(H - 2))) {
+            const uint32_t o = (uint32_t)iy * (uint32_t)gpitch + (uint32_t)ix;
+            const int g_r = ggray[o + 1], g_l = ggray[o - 1], g_d = ggray[o + (uint32_t)gpitch], g_u = ggray[o - (uint32_t)gpitch];
+            const int grad_x = g_r - g_l, grad_y = g_d - g_u;
+            GG[e] = (uint32_t)(grad_x * grad_x + grad_y * grad_y);
+          }
+#endif
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          if (base + tid * 8 + e >= sz) break;
+          const uint32_t p = pp[e];
+          const int xi = (int)(p >> 18), yi = (int)((p >> 4) & 0x3FFF);
+          // slope key of k_fit_quads (same float statements)
+          float dx = (float)xi - cx, dy = (float)yi - cy;
+          float quadrant;
+          if (dy > 0) quadrant = (dx > 0) ? 65536.0f : 131072.0f;
+          else quadrant = (dx > 0) ? 0.0f : -65536.0f;
+          if (dy < 0) { dy = -dy; dx = -dx; }
+          if (dx < 0) { float tmp = dx; dx = dy; dy = -tmp; }
+          const float slope = quadrant + __fdiv_rn(dy, dx);
+          const int sec = fq_sector(slope);
+          const uint32_t px = (uint32_t)xi, py = (uint32_t)yi;
+          const double x = (int)(px + 1) * .5, y = (int)(py + 1) * .5;
+          const double Wt = sqrt_u18(GG[e]) + 1;
+          const double wl = (px & py & 1u) ? 0.5 * Wt : Wt;
+          if (sec != cur) {
+            if (cur >= 0) flush();
+            cur = sec;
+#pragma unroll
+            for (int j = 0; j < 7; j++) a[j] = 0.0;
+          }
+          const double wx = wl * x, wy = wl * y;
+          a[0] += wx; a[1] += wy; a[2] += wx * x; a[3] += wx * y; a[4] += wy * y; a[5] += wl; a[6] += Wt;
+        }
+      }
+      if (cur >= 0) flush();
+      __syncthreads();
+      if (tid < 7) {
+        double run = 0.0;
+        for (int sct = 1; sct <= FQ_XG; sct++) { run += sB[sct * 7 + tid]; sB[sct * 7 + tid] = run; }
+      }
+      __syncthreads();
+      reject = !fq_feasible<FQ_PF_NT, 7, 6>(sB, P.max_line_fit_mse, W, H, s_okf, s_okw, &s_feasible);
+    }
+    if (!reject && tid == 0) {
+      const uint32_t pos = atomicAdd(&work_n_out[cls], 1u);   // (pos < cap: the list holds at most the items of the input list)
+      work_out[L.off[cls] + pos] = wi;
+    }
+  }
 }

@@ -553,6 +553,79 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
     keys[i] = ((uint64_t)float_sortable(slope) << 32) | ((uint64_t)y << 18) | ((uint64_t)x << 4) | (pts[i] & 15u);
   }
   qsort(keys, sz, sizeof(uint64_t), u64_cmp);
+  double diag_sector[3] = {0, 0, 0};
+  if (ato_diag_cap > 0) {
+    /* angular-sector variant of the relaxed feasibility test, computable BEFORE the sort: sectors are intervals of the
+     * slope key (contiguous in sorted order); duplicates are not removed, so a point on an odd-odd half-pixel location
+     * (the only ones that can occur twice) enters the scatter with half its weight and the weight bound in full */
+    for (int v = 0; v < 3; v++) {
+      const int SPQ = 8, m = 4 * SPQ;   /* sectors per quadrant */
+      const int sub = v == 0 ? 1 : 4;
+      float thrs[64];
+      static const float QB[4] = {-65536.0f, 0.0f, 65536.0f, 131072.0f};
+      for (int q = 0; q < 4; q++)
+        for (int k = 0; k < SPQ; k++) thrs[q * SPQ + k] = QB[q] + (float)tan(k * (M_PI / 2) / SPQ);
+      double (*B)[7] = calloc((size_t)m + 1, sizeof(double) * 7);   /* bins, then prefix */
+      for (int i = 0; i < sz; i++) {
+        uint32_t fs = (uint32_t)(keys[i] >> 32);
+        uint32_t fb = (fs & 0x80000000u) ? (fs & 0x7FFFFFFFu) : ~fs;
+        float slope; memcpy(&slope, &fb, 4);
+        int sec = 0;
+        for (int j = 1; j < m; j++) if (slope >= thrs[j]) sec = j;
+        int px = (int)((keys[i] >> 4) & 0x3FFF), py = (int)((keys[i] >> 18) & 0x3FFF);
+        double x = px * .5 + 0.5, y = py * .5 + 0.5;
+        int ix = (int)x, iy = (int)y;
+        double Wt = 1;
+        if (ix > 0 && ix + 1 < w && iy > 0 && iy + 1 < h) {
+          int grad_x = gray[iy * w + ix + 1] - gray[iy * w + ix - 1];
+          int grad_y = gray[(iy + 1) * w + ix] - gray[(iy - 1) * w + ix];
+          Wt = sqrt((double)(grad_x * grad_x + grad_y * grad_y)) + 1;
+        }
+        double wl = ((px & 1) && (py & 1)) ? 0.5 * Wt : Wt;
+        double* b = B[sec + 1];
+        if (i % sub == 0) { b[0] += wl * x; b[1] += wl * y; b[2] += wl * x * x; b[3] += wl * x * y; b[4] += wl * y * y; b[5] += wl; }
+        b[6] += Wt;
+      }
+      for (int j = 1; j <= m; j++) for (int t = 0; t < 7; t++) B[j][t] += B[j - 1][t];
+      const double T = 10.5;
+      unsigned char* ok = calloc((size_t)m * m, 1);
+      unsigned char* okw = calloc((size_t)m * m, 1);
+      for (int a = 0; a < m; a++)
+        for (int b = a; b < m; b++) {
+          int o = 1, ow = 1;
+          if (b > a + 1) {
+            double M[6]; for (int t = 0; t < 6; t++) M[t] = B[b][t] - B[a + 1][t];
+            double Wc = v == 2 ? B[m][6] : B[b + 1][6] - B[a][6];
+            if (M[5] > 0.25) {
+              double Sxx = M[2] - M[0] * M[0] / M[5], Sxy = M[3] - M[0] * M[1] / M[5], Syy = M[4] - M[1] * M[1] / M[5];
+              double q = 0.5 * (Sxx + Syy - sqrt((Sxx - Syy) * (Sxx - Syy) + 4 * Sxy * Sxy));
+              o = !(q > T * Wc);
+            }
+          }
+          {
+            double M[6]; for (int t = 0; t < 6; t++) M[t] = (B[m][t] - B[b + 1][t]) + B[a][t];
+            double Wc = v == 2 ? B[m][6] : (B[m][6] - B[b][6]) + B[a + 1][6];
+            if (M[5] > 0.25) {
+              double Sxx = M[2] - M[0] * M[0] / M[5], Sxy = M[3] - M[0] * M[1] / M[5], Syy = M[4] - M[1] * M[1] / M[5];
+              double q = 0.5 * (Sxx + Syy - sqrt((Sxx - Syy) * (Sxx - Syy) + 4 * Sxy * Sxy));
+              ow = !(q > T * Wc);
+            }
+          }
+          ok[a * m + b] = (unsigned char)o; okw[b * m + a] = (unsigned char)ow;
+        }
+      int feasible = 0;
+      unsigned char* r1 = malloc(m), *r2 = malloc(m), *r3 = malloc(m);
+      for (int a = 0; a < m && !feasible; a++) {
+        memset(r1, 0, m); memset(r2, 0, m); memset(r3, 0, m);
+        for (int b = a; b < m; b++) if (ok[a * m + b]) r1[b] = 1;
+        for (int b = a; b < m; b++) if (r1[b]) for (int c = b; c < m; c++) if (ok[b * m + c]) r2[c] = 1;
+        for (int c = a; c < m; c++) if (r2[c]) for (int d = c; d < m; d++) if (ok[c * m + d]) r3[d] = 1;
+        for (int d = a; d < m; d++) if (r3[d] && okw[d * m + a]) { feasible = 1; break; }
+      }
+      free(r1); free(r2); free(r3); free(ok); free(okw); free(B);
+      diag_sector[v] = feasible ? 0.0 : 2.0;
+    }
+  }
   /* remove duplicate points (same half-pixel location, a by-product of the segmentation); the
    * gradient-direction test above has already seen all of them (upstream fit_quad) */
   {
@@ -646,6 +719,9 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
       free(r1); free(r2); free(r3); free(ok); free(okw); free(P);
       g_diag_ratio[k] = feasible ? 0.0 : 2.0;
     }
+    g_diag_ratio[0] = diag_sector[0];   /* slots 0, 1: the pre-sort sector test with 32 / 64 sectors */
+    g_diag_ratio[1] = diag_sector[1];
+    g_diag_ratio[2] = diag_sector[2];
     g_diag_have = 1;
   }
 

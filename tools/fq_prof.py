@@ -17,9 +17,12 @@ det.set_profiling(2)
 det.detect_batch_ex(t)
 print({k: round(v, 3) for k, v in det.stage_ms().items()})
 pa = det.debug(0, 8).view(np.uint64)[:40].astype(np.float64).reshape(5, 8)
-names = ["pop+load", "bbox+dot", "keys+sort", "-", "dedup+terms+prefix", "errs+smooth+maxima", "select", "pairs+combos+final"]
+names = ["pop+load", "bbox+dot", "keys+sort", "presort-test", "dedup+terms+prefix", "errs+smooth+maxima", "select", "pairs+combos+final"]
 tot = pa.sum()
-for c in range(4):
+for c in range(5):
     p = pa[c]
     print("class %d: %5.1f%% of all fit cycles: " % (c, 100 * p.sum() / max(tot, 1)) + ", ".join("%s %.0f%%" % (n, 100 * v / max(p.sum(), 1)) for n, v in zip(names, p) if n != "-"))
+cnt = det.debug(0, 8).view(np.uint64)[40:60].astype(np.float64).reshape(5, 4)
+for c in range(5):
+    print("class %d: points reaching the pre-sort test %.0f, rejected there %.0f, rejected after walk 1 %.0f (per frame)" % (c, cnt[c][0] / B, cnt[c][1] / B, cnt[c][2] / B))
 det.close()
