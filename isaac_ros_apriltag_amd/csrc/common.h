@@ -29,6 +29,8 @@ struct FrameCounters {
   uint32_t flags;         // AMDAT_FLAG_*
   uint32_t nout;          // detections after reconcile
   uint32_t nroots;        // tile-local component roots (CC root list)
+  uint32_t ncand;         // quad candidates (four fitted lines) awaiting k_quad_finish
+  uint32_t pad0;
 };
 
 struct ClusterRec {
@@ -42,6 +44,15 @@ struct QuadRec {
   int32_t reversed_border;
   uint32_t pad;
   uint64_t key;
+};
+
+// A corner choice that passed the line-fit tests: the four lines {Ex, Ey, nx, ny} of the segments q0->q1, q1->q2, q2->q3,
+// q3->q0, handed from k_fit_quads to k_quad_finish.
+struct FitCand {
+  double line[4][4];
+  uint64_t key;
+  int32_t reversed_border;
+  uint32_t pad;
 };
 
 // Same layout as amdAprilTagsDetectionEx_t.

@@ -143,6 +143,7 @@ struct amdAprilTagsDetector_st {
   DetRec* d_dets = nullptr;
   DetRec* d_out = nullptr;
   uint16_t* d_order = nullptr;
+  FitCand* d_cands = nullptr;        // quad candidates of k_fit_quads (four lines each), consumed by k_quad_finish
   FrameCounters* d_counters = nullptr;
   FrameDesc* d_frames = nullptr;
   uint64_t* d_codes[AT_MAX_FAMILIES] = {nullptr, nullptr, nullptr, nullptr};
@@ -265,7 +266,7 @@ static void free_all(amdAprilTagsDetector_st* D) {
   hipFree(D->d_work); hipFree(D->d_work2); hipFree(D->d_workctl); hipFree(D->d_keys_scr); hipFree(D->d_quads);
   for (auto& c : D->cls) { hipFree(c.d_lf); hipFree(c.d_errs); }
   hipFree(D->d_fqprof);
-  hipFree(D->d_dets); hipFree(D->d_out); hipFree(D->d_order); hipFree(D->d_counters); hipFree(D->d_frames);
+  hipFree(D->d_cands); hipFree(D->d_dets); hipFree(D->d_out); hipFree(D->d_order); hipFree(D->d_counters); hipFree(D->d_frames);
   for (int i = 0; i < AT_MAX_FAMILIES; i++) hipFree(D->d_codes[i]);
   if (D->h_frames) hipHostFree(D->h_frames);
   if (D->h_counters) hipHostFree(D->h_counters);
@@ -435,6 +436,7 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
     alloc((void**)&D->d_keys_scr, (size_t)c.grid * c.slot_cap * 8);
   }
   alloc((void**)&D->d_quads, B * (size_t)P.qcap * sizeof(QuadRec));
+  alloc((void**)&D->d_cands, B * (size_t)P.qcap * sizeof(FitCand));
   alloc((void**)&D->d_dets, B * (size_t)P.dcap * sizeof(DetRec));
   alloc((void**)&D->d_out, B * (size_t)P.dcap * sizeof(DetRec));
   alloc((void**)&D->d_order, B * (size_t)P.dcap * 2);
@@ -645,7 +647,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
 #define FQ_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, (filtered ? work2 : D->d_work) + D->work_layout.off[c],                 \
                 D->d_workctl + (filtered ? 16 : 0) + c,                                                                                \
                 D->work_layout.cap[c], D->d_workctl + 8 + c, cl.d_lf, (big ? D->d_keys_scr : nullptr), cl.d_errs,                        \
-                D->d_quads, D->d_counters, (D->fq_counters ? D->d_fqprof + 8 * c : nullptr), cl.sort_cap, cl.slot_cap, pop, P
+                D->d_cands, D->d_counters, (D->fq_counters ? D->d_fqprof + 8 * c : nullptr), cl.sort_cap, cl.slot_cap, pop, P
 #define FQ_LAUNCH(NTV)                                                                                          \
   if (P.split_moments) hipLaunchKernelGGL((k_fit_quads<NTV, true>), grid, dim3(NTV), lds, sc, FQ_ARGS);          \
   else hipLaunchKernelGGL((k_fit_quads<NTV, false>), grid, dim3(NTV), lds, sc, FQ_ARGS);
@@ -701,6 +703,8 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
       HIP_TRY(hipEventRecord(D->ev_join[a], aux[a]));
       HIP_TRY(hipStreamWaitEvent(s, D->ev_join[a], 0));
     }
+    // corners + area / angle checks of the candidates, one thread each
+    hipLaunchKernelGGL(k_quad_finish, dim3(16, n), dim3(256), 0, s, D->d_cands, D->d_quads, D->d_counters, P);
   }
   mark();
   {

@@ -590,18 +590,20 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
                                                    const uint32_t* __restrict__ work, const uint32_t* __restrict__ work_n, uint32_t work_cap,
                                                    uint32_t* __restrict__ work_cursor, double* __restrict__ lf_scratch,
                                                    unsigned long long* __restrict__ keys_scratch, double* __restrict__ errs_scratch,
-                                                   QuadRec* __restrict__ quads_all, FrameCounters* __restrict__ counters,
+                                                   FitCand* __restrict__ cands_all, FrameCounters* __restrict__ counters,
                                                    unsigned long long* __restrict__ prof, int sort_cap, int slot_cap,
                                                    int pop, DetParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fq_smem[];
   unsigned long long* skeys = reinterpret_cast<unsigned long long*>(fq_smem);
-  double* chunk = reinterpret_cast<double*>(fq_smem + (size_t)FQ_KP(sort_cap) * 8);   // (the key array is skewed)
-  // pair tables alias the chunk buffer (used after the cumulative sums are finished)
-  // six tables over the 45 index pairs a < b < 10 (triangular index FQ_PIDX)
-  double* s_ferr = chunk; double* s_fmse = chunk + 45; double* s_fnx = chunk + 90; double* s_fny = chunk + 135;
-  double* s_werr = chunk + 180; double* s_wmse = chunk + 225;
-  double* s_lines = chunk + 270;  // [4][4]
-  double* s_lmse = chunk + 286;   // [4]
+  double* chunk = reinterpret_cast<double*>(fq_smem + (size_t)FQ_KP(sort_cap) * 8);   // (the key array is skewed); prefixes of the early-exit tests
+  // Twelve tables over the 45 index pairs a < b < 10 (triangular index FQ_PIDX): error, mse and the four line parameters
+  // of the forward segment a -> b and of the wrap-around segment b -> a.  They live in the key array, which is dead once
+  // the maxima are selected (4320 bytes; the smallest class's key array holds 6336).
+  double* const s_tab = reinterpret_cast<double*>(fq_smem);
+  double* const s_ferr = s_tab; double* const s_fmse = s_tab + 45; double* const s_fex = s_tab + 90; double* const s_fey = s_tab + 135;
+  double* const s_fnx = s_tab + 180; double* const s_fny = s_tab + 225;
+  double* const s_werr = s_tab + 270; double* const s_wmse = s_tab + 315; double* const s_wex = s_tab + 360; double* const s_wey = s_tab + 405;
+  double* const s_wnx = s_tab + 450; double* const s_wny = s_tab + 495;
   constexpr int NW = NT / 64;
   __shared__ long long s_dot[NW][3];
   __shared__ int s_box[NW][4];
@@ -611,7 +613,6 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
   __shared__ int s_maxidx[16];
   __shared__ int s_nkept;
   __shared__ uint16_t s_combo[210];
-  __shared__ float s_corner[4][2];
   __shared__ U128 s_wtot[NW * 6];   // [wave][moment]: wave totals of the current chunk
   __shared__ U128 s_woff[NW * 6];   // [wave][moment]: offset every lane of the wave adds
   __shared__ int s_wcnt[NW];
@@ -1359,14 +1360,13 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       const int t = task < 45 ? task : task - 45;
       const int pr = g_pair_table.v[t], a = pr >> 4, b = pr & 15;   // a < b
       if (b < m) {
+        double e, ms, lp[4];
         if (task < 45) {
-          double e, ms, lp[4];
           fit_line_dev(lf, szd, s_maxidx[a], s_maxidx[b], lp, &e, &ms);
-          s_ferr[t] = e; s_fmse[t] = ms; s_fnx[t] = lp[2]; s_fny[t] = lp[3];
+          s_ferr[t] = e; s_fmse[t] = ms; s_fex[t] = lp[0]; s_fey[t] = lp[1]; s_fnx[t] = lp[2]; s_fny[t] = lp[3];
         } else {
-          double e, ms;
-          fit_line_dev(lf, szd, s_maxidx[b], s_maxidx[a], nullptr, &e, &ms);
-          s_werr[t] = e; s_wmse[t] = ms;
+          fit_line_dev(lf, szd, s_maxidx[b], s_maxidx[a], lp, &e, &ms);
+          s_werr[t] = e; s_wmse[t] = ms; s_wex[t] = lp[0]; s_wey[t] = lp[1]; s_wnx[t] = lp[2]; s_wny[t] = lp[3];
         }
       }
     }
@@ -1400,86 +1400,31 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
                                                                  (int)__ffsll((long long)__ballot(mykey == topkey && best_t == bt)) - 1, 64));
       const bool found = (bt != (1 << 30)) && (be != (double)HUGE_VALF) && (be / szd < P.max_line_fit_mse);
       if (found) {
+        // The four lines of the best choice are table entries (the same fits, bit for bit): segments q0->q1, q1->q2,
+        // q2->q3 forward, q3->q0 around the end.  Intersections, area and angle checks need a handful of lanes for a few
+        // hundred dependent double-precision instructions; they run in k_quad_finish, one thread per candidate, instead
+        // of here on 5 lanes of 64 (a third of the one-wave class's cycles went into this tail).
         const uint32_t cmb = s_combo[bt];
-        const int sh = (lane & 3) * 4, sh1 = ((lane + 1) & 3) * 4;
-        // four final line fits (lanes 0..3), then four intersections (lanes 0..3)
-        if (lane < 4) {
-          double ms;
-          fit_line_dev(lf, szd, s_maxidx[(cmb >> sh) & 15], s_maxidx[(cmb >> sh1) & 15], s_lines + lane * 4, nullptr, &ms);
-          s_lmse[lane] = ms;
-        }
-        __threadfence_block();
-        bool okq = true;
-        if (lane < 4) {
-          const int i = lane, j = (lane + 1) & 3;
-          okq = !(s_lmse[0] > P.max_line_fit_mse) && !(s_lmse[1] > P.max_line_fit_mse) &&
-                !(s_lmse[2] > P.max_line_fit_mse) && !(s_lmse[3] > P.max_line_fit_mse);
-          const double A00 = s_lines[i * 4 + 3], A01 = -s_lines[j * 4 + 3];
-          const double A10 = -s_lines[i * 4 + 2], A11 = s_lines[j * 4 + 2];
-          const double B0 = -s_lines[i * 4 + 0] + s_lines[j * 4 + 0];
-          const double B1 = -s_lines[i * 4 + 1] + s_lines[j * 4 + 1];
-          const double det = A00 * A11 - A10 * A01;
-          if (fabs(det) < 0.001) okq = false;
-          const double W00 = A11 / det, W01 = -A01 / det;
-          const double L0 = W00 * B0 + W01 * B1;
-          s_corner[i][0] = (float)(s_lines[i * 4 + 0] + L0 * A00);
-          s_corner[i][1] = (float)(s_lines[i * 4 + 1] + L0 * A10);
-        }
-        __threadfence_block();
-        const bool all_ok = __ballot(!okq) == 0ull;
-        if (all_ok) {   // uniform over the wave
-          // Area (two Heron triangles) and the four corner-angle / winding checks, spread over lanes instead of
-          // one lane doing eight square roots and six divisions in sequence: lane i < 4 owns corner i with the
-          // edges i -> i+1 -> i+2 (edge length and angle check), lane 4 the diagonal p0-p2; lanes 0 and 1 then
-          // take one triangle each.  Every expression is the one the serial form (and the CPU oracle) evaluates.
-          bool cok = true;
-          double len = 0;
-          if (lane < 5) {
-            const int i0 = lane & 3, i1 = (lane + 1) & 3, i2 = (lane + 2) & 3;
-            const double ax = s_corner[i0][0], ay = s_corner[i0][1];
-            if (lane < 4) {
-              const double bx = s_corner[i1][0], by = s_corner[i1][1], cx2 = s_corner[i2][0], cy2 = s_corner[i2][1];
-              const double dx1 = bx - ax, dy1 = by - ay, dx2 = cx2 - bx, dy2 = cy2 - by;
-              const double q1 = dx1 * dx1 + dy1 * dy1;
-              len = __dsqrt_rn(q1);
-              const double cos_dtheta = (dx1 * dx2 + dy1 * dy2) / __dsqrt_rn(q1 * (dx2 * dx2 + dy2 * dy2));
-              if ((cos_dtheta > P.cos_critical_rad || cos_dtheta < -P.cos_critical_rad) || dx1 * dy2 < dy1 * dx2) cok = false;
-            } else {
-              const double px2 = s_corner[2][0], py2 = s_corner[2][1];
-              len = __dsqrt_rn((ax - px2) * (ax - px2) + (ay - py2) * (ay - py2));
-            }
+        const int q0 = cmb & 15, q1 = (cmb >> 4) & 15, q2 = (cmb >> 8) & 15, q3 = (cmb >> 12) & 15;
+        uint32_t ci = 0;
+        if (lane == 0) ci = atomicAdd(&counters[frame].ncand, 1u);
+        ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)ci);
+        if (ci < P.qcap) {
+          FitCand* const cd = cands_all + (size_t)frame * P.qcap + ci;
+          if (lane < 4) {
+            const int pi = lane == 0 ? FQ_PIDX(q0, q1) : lane == 1 ? FQ_PIDX(q1, q2) : lane == 2 ? FQ_PIDX(q2, q3) : FQ_PIDX(q0, q3);
+            const bool wrap = lane == 3;
+            cd->line[lane][0] = wrap ? s_wex[pi] : s_fex[pi];
+            cd->line[lane][1] = wrap ? s_wey[pi] : s_fey[pi];
+            cd->line[lane][2] = wrap ? s_wnx[pi] : s_fnx[pi];
+            cd->line[lane][3] = wrap ? s_wny[pi] : s_fny[pi];
+          } else if (lane == 4) {
+            cd->key = cl.key;
+            cd->reversed_border = q_reversed;
+            cd->pad = 0;
           }
-          const double e0 = readlane_f64(len, 0), e1 = readlane_f64(len, 1), e2 = readlane_f64(len, 2), e3 = readlane_f64(len, 3);
-          const double ed = readlane_f64(len, 4);
-          // lane 0: triangle (0,1,2) with sides e0, e1, diagonal; lane 1: triangle (2,3,0) with sides e2, e3, diagonal
-          const double sa = lane == 0 ? e0 : e2, sb = lane == 0 ? e1 : e3;
-          const double hp = (sa + sb + ed) / 2;
-          const double tri = __dsqrt_rn(hp * (hp - sa) * (hp - sb) * (hp - ed));
-          double area = 0;
-          area += readlane_f64(tri, 0);
-          area += readlane_f64(tri, 1);
-          bool ok = __ballot(!cok) == 0ull;
-          if (area < 0.95 * P.min_tag_width * P.min_tag_width) ok = false;
-          if (lane != 0) ok = false;   // lane 0 appends the quad
-          if (ok) {
-            QuadRec q;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-              float fx = s_corner[c][0], fy = s_corner[c][1];
-              if (P.decimate > 1) {
-                const double f = (double)(float)P.decimate;
-                fx = (float)(((double)fx - 0.5) * f + 0.5);
-                fy = (float)(((double)fy - 0.5) * f + 0.5);
-              }
-              q.p[c][0] = fx; q.p[c][1] = fy;
-            }
-            q.reversed_border = q_reversed;
-            q.pad = 0;
-            q.key = cl.key;
-            const uint32_t qi = atomicAdd(&counters[frame].nquads, 1u);
-            if (qi < P.qcap) quads_all[(size_t)frame * P.qcap + qi] = q;
-            else atomicOr(&counters[frame].flags, 0x8u);
-          }
+        } else if (lane == 0) {
+          atomicOr(&counters[frame].flags, 0x8u);
         }
       }
     }
@@ -1678,5 +1623,77 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
       const uint32_t pos = atomicAdd(&work_n_out[cls], 1u);   // (pos < cap: the list holds at most the items of the input list)
       work_out[L.off[cls] + pos] = wi;
     }
+  }
+}
+
+// ---- k_quad_finish: corners, area and angle checks of the candidates k_fit_quads found (one thread per candidate) -------
+// The statements are the serial form of upstream's fit_quad tail (and of the CPU restatement): four line intersections,
+// corners rounded to float, two Heron triangles, four corner angles with the winding test.
+__global__ __launch_bounds__(256) void k_quad_finish(const FitCand* __restrict__ cands_all, QuadRec* __restrict__ quads_all,
+                                                     FrameCounters* __restrict__ counters, DetParams P) {
+  const int frame = (int)blockIdx.y + P.frame0;
+  uint32_t ncand = counters[frame].ncand;
+  if (ncand > P.qcap) ncand = P.qcap;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < ncand; i += gridDim.x * 256) {
+    const FitCand cd = cands_all[(size_t)frame * P.qcap + i];
+    float corner[4][2];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int j = (k + 1) & 3;
+      const double A00 = cd.line[k][3], A01 = -cd.line[j][3];
+      const double A10 = -cd.line[k][2], A11 = cd.line[j][2];
+      const double B0 = -cd.line[k][0] + cd.line[j][0];
+      const double B1 = -cd.line[k][1] + cd.line[j][1];
+      const double det = A00 * A11 - A10 * A01;
+      if (fabs(det) < 0.001) ok = false;
+      const double W00 = A11 / det, W01 = -A01 / det;
+      const double L0 = W00 * B0 + W01 * B1;
+      corner[k][0] = (float)(cd.line[k][0] + L0 * A00);
+      corner[k][1] = (float)(cd.line[k][1] + L0 * A10);
+    }
+    if (!ok) continue;
+    double len[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i1 = (k + 1) & 3, i2 = (k + 2) & 3;
+      const double ax = corner[k][0], ay = corner[k][1];
+      const double bx = corner[i1][0], by = corner[i1][1], cx2 = corner[i2][0], cy2 = corner[i2][1];
+      const double dx1 = bx - ax, dy1 = by - ay, dx2 = cx2 - bx, dy2 = cy2 - by;
+      const double q1 = dx1 * dx1 + dy1 * dy1;
+      len[k] = __dsqrt_rn(q1);
+      const double cos_dtheta = (dx1 * dx2 + dy1 * dy2) / __dsqrt_rn(q1 * (dx2 * dx2 + dy2 * dy2));
+      if ((cos_dtheta > P.cos_critical_rad || cos_dtheta < -P.cos_critical_rad) || dx1 * dy2 < dy1 * dx2) ok = false;
+    }
+    double area = 0;
+    {
+      const double ax = corner[0][0], ay = corner[0][1], px2 = corner[2][0], py2 = corner[2][1];
+      const double ed = __dsqrt_rn((ax - px2) * (ax - px2) + (ay - py2) * (ay - py2));
+#pragma unroll
+      for (int t = 0; t < 2; t++) {   // triangle (0,1,2): sides len0, len1, diagonal; triangle (2,3,0): len2, len3, diagonal
+        const double sa = len[2 * t], sb = len[2 * t + 1];
+        const double hp = (sa + sb + ed) / 2;
+        area += __dsqrt_rn(hp * (hp - sa) * (hp - sb) * (hp - ed));
+      }
+    }
+    if (area < 0.95 * P.min_tag_width * P.min_tag_width) ok = false;
+    if (!ok) continue;
+    QuadRec q;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      float fx = corner[c][0], fy = corner[c][1];
+      if (P.decimate > 1) {
+        const double f = (double)(float)P.decimate;
+        fx = (float)(((double)fx - 0.5) * f + 0.5);
+        fy = (float)(((double)fy - 0.5) * f + 0.5);
+      }
+      q.p[c][0] = fx; q.p[c][1] = fy;
+    }
+    q.reversed_border = cd.reversed_border;
+    q.pad = 0;
+    q.key = cd.key;
+    const uint32_t qi = atomicAdd(&counters[frame].nquads, 1u);
+    if (qi < P.qcap) quads_all[(size_t)frame * P.qcap + qi] = q;
+    else atomicOr(&counters[frame].flags, 0x8u);
   }
 }
