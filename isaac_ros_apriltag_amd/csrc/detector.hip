@@ -609,7 +609,8 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
   mark();
   {
     // keys | pair-table region
-    auto lds_bytes = [](const FqClass& c) { return (size_t)FQ_KP(c.sort_cap) * 8 + (size_t)FQ_TABLE_DOUBLES * 8; };   // skewed key array
+    // skewed key array (later: errors, candidates, pair tables) | group prefixes of the early-exit test (not in the one-wave class)
+    auto lds_bytes = [](const FqClass& c) { return (size_t)FQ_KP(c.sort_cap) * 8 + (c.nt > 64 ? (size_t)FQ_TABLE_DOUBLES * 8 : 0); };
 
     // The classes are independent (they only append to the quad list).  Every class's persistent grid can fill the
     // chip's register file by itself, so whichever workgroups are placed first stay until their list is empty, and the
@@ -676,7 +677,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
       launch_prefilter(s);
       HIP_TRY(hipEventRecord(D->ev_fork, s));
       for (int a = 0; a < 3; a++) HIP_TRY(hipStreamWaitEvent(aux[a], D->ev_fork, 0));
-      for (int c = FQ_NCLS - 1; c >= FQ_PREFILTER_CLASS; c--) launch_class(c, s);
+      for (int c = FQ_PREFILTER_CLASS; c < FQ_NCLS; c++) launch_class(c, s);   // (nearly all survivors are in the first of them)
       launch_class(1, aux[0]);
       launch_class(0, aux[1]);
     } else {

@@ -372,6 +372,46 @@ __device__ __forceinline__ int fq_sector(float slope) {
                   (r >= 1.4966058f ? 1 : 0) + (r >= 2.4142137f ? 1 : 0) + (r >= 5.0273395f ? 1 : 0);
   return qi * 8 + sub;
 }
+// 64 sectors (sixteen per band, cut at multiples of 5.625 degrees); sector s of fq_sector is the union of 2s and 2s + 1
+__device__ __forceinline__ int fq_sector64(float slope) {
+  const int qi = (slope >= 0.0f ? 1 : 0) + (slope >= 65536.0f ? 1 : 0) + (slope >= 131072.0f ? 1 : 0);
+  const float r = slope - (float)(qi - 1) * 65536.0f;
+  const int sub = (r >= 0.09849140f ? 1 : 0) + (r >= 0.19891237f ? 1 : 0) + (r >= 0.30334668f ? 1 : 0) + (r >= 0.41421357f ? 1 : 0) +
+                  (r >= 0.53451114f ? 1 : 0) + (r >= 0.66817864f ? 1 : 0) + (r >= 0.82067879f ? 1 : 0) + (r >= 1.0f ? 1 : 0) +
+                  (r >= 1.2185035f ? 1 : 0) + (r >= 1.4966058f ? 1 : 0) + (r >= 1.8708684f ? 1 : 0) + (r >= 2.4142137f ? 1 : 0) +
+                  (r >= 3.2965582f ? 1 : 0) + (r >= 5.0273395f ? 1 : 0) + (r >= 10.153170f ? 1 : 0);
+  return qi * 16 + sub;
+}
+// fq_feasible over 64 groups for a one-wave workgroup: lane b evaluates the arcs (a, b) of one cut group a per trip, so a
+// ballot is row a of the relation; the path search keeps one 64-bit row per lane.
+template <int ST, int WI>
+__device__ __forceinline__ bool fq_feasible64(const double* sP, double mse_limit, int W, int H) {
+  const int b = (int)threadIdx.x;   // 0..63
+  const double thr = mse_limit * 1.02 + 0.1 + 0x1p-50 * (sP[64 * ST + 2] + sP[64 * ST + 4]) +
+                     1e-7 * 0.25 * ((double)W * (double)W + (double)H * (double)H);
+  unsigned long long rowf = 0, roww = 0;   // lane a keeps row a
+#pragma unroll 1
+  for (int a = 0; a < 64; a++) {
+    bool okf = true, okw = true;
+    if (b >= a) {
+      if (b >= a + 2) okf = fq_arc_possible(sP + (a + 1) * ST, sP + b * ST, nullptr, sP[(b + 1) * ST + WI] - sP[a * ST + WI], thr);
+      __builtin_amdgcn_sched_barrier(0);
+      okw = fq_arc_possible(sP + (b + 1) * ST, sP + 64 * ST, sP + a * ST, (sP[64 * ST + WI] - sP[b * ST + WI]) + sP[(a + 1) * ST + WI], thr);
+    }
+    const unsigned long long mf = __ballot(okf && b >= a), mw = __ballot(okw && b >= a);
+    if (b == a) { rowf = mf; roww = mw; }
+  }
+  auto row_of = [&](int l) {
+    return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rowf, l) |
+           ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rowf >> 32), l) << 32);
+  };
+  unsigned long long r2 = 0, r3 = 0;
+#pragma unroll 8
+  for (int l = 0; l < 64; l++) r2 |= ((rowf >> l) & 1ull) ? row_of(l) : 0ull;
+#pragma unroll 8
+  for (int l = 0; l < 64; l++) r3 |= ((r2 >> l) & 1ull) ? row_of(l) : 0ull;
+  return __ballot((r3 & roww) != 0ull) != 0ull;
+}
 
 // Sort keys are stored so that their order as IEEE doubles equals the wanted unsigned order: a
 // compare-exchange is then v_min_f64 + v_max_f64 (two instructions instead of a 64-bit compare and four
@@ -563,7 +603,7 @@ constexpr PairTable make_pair_table() {
 __device__ const PairTable g_pair_table = make_pair_table();
 
 // Dynamic LDS layout: [0, 8*sort_cap) slope keys (later: raw/smoothed errors, then maxima candidates) |
-// FQ_TABLE_DOUBLES doubles of pair-fit tables.  Clusters with size in (size_lo, size_hi] are processed by this
+// FQ_TABLE_DOUBLES doubles for the group prefixes of the early-exit test (none in the one-wave class).  Clusters with size in (size_lo, size_hi] are processed by this
 // launch; those above sort_cap (only possible in the last class) sort in global scratch.
 template <int NT, bool SPLIT>
 #ifndef FQ_EPT
@@ -571,7 +611,7 @@ template <int NT, bool SPLIT>
 #endif
 #define FQ_SEL_REGS 8          // maxima candidates per lane held in registers during the top-10 selection
 #define FQ_SMOOTH_REGS_OF(NT) ((NT) >= 1024 ? 8 : 16)   // smoothed errors per thread kept in registers (clusters up to that many x threads)
-#define FQ_TABLE_DOUBLES 290   // six 45-entry pair tables, 4 lines x 4 parameters, 4 line mse
+#define FQ_TABLE_DOUBLES ((FQ_XG + 1) * 7)   // prefixes over FQ_XG groups, up to seven sums each
 #define FQ_PIDX(a, b) ((((a) * (19 - (a))) >> 1) + (b) - (a) - 1)   // a < b < 10 -> 0..44
 #ifndef FQ_WPE_64
 #define FQ_WPE_64 4
@@ -1457,7 +1497,7 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
                                                        uint32_t* __restrict__ work_out, uint32_t* __restrict__ work_n_out,
                                                        FqWorkLayout L, int first_class, DetParams P) {
   __shared__ __attribute__((aligned(16))) uint32_t spts[FQ_PF_CHUNK];
-  __shared__ double sB[(FQ_XG + 1) * 7];
+  __shared__ double sB[(64 + 1) * 7];   // sums of the 64 sectors, then their prefixes
   __shared__ long long s_dot[FQ_PF_NT / 64][3];
   __shared__ int s_box[FQ_PF_NT / 64][4];
   __shared__ uint32_t s_okf[FQ_XG], s_okw[FQ_XG];
@@ -1520,7 +1560,7 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
         s_box[wv][0] = xmin; s_box[wv][1] = xmax; s_box[wv][2] = ymin; s_box[wv][3] = ymax;
         s_dot[wv][0] = sxg; s_dot[wv][1] = sgx; s_dot[wv][2] = sgy;
       }
-      for (int t = tid; t < (FQ_XG + 1) * 7; t += FQ_PF_NT) sB[t] = 0.0;
+      for (int t = tid; t < (64 + 1) * 7; t += FQ_PF_NT) sB[t] = 0.0;
       __syncthreads();
       xmin = s_box[0][0]; xmax = s_box[0][1]; ymin = s_box[0][2]; ymax = s_box[0][3];
       sxg = s_dot[0][0]; sgx = s_dot[0][1]; sgy = s_dot[0][2];
@@ -1595,7 +1635,7 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
           if (dy < 0) { dy = -dy; dx = -dx; }
           if (dx < 0) { float tmp = dx; dx = dy; dy = -tmp; }
           const float slope = quadrant + __fdiv_rn(dy, dx);
-          const int sec = fq_sector(slope);
+          const int sec = fq_sector64(slope);
           const uint32_t px = (uint32_t)xi, py = (uint32_t)yi;
           const double x = (int)(px + 1) * .5, y = (int)(py + 1) * .5;
           const double Wt = sqrt_u18(GG[e]) + 1;
@@ -1614,12 +1654,17 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
       __syncthreads();
       if (tid < 7) {
         double run = 0.0;
-        for (int sct = 1; sct <= FQ_XG; sct++) { run += sB[sct * 7 + tid]; sB[sct * 7 + tid] = run; }
+        for (int sct = 1; sct <= 64; sct++) { run += sB[sct * 7 + tid]; sB[sct * 7 + tid] = run; }
       }
       __syncthreads();
-      reject = !fq_feasible<FQ_PF_NT, 7, 6>(sB, P.max_line_fit_mse, W, H, s_okf, s_okw, &s_feasible);
+      // 32 sectors first (every second prefix: a quarter of the arc evaluations); a cluster that passes is looked at again
+      // with all 64 (config 2: 84 % of the points above 2048 per cluster fail the first test, 96 % the second)
+      reject = !fq_feasible<FQ_PF_NT, 14, 6>(sB, P.max_line_fit_mse, W, H, s_okf, s_okw, &s_feasible);
+      if (!reject && FQ_PF_NT == 64) reject = !fq_feasible64<7, 6>(sB, P.max_line_fit_mse, W, H);
     }
     if (!reject && tid == 0) {
+      // (one list per class: sending all survivors to the largest class's 1024-thread workgroups, one per CU, was measured
+      // slower -- 0.53 against 0.35 ms of tail: they are few, but each is a chain of ~100 us)
       const uint32_t pos = atomicAdd(&work_n_out[cls], 1u);   // (pos < cap: the list holds at most the items of the input list)
       work_out[L.off[cls] + pos] = wi;
     }

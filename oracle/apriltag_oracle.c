@@ -559,9 +559,9 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
      * slope key (contiguous in sorted order); duplicates are not removed, so a point on an odd-odd half-pixel location
      * (the only ones that can occur twice) enters the scatter with half its weight and the weight bound in full */
     for (int v = 0; v < 3; v++) {
-      const int SPQ = 8, m = 4 * SPQ;   /* sectors per quadrant */
-      const int sub = v == 0 ? 1 : 4;
-      float thrs[64];
+      const int SPQ = 8 << v, m = 4 * SPQ;   /* sectors per quadrant: 32 / 64 / 128 sectors */
+      const int sub = 1;
+      float thrs[128];
       static const float QB[4] = {-65536.0f, 0.0f, 65536.0f, 131072.0f};
       for (int q = 0; q < 4; q++)
         for (int k = 0; k < SPQ; k++) thrs[q * SPQ + k] = QB[q] + (float)tan(k * (M_PI / 2) / SPQ);
@@ -595,7 +595,7 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
           int o = 1, ow = 1;
           if (b > a + 1) {
             double M[6]; for (int t = 0; t < 6; t++) M[t] = B[b][t] - B[a + 1][t];
-            double Wc = v == 2 ? B[m][6] : B[b + 1][6] - B[a][6];
+            double Wc = B[b + 1][6] - B[a][6];
             if (M[5] > 0.25) {
               double Sxx = M[2] - M[0] * M[0] / M[5], Sxy = M[3] - M[0] * M[1] / M[5], Syy = M[4] - M[1] * M[1] / M[5];
               double q = 0.5 * (Sxx + Syy - sqrt((Sxx - Syy) * (Sxx - Syy) + 4 * Sxy * Sxy));
@@ -604,7 +604,7 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
           }
           {
             double M[6]; for (int t = 0; t < 6; t++) M[t] = (B[m][t] - B[b + 1][t]) + B[a][t];
-            double Wc = v == 2 ? B[m][6] : (B[m][6] - B[b][6]) + B[a + 1][6];
+            double Wc = (B[m][6] - B[b][6]) + B[a + 1][6];
             if (M[5] > 0.25) {
               double Sxx = M[2] - M[0] * M[0] / M[5], Sxy = M[3] - M[0] * M[1] / M[5], Syy = M[4] - M[1] * M[1] / M[5];
               double q = 0.5 * (Sxx + Syy - sqrt((Sxx - Syy) * (Sxx - Syy) + 4 * Sxy * Sxy));

@@ -52,10 +52,12 @@ def main():
     best = ratio.max(axis=1) > 1.0
     print("any level: rejects %d clusters %d points (%.1f %% of doomed points), unsound %d" %
           ((best & doomed).sum(), pts[best & doomed].sum(), 100.0 * pts[best & doomed].sum() / max(1, pts[doomed].sum()), (best & good).sum()))
+    names = ["sect32", "sect64", "sect128", "grp48", "grp64", "grp96", "grp128", "grp256"]
     for lo, hi in ((24, 768), (769, 2048), (2049, 4096), (4097, 8192), (8193, 1 << 30)):
         m = (pts >= lo) & (pts <= hi)
         print("  class %5d..%-6d: %6d points doomed, %6d rejected; %6d points admissible" %
               (lo, min(hi, 99999), pts[m & doomed].sum(), pts[m & doomed & best].sum(), pts[m & good].sum()))
+        print("       per test: " + ", ".join("%s %d" % (names[k], pts[m & doomed & (ratio[:, k] > 1.0)].sum()) for k in range(8)))
 
 
 if __name__ == "__main__":
