@@ -634,7 +634,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
       unsigned gp = (2048u / FQ_PF_NT) * (unsigned)D->num_cus;
       if (gp > 256u * n) gp = 256u * n;
       hipLaunchKernelGGL(k_fit_prefilter, dim3(gp), dim3(FQ_PF_NT), 0, sp, D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work,
-                         D->d_workctl, work2, D->d_workctl + 16, D->work_layout, FQ_PREFILTER_CLASS, P);
+                         D->d_workctl, work2, D->d_workctl + 16, D->work_layout, FQ_PREFILTER_CLASS, (D->fq_counters ? D->d_fqprof : nullptr), P);
     };
     auto launch_class = [&](int c, hipStream_t sc) {
       const FqClass& cl = D->cls[c];

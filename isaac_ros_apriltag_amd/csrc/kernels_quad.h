@@ -281,7 +281,8 @@ __device__ __forceinline__ void fit_line_dev(const double* lf, int sz, int i0, i
 // the maxima turn out to be: the second walk, the windowed errors, the maxima and the corner search are skipped.
 // The test never changes a result.  mse_limit carries an allowance for the rounding of the evaluation it stands in
 // for (differences of once-rounded prefixes: a few ulps of the largest prefix over an arc weight >= 2; the float square
-// root: 2^-23.5 of the arc's total variance, which the image diagonal bounds) and for its own rounding (2 %).
+// root: 2^-23.5 of the arc's total variance, which the image diagonal bounds) and for its own rounding (2 %, plus 2^-44 of
+// the cluster's total second moments for the order-dependent rounding of the sector sums and their prefix scan).
 // On sigma-2 1080p frames 72 % of the points of clusters without an admissible corner choice sit in clusters this
 // test rejects with 64 groups, 68 % with 32 (tools/early_exit_power.py, CPU restatement); the one-wave class (up to
 // 768 points) gains nothing from it and does not run it.
@@ -294,7 +295,12 @@ __device__ __forceinline__ void fit_line_dev(const double* lf, int sz, int i0, i
 #define FQ_PRESORT_MIN_NT (1 << 20)
 #endif
 #define FQ_PREFILTER_CLASS 2
-// moments of prefix difference hi - lo (+ add), returns false only if lambda_min of their scatter exceeds thr * Wc
+// Moments m = hi - lo (+ add) of the groups strictly between two cuts; returns false only if lambda_min of their scatter
+// certainly exceeds thr * Wc.  Division- and root-free: with W = m5, A = W m2 - m0^2, B = W m3 - m0 m1, C = W m4 - m1^2 (W times
+// the scatter matrix) and c = thr * Wc, both eigenvalues of the scatter exceed c exactly when (A - cW) + (C - cW) > 0 and
+// (A - cW)(C - cW) - B^2 > 0.  Rounding: coordinates are below 2048 on this path (split_moments), so m2, m4 <= 2^22 W and
+// each of A, B, C carries an absolute error below e = 4e-9 W^2 (eight roundings of terms <= W^2 2^22); the trace and the
+// determinant are compared against the error bounds that follow from e, so a "false" is a proof.
 __device__ __forceinline__ bool fq_arc_possible(const double* lo, const double* hi, const double* add, double Wc, double thr) {
   double m[6];
 #pragma unroll
@@ -303,13 +309,18 @@ __device__ __forceinline__ bool fq_arc_possible(const double* lo, const double* 
 #pragma unroll
     for (int j = 0; j < 6; j++) m[j] += add[j];
   }
-  if (!(m[5] > 0.25)) return true;   // no points in between (every weight is >= 1/2)
-  const double rW = 1.0 / m[5];
-  const double Sxx = m[2] - m[0] * m[0] * rW, Sxy = m[3] - m[0] * m[1] * rW, Syy = m[4] - m[1] * m[1] * rW;
-  const double dif = Sxx - Syy;
-  const double lam = 0.5 * ((Sxx + Syy) - __dsqrt_rn(dif * dif + 4.0 * Sxy * Sxy));
-  return !(lam > thr * Wc);
+  const double W = m[5];
+  if (!(W > 0.25)) return true;   // no points in between (every weight is >= 1/2)
+  const double cW = thr * Wc * W;
+  const double a = (W * m[2] - m[0] * m[0]) - cW, d = (W * m[4] - m[1] * m[1]) - cW, B = W * m[3] - m[0] * m[1];
+  const double e = 4.1e-9 * W * W;
+  const double fa = fabs(a), fd = fabs(d), fB = fabs(B);
+  const double tr = a + d, det = a * d - B * B;
+  const double e1 = 2.0 * e + 0x1p-50 * (fa + fd);
+  const double e2 = e * (fa + fd + 2.0 * fB) + 3.0 * e * e + 0x1p-50 * (fa * fd + fB * fB);
+  return !(tr > e1 && det > e2);
 }
+
 // The whole test on a prefix array sP[(FQ_XG + 1)][ST] in LDS (entry g = sums over the groups before g; components 0..5 =
 // the six moments with the scatter weights, component WI = the weight bound): true if some a <= b <= c <= d passes on all
 // four arcs.  Contains workgroup barriers; every thread returns the same value.
@@ -318,7 +329,7 @@ __device__ __forceinline__ bool fq_feasible(const double* sP, double mse_limit, 
                                             int* s_feasible) {
   const int tid = threadIdx.x;
   // allowance for the rounding of the evaluation this test stands in for (see above)
-  const double thr = mse_limit * 1.02 + 0.1 + 0x1p-50 * (sP[FQ_XG * ST + 2] + sP[FQ_XG * ST + 4]) +
+  const double thr = mse_limit * 1.02 + 0.1 + 0x1p-44 * (sP[FQ_XG * ST + 2] + sP[FQ_XG * ST + 4]) +
                      1e-7 * 0.25 * ((double)W * (double)W + (double)H * (double)H);
 #pragma unroll 1
   for (int pbase = 0; pbase < FQ_XG * FQ_XG; pbase += NT) {
@@ -387,7 +398,7 @@ __device__ __forceinline__ int fq_sector64(float slope) {
 template <int ST, int WI>
 __device__ __forceinline__ bool fq_feasible64(const double* sP, double mse_limit, int W, int H) {
   const int b = (int)threadIdx.x;   // 0..63
-  const double thr = mse_limit * 1.02 + 0.1 + 0x1p-50 * (sP[64 * ST + 2] + sP[64 * ST + 4]) +
+  const double thr = mse_limit * 1.02 + 0.1 + 0x1p-44 * (sP[64 * ST + 2] + sP[64 * ST + 4]) +
                      1e-7 * 0.25 * ((double)W * (double)W + (double)H * (double)H);
   unsigned long long rowf = 0, roww = 0;   // lane a keeps row a
 #pragma unroll 1
@@ -1495,7 +1506,7 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
                                                        const uint32_t* __restrict__ pts_all, const ClusterRec* __restrict__ clusters_all,
                                                        const uint32_t* __restrict__ work, const uint32_t* __restrict__ work_n,
                                                        uint32_t* __restrict__ work_out, uint32_t* __restrict__ work_n_out,
-                                                       FqWorkLayout L, int first_class, DetParams P) {
+                                                       FqWorkLayout L, int first_class, unsigned long long* __restrict__ prof, DetParams P) {
   __shared__ __attribute__((aligned(16))) uint32_t spts[FQ_PF_CHUNK];
   __shared__ double sB[(64 + 1) * 7];   // sums of the 64 sectors, then their prefixes
   __shared__ long long s_dot[FQ_PF_NT / 64][3];
@@ -1504,6 +1515,13 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
   __shared__ int s_feasible;
   const int tid = threadIdx.x;
   const int W = P.W, H = P.H;
+#ifdef AMDAT_FQ_PROFILE   // tools-only: shader cycles per phase (prof[60..63]: box + dot, sector sums, scan + 32-sector test, 64-sector test)
+#define PF_TICK(slot) if (prof && tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&prof[slot], now_ - t_prev_); t_prev_ = now_; }
+  unsigned long long t_prev_ = prof ? __builtin_readcyclecounter() : 0ull;
+#else
+#define PF_TICK(slot)
+  (void)prof;
+#endif
   // items of the classes first_class .. FQ_NCLS - 1, largest class first
   uint32_t cnt[FQ_NCLS], total = 0;
 #pragma unroll
@@ -1542,15 +1560,18 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
       uint32_t pq[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) pq[u] = pts[min(i + u * FQ_PF_NT, sz - 1)];
+      // gradient signs (-1, 0, 1) summed in 32 bits per trip (8 x 2^14 at most), scaled by 255 once per trip
+      int t_xg = 0, t_gx = 0, t_gy = 0;
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const uint32_t p = (i + u * FQ_PF_NT < sz) ? pq[u] : ((pq[0] & ~15u) | 5u);
         const int x = (int)(p >> 18), y = (int)((p >> 4) & 0x3FFF);
-        const int gx = ((int)((p >> 2) & 3) - 1) * 255, gy = ((int)(p & 3) - 1) * 255;
+        const int gx = (int)((p >> 2) & 3) - 1, gy = (int)(p & 3) - 1;
         xmin = min(xmin, x); xmax = max(xmax, x); ymin = min(ymin, y); ymax = max(ymax, y);
-        sxg += (long long)x * gx + (long long)y * gy;
-        sgx += gx; sgy += gy;
+        t_xg += x * gx + y * gy;
+        t_gx += gx; t_gy += gy;
       }
+      sxg += (long long)(t_xg * 255); sgx += t_gx * 255; sgy += t_gy * 255;
     }
     xmin = wave_min_i(xmin); xmax = wave_max_i(xmax); ymin = wave_min_i(ymin); ymax = wave_max_i(ymax);
     sxg = wave_sum_ll(sxg); sgx = wave_sum_ll(sgx); sgy = wave_sum_ll(sgy);
@@ -1570,6 +1591,7 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
         sxg += s_dot[w][0]; sgx += s_dot[w][1]; sgy += s_dot[w][2];
       }
     }
+    PF_TICK(60)
     bool reject = (xmax - xmin) * (ymax - ymin) < P.min_tag_width;
     const double cxd = (xmin + xmax) * 0.5 + 0.05118, cyd = (ymin + ymax) * 0.5 + -0.028581;
     const double dot = (double)sxg - cxd * (double)sgx - cyd * (double)sgy;
@@ -1652,6 +1674,7 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
       }
       if (cur >= 0) flush();
       __syncthreads();
+      PF_TICK(61)
       if (tid < 7) {
         double run = 0.0;
         for (int sct = 1; sct <= 64; sct++) { run += sB[sct * 7 + tid]; sB[sct * 7 + tid] = run; }
@@ -1660,7 +1683,9 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
       // 32 sectors first (every second prefix: a quarter of the arc evaluations); a cluster that passes is looked at again
       // with all 64 (config 2: 84 % of the points above 2048 per cluster fail the first test, 96 % the second)
       reject = !fq_feasible<FQ_PF_NT, 14, 6>(sB, P.max_line_fit_mse, W, H, s_okf, s_okw, &s_feasible);
+      PF_TICK(62)
       if (!reject && FQ_PF_NT == 64) reject = !fq_feasible64<7, 6>(sB, P.max_line_fit_mse, W, H);
+      PF_TICK(63)
     }
     if (!reject && tid == 0) {
       // (one list per class: sending all survivors to the largest class's 1024-thread workgroups, one per CU, was measured
