@@ -14,8 +14,10 @@
 //
 // Input file: int32 magic 'ATS1', streams S, frames-per-stream F, width, height, decimate; then S records of five
 // doubles {fx, fy, cx, cy, tag_size}; then S*F mono8 frames.  Output: one JSON line with the whole-job frame rate and,
-// per stream, the detection count and an FNV-1a checksum of (id, corners) that tests/test_gpu_parity.py compares with
-// the Python path.
+// per stream, the detection count and an FNV-1a checksum of (id, corners, translation) that tests/test_gpu_parity.py
+// compares with the Python path.  The tag size is a property of the handle (amdCreateAprilTagsDetector, as in
+// nvCreateAprilTagsDetector): a GPU whose streams carry different tag sizes gets one handle per distinct size and runs
+// them one after the other.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -25,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -116,56 +119,74 @@ int main(int argc, char** argv) {
     CHECK_HIP(hipMemcpy(blk.data(), d_block[g], block_doubles * 8, hipMemcpyDeviceToHost));
     std::vector<int> mine;
     for (int s = 0; s < S; s++) if (s % G == g) mine.push_back(s);
-    const uint32_t B = (uint32_t)(mine.size() * F);
-    if (B == 0) { bar.wait(); bar.wait(); return; }
-    amdAprilTagsConfig_t cfg;
-    amdAprilTagsDefaultConfig(&cfg, (uint32_t)W, (uint32_t)H);
-    cfg.decimate = (uint32_t)blk[(size_t)S * 5];
-    cfg.max_batch = B;
-    cfg.device = g;
-    cfg.tag_size = (float)blk[(size_t)mine[0] * 5 + 4];
-    amdAprilTagsHandle h = nullptr;
-    CHECK_AT(amdCreateAprilTagsDetectorEx(&h, &cfg));
-    uint8_t* d_frames = nullptr;
-    CHECK_HIP(hipMalloc((void**)&d_frames, (size_t)B * fbytes));
-    std::vector<amdAprilTagsImageInput_t> imgs(B);
-    std::vector<amdAprilTagsCameraIntrinsics_t> intr(B);
-    for (size_t k = 0; k < mine.size(); k++) {
-      const int s = mine[k];
-      CHECK_HIP(hipMemcpy(d_frames + k * F * fbytes, frames.data() + (size_t)s * F * fbytes, (size_t)F * fbytes, hipMemcpyHostToDevice));
-      for (int i = 0; i < F; i++) {
-        const size_t b = k * F + i;
-        imgs[b] = {(uint32_t)W, (uint32_t)H, d_frames + b * fbytes, (size_t)W};
-        intr[b] = {(float)blk[(size_t)s * 5 + 0], (float)blk[(size_t)s * 5 + 1], (float)blk[(size_t)s * 5 + 2], (float)blk[(size_t)s * 5 + 3]};
+    if (mine.empty()) { bar.wait(); bar.wait(); return; }
+    // one handle per distinct tag size among this GPU's streams
+    std::map<float, std::vector<int>> by_size;
+    for (int s : mine) by_size[(float)blk[(size_t)s * 5 + 4]].push_back(s);
+    struct Group {
+      std::vector<int> streams;
+      amdAprilTagsHandle h = nullptr;
+      uint8_t* d_frames = nullptr;
+      std::vector<amdAprilTagsImageInput_t> imgs;
+      std::vector<amdAprilTagsCameraIntrinsics_t> intr;
+      std::vector<amdAprilTagsID_t> tags;
+      std::vector<uint32_t> cnt;
+    };
+    std::vector<Group> groups;
+    for (auto& kv : by_size) {
+      Group gr;
+      gr.streams = kv.second;
+      const uint32_t B = (uint32_t)(gr.streams.size() * F);
+      amdAprilTagsConfig_t cfg;
+      amdAprilTagsDefaultConfig(&cfg, (uint32_t)W, (uint32_t)H);
+      cfg.decimate = (uint32_t)blk[(size_t)S * 5];
+      cfg.max_batch = B;
+      cfg.device = g;
+      cfg.tag_size = kv.first;
+      CHECK_AT(amdCreateAprilTagsDetectorEx(&gr.h, &cfg));
+      CHECK_HIP(hipMalloc((void**)&gr.d_frames, (size_t)B * fbytes));
+      gr.imgs.resize(B); gr.intr.resize(B); gr.tags.resize((size_t)B * max_tags); gr.cnt.resize(B);
+      for (size_t k = 0; k < gr.streams.size(); k++) {
+        const int s = gr.streams[k];
+        CHECK_HIP(hipMemcpy(gr.d_frames + k * F * fbytes, frames.data() + (size_t)s * F * fbytes, (size_t)F * fbytes, hipMemcpyHostToDevice));
+        for (int i = 0; i < F; i++) {
+          const size_t b = k * F + i;
+          gr.imgs[b] = {(uint32_t)W, (uint32_t)H, gr.d_frames + b * fbytes, (size_t)W};
+          gr.intr[b] = {(float)blk[(size_t)s * 5 + 0], (float)blk[(size_t)s * 5 + 1], (float)blk[(size_t)s * 5 + 2], (float)blk[(size_t)s * 5 + 3]};
+        }
       }
+      groups.push_back(std::move(gr));
     }
-    std::vector<amdAprilTagsID_t> tags((size_t)B * max_tags);
-    std::vector<uint32_t> cnt(B);
-    CHECK_AT(amdAprilTagsDetectBatch(h, B, imgs.data(), intr.data(), tags.data(), cnt.data(), max_tags, nullptr));   // warm-up
+    auto run_all = [&]() {
+      for (Group& gr : groups)
+        CHECK_AT(amdAprilTagsDetectBatch(gr.h, (uint32_t)gr.imgs.size(), gr.imgs.data(), gr.intr.data(), gr.tags.data(), gr.cnt.data(), max_tags, nullptr));
+    };
+    run_all();   // warm-up
     bar.wait();
     const auto t0 = std::chrono::steady_clock::now();
-    for (int it = 0; it < steps; it++)
-      CHECK_AT(amdAprilTagsDetectBatch(h, B, imgs.data(), intr.data(), tags.data(), cnt.data(), max_tags, nullptr));
+    for (int it = 0; it < steps; it++) run_all();
     seconds[g] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     bar.wait();
-    for (size_t k = 0; k < mine.size(); k++) {
-      uint64_t hsh = 0xCBF29CE484222325ull;
-      uint32_t n = 0;
-      for (int i = 0; i < F; i++) {
-        const size_t b = k * F + i;
-        for (uint32_t d = 0; d < cnt[b]; d++) {
-          const amdAprilTagsID_t& t = tags[b * max_tags + d];
-          hsh = fnv1a(hsh, &t.id, sizeof(t.id));
-          hsh = fnv1a(hsh, t.corners, sizeof(t.corners));
-          hsh = fnv1a(hsh, t.translation, sizeof(t.translation));
+    for (Group& gr : groups) {
+      for (size_t k = 0; k < gr.streams.size(); k++) {
+        uint64_t hsh = 0xCBF29CE484222325ull;
+        uint32_t n = 0;
+        for (int i = 0; i < F; i++) {
+          const size_t b = k * F + i;
+          for (uint32_t d = 0; d < gr.cnt[b]; d++) {
+            const amdAprilTagsID_t& t = gr.tags[b * max_tags + d];
+            hsh = fnv1a(hsh, &t.id, sizeof(t.id));
+            hsh = fnv1a(hsh, t.corners, sizeof(t.corners));
+            hsh = fnv1a(hsh, t.translation, sizeof(t.translation));
+          }
+          n += gr.cnt[b];
         }
-        n += cnt[b];
+        sums[gr.streams[k]] = hsh;
+        ndet[gr.streams[k]] = n;
       }
-      sums[mine[k]] = hsh;
-      ndet[mine[k]] = n;
+      CHECK_HIP(hipFree(gr.d_frames));
+      CHECK_AT(amdAprilTagsDestroy(gr.h));
     }
-    CHECK_HIP(hipFree(d_frames));
-    CHECK_AT(amdAprilTagsDestroy(h));
   };
   std::vector<std::thread> th;
   for (int g = 0; g < G; g++) th.emplace_back(worker, g);

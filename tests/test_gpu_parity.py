@@ -545,8 +545,10 @@ def test_checkerboard_more_quads_than_the_old_fixed_capacity(built):
 
 
 def test_cpp_multi_stream_host(built, tmp_path):
-    """examples/multi_stream_host.cpp: one handle per GPU, ncclBroadcast of the per-stream parameter block, streams
-    sharded s % G.  On this 1-GPU box G = 1; every stream's records must equal the Python path's, byte for byte."""
+    """examples/multi_stream_host.cpp with BASELINE config 4's EIGHT streams: one handle per GPU (and per distinct tag
+    size), ncclBroadcast of the per-stream parameter block, streams sharded s % G.  On this 1-GPU box G = 1; every
+    stream's records must equal, byte for byte, those of the Python path (the one the other tests check against the
+    oracle).  Two tag sizes alternate over the streams, so a wrong handle-to-stream assignment shows in the translations."""
     import subprocess
     import sys
     from isaac_ros_apriltag_amd import build as b
@@ -556,8 +558,8 @@ def test_cpp_multi_stream_host(built, tmp_path):
     exe = b.HOST_BIN
     assert os.path.exists(exe), "examples/multi_stream_host was not built (isaac_ros_apriltag_amd.build.build_host)"
     path = str(tmp_path / "streams.bin")
-    S, F = 3, 2
-    block = dump_streams.dump(path, S, F, 0.0, 1)
+    S, F = 8, 2
+    block = dump_streams.dump(path, S, F, 0.0, 1, tag_sizes=[0.22, 0.16])
     out = subprocess.run([exe, path, "1", "2"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])
@@ -567,8 +569,10 @@ def test_cpp_multi_stream_host(built, tmp_path):
         for byte in data:
             h = ((h ^ byte) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
         return h
+    seen = set()
     for s in range(S):
         sp = streams.stream_params(block, s)
+        assert sp["tag_size"] == (0.22, 0.16)[s % 2]
         frames = np.stack([synth.scene_c2(seed=int(sp["seed"]) + i, sigma=0.0)[0] for i in range(F)])
         det = AprilTagDetector(1920, 1080, intrinsics=(sp["fx"], sp["fy"], sp["cx"], sp["cy"]), tag_size=sp["tag_size"], max_batch=F)
         tags, cnt = det.detect_batch_raw(torch.from_numpy(frames).cuda(), max_tags=64)
@@ -581,8 +585,35 @@ def test_cpp_multi_stream_host(built, tmp_path):
                 h = fnv(h, bytes(t.corners))
                 h = fnv(h, bytes(t.translation))
         o = rec["streams_out"][s]
+        assert o["stream"] == s and o["gpu"] == 0
         assert o["detections"] == sum(cnt) == 10 * F
         assert o["fnv"] == "%016x" % h, (s, o)
+        seen.add(o["fnv"])
+    assert len(seen) == S   # every stream has its own frames and intrinsics
+
+
+def test_bench_two_ranks_on_one_gpu(built):
+    """BASELINE config 4's N > 1 path as the driver would launch it, on the one GPU this box has: bench.py --gpus 2
+    starts two ranks itself (torch.distributed.run), the gloo backend carries the one broadcast of the parameter block,
+    both ranks share cuda:0, the eight streams split four per rank, and every rank's parity gate compares every frame of its
+    batch with the CPU oracle.  (On an 8-GPU node the same code path runs with the nccl backend = RCCL.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--shared-gpu", "--steps", "2",
+           "--warmup", "1", "--batch", "32", "--distinct", "32", "--no-extra", "--no-roofline"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 prints ONE line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
+    cfg = rec["config"]
+    assert cfg["world_size_seen_by_gloo"] == 2 and cfg["streams"] == 8 and cfg["streams_per_gpu"] == 4
+    assert cfg["frames_per_step_per_gpu"] == 32
+    assert rec["parity_gate"] == "pass"
+    assert rec["value"] > 0 and abs(rec["value"] - 2 * 32 / (rec["ms_per_step"] * 1e-3)) < 0.01 * rec["value"]
 
 
 def test_c99_example_runs(built, tmp_path):

@@ -13,8 +13,12 @@ sys.path.insert(0, ROOT)
 from isaac_ros_apriltag_amd import streams, synth  # noqa: E402
 
 
-def dump(path, nstreams=8, nframes=4, sigma=2.0, decimate=1, width=1920, height=1080):
+def dump(path, nstreams=8, nframes=4, sigma=2.0, decimate=1, width=1920, height=1080, tag_sizes=None):
+    """tag_sizes: optional per-stream tag sizes (cycled); default = one size for all streams."""
     block = streams.make_param_block(nstreams, width, height, decimate)
+    if tag_sizes:
+        for s in range(nstreams):
+            block[s][streams.PARAM_FIELDS.index("tag_size")] = tag_sizes[s % len(tag_sizes)]
     with open(path, "wb") as f:
         f.write(struct.pack("<6i", 0x31535441, nstreams, nframes, width, height, decimate))
         for s in range(nstreams):
