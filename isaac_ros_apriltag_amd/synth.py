@@ -179,6 +179,12 @@ def scene_c2(seed=1234, sigma=2.0):
     return _grid_scene(1920, 1080, [("tag36h11", i) for i in range(10)], 5, 2, seed, 96, 192, 30, 25, sigma)
 
 
+def scene_c2_ids(ids, seed=1234, sigma=2.0):
+    """Config 2's layout with the ten given tag36h11 ids (golden vectors and tests beyond ids 0-9, e.g. 100..586)."""
+    assert len(ids) == 10
+    return _grid_scene(1920, 1080, [("tag36h11", int(i)) for i in ids], 5, 2, seed, 96, 192, 30, 25, sigma)
+
+
 def scene_c5(seed=1234, sigma=2.0):
     """Config 5: config-2 layout with 5 tag36h11 ids and 5 tag25h9 ids."""
     ids = [("tag36h11", i) for i in range(5)] + [("tag25h9", i) for i in range(5)]

@@ -428,7 +428,7 @@ static int quad_segment_maxima(const ato_params_t* prm, const lfp_t* lfps, int s
     double best_error = (double)HUGE_VALF;
     g_qsm_reason = 4;
     double err01, err12, err23, err30, mse01, mse12, mse23, mse30, p01[4], p12[4];
-    double max_dot = prm->cos_critical_rad;
+    double max_dot = (prm->variant & ATO_VAR_FLOAT_COS) ? (double)(float)prm->cos_critical_rad : prm->cos_critical_rad;
     for (int m0 = 0; m0 < nmaxima - 3; m0++) {
       int i0 = maxima[m0];
       for (int m1 = m0 + 1; m1 < nmaxima - 2; m1++) {
@@ -770,7 +770,8 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
     double dx1 = (double)quad->p[i1][0] - (double)quad->p[i0][0], dy1 = (double)quad->p[i1][1] - (double)quad->p[i0][1];
     double dx2 = (double)quad->p[i2][0] - (double)quad->p[i1][0], dy2 = (double)quad->p[i2][1] - (double)quad->p[i1][1];
     double cos_dtheta = (dx1 * dx2 + dy1 * dy2) / sqrt((dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2));
-    if ((cos_dtheta > prm->cos_critical_rad || cos_dtheta < -prm->cos_critical_rad) || dx1 * dy2 < dy1 * dx2) { ATO_STAT(9, sz_in); goto finish; }
+    const double cos_crit = (prm->variant & ATO_VAR_FLOAT_COS) ? (double)(float)prm->cos_critical_rad : prm->cos_critical_rad;
+    if ((cos_dtheta > cos_crit || cos_dtheta < -cos_crit) || dx1 * dy2 < dy1 * dx2) { ATO_STAT(9, sz_in); goto finish; }
   }
   res = 1;
   ATO_STAT(10, sz_in);
@@ -1047,6 +1048,31 @@ static float quad_decode(const ato_params_t* prm, const ato_family_t* fam, const
   }
   float black_score = 0, white_score = 0, black_count = 1, white_count = 1;
   uint64_t rcode = 0;
+  if (prm->variant & ATO_VAR_AT3_BIT_ORDER) {
+    /* AprilTag 3 numbers the data bits quadrant by quadrant: rows y = 1 + l, x = 1 + l .. d - 1 - l of the top triangle,
+     * then the same triangle rotated by 90, 180, 270 degrees ((x, y) -> (d + 1 - y, x)), the centre bit of an odd d last.
+     * The code word itself stays row-major here (this restatement's tables are); only the order of the float score
+     * sums changes. */
+    int ox[64], oy[64], n = 0;
+    for (int q = 0; q < 4; q++)
+      for (int l = 0; 2 * l < d - 1; l++)
+        for (int x = 1 + l; x <= d - 1 - l; x++) {
+          int bx = x, by = 1 + l;
+          for (int r = 0; r < q; r++) { int nx = d + 1 - by, ny = bx; bx = nx; by = ny; }
+          ox[n] = bx; oy[n] = by; n++;
+        }
+    if (d & 1) { ox[n] = (d + 1) / 2; oy[n] = (d + 1) / 2; n++; }
+    for (int i = 0; i < n; i++) {
+      double v = values[(oy[i] - min_coord) * tw + ox[i] - min_coord];
+      if (v > 0) { white_score = (float)((double)white_score + v); white_count++; }
+      else { black_score = (float)((double)black_score - v); black_count++; }
+    }
+    for (int i = 0; i < (int)fam->nbits; i++) {
+      int bitx = 1 + i % d, bity = 1 + i / d;
+      rcode <<= 1;
+      if (values[(bity - min_coord) * tw + bitx - min_coord] > 0) rcode |= 1;
+    }
+  } else
   for (int i = 0; i < (int)fam->nbits; i++) {
     int bitx = 1 + i % d, bity = 1 + i / d;
     rcode <<= 1;
@@ -1312,6 +1338,16 @@ int ato_detect(const ato_params_t* prm, const ato_family_t* fams, int nfam, cons
         det->H[r * 3 + 0] = H[r * 3 + 0] * c + H[r * 3 + 1] * s;
         det->H[r * 3 + 1] = H[r * 3 + 0] * -s + H[r * 3 + 1] * c;
         det->H[r * 3 + 2] = H[r * 3 + 2];
+      }
+      if (prm->variant & ATO_VAR_TRIG_RZ) {   /* upstream: R from libm's cos / sin, full matrix product (matd_op "M*M") */
+        const double theta = rotation * M_PI / 2.0;
+        const double Rz[9] = {cos(theta), -sin(theta), 0, sin(theta), cos(theta), 0, 0, 0, 1};
+        for (int r = 0; r < 3; r++)
+          for (int cc = 0; cc < 3; cc++) {
+            double acc = 0;
+            for (int k = 0; k < 3; k++) acc += H[r * 3 + k] * Rz[k * 3 + cc];
+            det->H[r * 3 + cc] = acc;
+          }
       }
       homography_project(det->H, 0, 0, &det->c[0], &det->c[1]);
       for (int i = 0; i < 4; i++) {

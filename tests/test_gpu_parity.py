@@ -491,7 +491,7 @@ def test_random_scene_sweep(built):
         tags = []
         for t in range(ntags):
             fam = str(rng.choice(fams_all))
-            ncodes = {"tag36h11": 27, "tag25h9": 35, "tag16h5": 30}[fam]
+            ncodes = {"tag36h11": 587, "tag25h9": 35, "tag16h5": 30}[fam]
             side = float(rng.uniform(40, 110))
             cx, cy = float(rng.uniform(120, 520)), float(rng.uniform(100, 380))
             R = synth.rot_xyz(float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-3.1, 3.1)))

@@ -4,10 +4,13 @@ The HIP path is checked bit for bit against the canonical oracle (oracle/aprilta
 steps of that oracle are defined differently from upstream on purpose: exact cumulative
 moment sums instead of sequential double additions, the eigenvector line normal instead of atan2f/cosf/sinf in
 the edge refinement, Newton steps instead of the SVD for the polar factor of the pose -- plus the exact integer
-border-direction dot instead of a float accumulation.  ATO_VAR_* switches each step to the upstream
-formulation; this file BOUNDS what that changes, on configs 1, 2, 3 and 5:
+border-direction dot instead of a float accumulation, the double cos(10 deg) where upstream's parameter field is a
+float, the row-major order of the decision margin's float sums where AprilTag 3 walks its quadrant bit order, and
+exact {0, +-1} entries where upstream rotates the homography with libm's cos / sin.  ATO_VAR_* switches each step to
+the upstream formulation; this file BOUNDS what that changes, on configs 1, 2, 3 and 5:
 
   ids, hamming, detection count        identical
+  decision margin                      within 1e-4 relative (float sums in another order)
   corners / centre                     within 2.5e-4 px (measured: 6.1e-5 px at 1080p, 1.2e-4 px at 4K, all of it
                                        from the float atan2f/cosf/sinf of the edge normal), i.e. identical after
                                        rounding to 1e-3 px except for a value that sits within 2.5e-4 px of a
@@ -22,7 +25,9 @@ import parity_util as pu
 from isaac_ros_apriltag_amd import synth
 from oracle import pyoracle as po
 
-ALL = po.VAR_SEQ_MOMENTS | po.VAR_ATAN_NORMAL | po.VAR_SVD_POLAR | po.VAR_FLOAT_DOT
+ALL = (po.VAR_SEQ_MOMENTS | po.VAR_ATAN_NORMAL | po.VAR_SVD_POLAR | po.VAR_FLOAT_DOT | po.VAR_FLOAT_COS |
+       po.VAR_AT3_BIT_ORDER | po.VAR_TRIG_RZ)
+MARGIN_TOL = 1e-4    # decision margins are floats around 30..120: a few ulp of a float sum taken in another order
 ROUND_PX = 1e-3
 CORNER_TOL = 0.25 * ROUND_PX
 POSE_TOL = 1e-4
@@ -50,6 +55,7 @@ def _compare(a, b):
         dc = max(dc, float(np.abs(x["p"] - y["p"]).max()), float(np.abs(x["center"] - y["center"]).max()))
         dr = max(dr, float(np.abs(x["R"] - y["R"]).max()))
         dt = max(dt, float(np.abs(x["t"] - y["t"]).max()))
+        assert abs(x["decision_margin"] - y["decision_margin"]) <= MARGIN_TOL * max(1.0, abs(x["decision_margin"]))
     return dc, dr, dt
 
 
@@ -57,6 +63,9 @@ def _compare(a, b):
                                           (po.VAR_ATAN_NORMAL, "atan2f normal"),
                                           (po.VAR_SVD_POLAR, "SVD polar factor"),
                                           (po.VAR_FLOAT_DOT, "float border dot"),
+                                          (po.VAR_FLOAT_COS, "float cos_critical_rad"),
+                                          (po.VAR_AT3_BIT_ORDER, "AprilTag 3 bit order of the score sums"),
+                                          (po.VAR_TRIG_RZ, "cos/sin rotation of H"),
                                           (ALL, "all upstream formulations")])
 def test_upstream_formulations_within_rounding(built, variant, name):
     worst = [0.0, 0.0, 0.0]

@@ -22,6 +22,8 @@ SCENES = {
     "pol_golden": dict(scene="scene_pol_golden", kwargs={}, families=["tag36h11"], decimate=1),
     "c2_seed1234_sigma2": dict(scene="scene_c2", kwargs={"seed": 1234, "sigma": 2.0}, families=["tag36h11"], decimate=1),
     "c2_seed1240_sigma2_dec2": dict(scene="scene_c2", kwargs={"seed": 1240, "sigma": 2.0}, families=["tag36h11"], decimate=2),
+    "c2_high_ids_sigma2": dict(scene="scene_c2_ids", kwargs={"ids": [100, 137, 211, 298, 333, 402, 467, 511, 560, 586], "seed": 1301, "sigma": 2.0},
+                               families=["tag36h11"], decimate=1),
     "c5_two_families": dict(scene="scene_c5", kwargs={"seed": 1234, "sigma": 2.0}, families=["tag36h11", "tag25h9"], decimate=1),
 }
 
