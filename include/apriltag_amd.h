@@ -62,10 +62,14 @@ typedef enum {
   AMDAT_TAG36H11 = 0,   /* 587 codes (include/apriltag_amd_families.h states the provenance of every table) */
   AMDAT_TAG25H9 = 1,    /* 35 codes */
   AMDAT_TAG16H5 = 2,    /* 30 codes */
-  AMDAT_TAG36H10 = 3,   /* 2320 codes */
-  AMDAT_CUSTOM0 = 4,    /* slots filled by amdAprilTagsRegisterFamily */
+  AMDAT_TAG36H10 = 3,   /* no built-in table: the offline regeneration does not reproduce the published 2320 codes
+                         * (include/apriltag_amd_families.h); the slot accepts a table through amdAprilTagsRegisterFamily */
+  AMDAT_CUSTOM0 = 4,    /* slots filled by amdAprilTagsRegisterFamily[Ex] */
   AMDAT_CUSTOM1 = 5,
-  AMDAT_ENUM_SIZE = 6
+  AMDAT_CUSTOM2 = 6,
+  AMDAT_CUSTOM3 = 7,
+  AMDAT_CUSTOM4 = 8,
+  AMDAT_ENUM_SIZE = 9
 } amdAprilTagsFamily;
 
 typedef struct {
@@ -197,6 +201,18 @@ int amdAprilTagsCopyToDevice(void* dst_dev, const void* src_host, size_t bytes, 
 /* Registers a tag family as data (row-major codes, MSB = top-left data cell) in a custom slot. */
 int amdAprilTagsRegisterFamily(amdAprilTagsFamily slot, const char* name, uint32_t data_bits_per_side,
                                const uint64_t* codes, uint32_t ncodes);
+/* The same for an AprilTag-3 style layout -- what the circle / standard / custom families of the reference's table
+ * (src/apriltag_node.cpp:47-58: circle21h7, circle49h12, custom48h12, standard41h12, standard52h13) need: nbits data bits
+ * (<= 64), bit i at cell (bit_x[i], bit_y[i]) in border coordinates ((0, 0) = top-left cell of the border square of
+ * width_at_border cells; cells of outer rings are negative or >= width_at_border), total_width cells across everything
+ * (<= 12, same parity as width_at_border), reversed_border != 0 when the border square is white inside a black ring.
+ * Bit (nbits - 1 - i) of a code is data bit i (AprilTag 3's own convention), 1 = white.  The layout must map onto itself
+ * under the quarter turn (x, y) -> (width_at_border - 1 - y, x); AMDAT_INVALID_ARGUMENT otherwise.  This library ships
+ * no code tables for those five families (none can be verified offline); a host that has them registers them here under
+ * the reference's names and amdAprilTagsFamilyFromName / the node shell find them. */
+int amdAprilTagsRegisterFamilyEx(amdAprilTagsFamily slot, const char* name, uint32_t nbits, const int8_t* bit_x,
+                                 const int8_t* bit_y, uint32_t width_at_border, uint32_t total_width, int reversed_border,
+                                 const uint64_t* codes, uint32_t ncodes);
 /* Family metadata: returns 0 and fills the outputs if the family is known. */
 int amdAprilTagsFamilyInfo(amdAprilTagsFamily family, const char** name, uint32_t* data_bits_per_side,
                            uint32_t* ncodes, const uint64_t** codes);
@@ -204,40 +220,9 @@ int amdAprilTagsFamilyInfo(amdAprilTagsFamily family, const char** name, uint32_
  * or without an offline codebook. */
 int amdAprilTagsFamilyFromName(const char* name);
 
-/* ---- measurement ------------------------------------------------------------------------- */
-#define AMDAT_NUM_STAGES 12
-/* Stage names, index-aligned with amdAprilTagsGetStageMs. */
-const char* amdAprilTagsStageName(uint32_t stage);
-/* enable != 0: bracket every stage of subsequent submissions with HIP events on the submission
- * stream.  enable == 2 additionally accumulates per-phase shader-cycle counters inside the quad-fit
- * kernel (AMDAT_DBG_FQPROF; perturbs its timing). */
-int amdAprilTagsSetProfiling(amdAprilTagsHandle handle, int enable);
-/* Milliseconds per stage of the last submission (AMDAT_NUM_STAGES floats). */
-int amdAprilTagsGetStageMs(amdAprilTagsHandle handle, float* ms);
-/* Runs only the threshold pass (S1+S2) on n frames; used by the roofline measurement. */
-int amdAprilTagsThresholdOnly(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
-                              amdAprilTagsStream stream);
-
-/* ---- stage inspection (parity tests) ------------------------------------------------------ */
-typedef enum {
-  AMDAT_DBG_GRAY = 0,      /* u8  w*h working gray image */
-  AMDAT_DBG_THRESH = 1,    /* u8  w*h */
-  AMDAT_DBG_LABEL = 2,     /* u32 w*h canonical representative or 0xFFFFFFFF */
-  AMDAT_DBG_CSIZE = 3,     /* u32 w*h, valid at representatives */
-  AMDAT_DBG_CLUSTERS = 4,  /* {u64 key; u32 start; u32 count} x nclusters */
-  AMDAT_DBG_POINTS = 5,    /* u32 packed points, grouped by cluster */
-  AMDAT_DBG_QUADS = 6,     /* {float p[4][2]; i32 reversed_border; u32 pad; u64 key} x nquads */
-  AMDAT_DBG_COUNTS = 7,    /* u32[8]: npoints_raw, nclusters, npoints_kept, nquads, ndets, flags, w, h */
-  AMDAT_DBG_FQPROF = 8     /* u64[64]: shader-cycle totals, 8 phases x up to 8 size classes of the quad-fit kernel (profiling on) */
-} amdAprilTagsDebugBuffer;
-/* Copies an intermediate buffer of frame `frame` of the last submission to host memory.
- * Returns the number of bytes the buffer holds through *bytes (copy truncated to capacity). */
-int amdAprilTagsDebugCopy(amdAprilTagsHandle handle, uint32_t frame, amdAprilTagsDebugBuffer what,
-                          void* host_dst, size_t capacity, size_t* bytes);
-/* Device-arithmetic self check: op 0 = sqrt(f64), 1 = a/b (f64), 2 = sqrtf(f32 bits in low word),
- * 3 = a/b (f32), 4 = a/b (f64) through the shared-reciprocal sequence the line fit uses, 5 = square root of the
- * integer a < 2^18 through the line-fit weights' f32-seeded sequence.  n pairs in, n results out (host pointers). */
-int amdAprilTagsDebugMath(int op, uint32_t n, const double* a, const double* b, double* out);
+/* Measurement and stage-inspection entry points (profiling, the threshold-only launch of the roofline measurement,
+ * intermediate buffers, the device arithmetic self check) are declared in apriltag_amd_debug.h: they are exported by
+ * the same library but are not part of the detector boundary a node binds. */
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libapriltag_amd.so")
 
 NUM_STAGES = 12
-FAMILY_ENUM = {"tag36h11": 0, "tag25h9": 1, "tag16h5": 2, "tag36h10": 3}
+FAMILY_ENUM = {"tag36h11": 0, "tag25h9": 1, "tag16h5": 2}
+SLOT_TAG36H10, SLOT_CUSTOM0 = 3, 4   # registrable slots: 3 (tag36h10: no built-in table) and 4..8
 (DBG_GRAY, DBG_THRESH, DBG_LABEL, DBG_CSIZE, DBG_CLUSTERS, DBG_POINTS, DBG_QUADS, DBG_COUNTS) = range(8)
 
 STATUS = {0: "AMDAT_SUCCESS", 1: "AMDAT_INVALID_ARGUMENT", 2: "AMDAT_UNSUPPORTED", 3: "AMDAT_HIP_ERROR",
@@ -56,6 +57,7 @@ class Config(C.Structure):
 EXPORTS = ["amdAprilTagsDefaultConfig", "amdCreateAprilTagsDetector", "amdCreateAprilTagsDetectorEx",
            "amdAprilTagsDestroy", "amdAprilTagsDetect", "amdAprilTagsDetectBatch", "amdAprilTagsDetectBatchEx",
            "amdAprilTagsGetFrameFlags", "amdAprilTagsConvertToMono8", "amdAprilTagsRegisterFamily",
+           "amdAprilTagsRegisterFamilyEx",
            "amdAprilTagsFamilyInfo", "amdAprilTagsFamilyFromName", "amdAprilTagsStageName",
            "amdAprilTagsSetProfiling", "amdAprilTagsGetStageMs", "amdAprilTagsThresholdOnly",
            "amdAprilTagsDebugCopy", "amdAprilTagsDebugMath", "amdAprilTagsDeviceAlloc", "amdAprilTagsDeviceFree",
@@ -90,6 +92,8 @@ def lib():
     L.amdAprilTagsConvertToMono8.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                              C.c_size_t, H]
     L.amdAprilTagsRegisterFamily.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32]
+    L.amdAprilTagsRegisterFamilyEx.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.c_uint32,
+                                               C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.c_uint32]
     L.amdAprilTagsFamilyInfo.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32),
                                          C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint64))]
     L.amdAprilTagsFamilyFromName.argtypes = [C.c_char_p]
@@ -139,6 +143,22 @@ def family_info(name_or_enum):
     nm, d, n, codes = C.c_char_p(), C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint64)()
     _check("amdAprilTagsFamilyInfo", L.amdAprilTagsFamilyInfo(fam, C.byref(nm), C.byref(d), C.byref(n), C.byref(codes)))
     return {"enum": fam, "name": nm.value.decode(), "d": d.value, "codes": [int(codes[i]) for i in range(n.value)]}
+
+
+def register_family(slot, name, d, codes):
+    """Classic d x d family (row-major codes) in a registrable slot."""
+    cc = (C.c_uint64 * len(codes))(*[int(c) for c in codes])
+    _check("amdAprilTagsRegisterFamily", lib().amdAprilTagsRegisterFamily(slot, name.encode(), d, cc, len(codes)))
+
+
+def register_family_ex(slot, name, bit_x, bit_y, width_at_border, total_width, reversed_border, codes):
+    """AprilTag-3 style layout (bit i at cell (bit_x[i], bit_y[i]) in border coordinates)."""
+    n = len(bit_x)
+    bx = (C.c_int8 * n)(*[int(v) for v in bit_x])
+    by = (C.c_int8 * n)(*[int(v) for v in bit_y])
+    cc = (C.c_uint64 * len(codes))(*[int(c) for c in codes])
+    _check("amdAprilTagsRegisterFamilyEx", lib().amdAprilTagsRegisterFamilyEx(slot, name.encode(), n, bx, by, width_at_border, total_width,
+                                                                             int(bool(reversed_border)), cc, len(codes)))
 
 
 def debug_math(op, a, b):

@@ -71,6 +71,10 @@ struct FamilyDev {
   int32_t reversed_border;
   uint32_t ncodes;
   const uint64_t* codes;  // device pointer
+  // AprilTag-3 style layout: cell of data bit i in border coordinates, and the bit that the 90-degree pattern rotation
+  // moves onto bit i (new(x, y) = old(width_at_border - 1 - y, x)); classic families: (1 + i % d, 1 + i / d)
+  int8_t bit_x[64], bit_y[64];
+  uint8_t rot_src[64];
 };
 
 // Geometry + algorithm parameters shared by all kernels of a handle.

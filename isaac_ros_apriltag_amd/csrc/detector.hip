@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/apriltag_amd.h"
+#include "../../include/apriltag_amd_debug.h"
 #include "../../include/apriltag_amd_families.h"
 #include "common.h"
 #include "kernels_cc.h"
@@ -44,36 +45,56 @@ static_assert(sizeof(ClusterRec) == 16, "ClusterRec layout");
 namespace {
 struct FamilyHost {
   const char* name = nullptr;
-  uint32_t d = 0;
+  uint32_t d = 0;            // data cells per side of a classic family, 0 for other layouts
+  uint32_t nbits = 0, width_at_border = 0, total_width = 0;
+  int reversed_border = 0;
+  int8_t bit_x[64] = {0}, bit_y[64] = {0};
+  uint8_t rot_src[64] = {0};
   uint32_t ncodes = 0;
   const uint64_t* codes = nullptr;
   std::vector<uint64_t> owned;
   char name_buf[32] = {0};
 };
+// Fills the rotation table; false if the layout does not map onto itself under (x, y) -> (wb - 1 - y, x) or repeats a cell.
+bool family_finish_layout(FamilyHost& f) {
+  for (uint32_t i = 0; i < f.nbits; i++) {
+    const int sx = (int)f.width_at_border - 1 - f.bit_y[i], sy = f.bit_x[i];
+    int src = -1;
+    for (uint32_t j = 0; j < f.nbits; j++) {
+      if (f.bit_x[j] == sx && f.bit_y[j] == sy) src = (int)j;
+      if (j < i && f.bit_x[j] == f.bit_x[i] && f.bit_y[j] == f.bit_y[i]) return false;
+    }
+    if (src < 0) return false;
+    f.rot_src[i] = (uint8_t)src;
+  }
+  return true;
+}
+void family_set_classic(FamilyHost& f, uint32_t d) {
+  f.d = d; f.nbits = d * d; f.width_at_border = d + 2; f.total_width = d + 4; f.reversed_border = 0;
+  for (uint32_t i = 0; i < f.nbits; i++) { f.bit_x[i] = (int8_t)(1 + i % d); f.bit_y[i] = (int8_t)(1 + i / d); }
+  family_finish_layout(f);
+}
 FamilyHost g_families[AMDAT_ENUM_SIZE];
 std::once_flag g_fam_once;
 std::mutex g_fam_mutex;
 
 void init_families() {
   g_families[AMDAT_TAG36H11].name = "tag36h11";
-  g_families[AMDAT_TAG36H11].d = 6;
+  family_set_classic(g_families[AMDAT_TAG36H11], 6);
   g_families[AMDAT_TAG36H11].ncodes = APRILTAG_AMD_TAG36H11_NCODES;
   g_families[AMDAT_TAG36H11].codes = apriltag_amd_tag36h11_codes;
   g_families[AMDAT_TAG25H9].name = "tag25h9";
-  g_families[AMDAT_TAG25H9].d = 5;
+  family_set_classic(g_families[AMDAT_TAG25H9], 5);
   g_families[AMDAT_TAG25H9].ncodes = APRILTAG_AMD_TAG25H9_NCODES;
   g_families[AMDAT_TAG25H9].codes = apriltag_amd_tag25h9_codes;
   g_families[AMDAT_TAG16H5].name = "tag16h5";
-  g_families[AMDAT_TAG16H5].d = 4;
+  family_set_classic(g_families[AMDAT_TAG16H5], 4);
   g_families[AMDAT_TAG16H5].ncodes = APRILTAG_AMD_TAG16H5_NCODES;
   g_families[AMDAT_TAG16H5].codes = apriltag_amd_tag16h5_codes;
-#ifdef APRILTAG_AMD_TAG36H10_NCODES
-  g_families[AMDAT_TAG36H10].name = "tag36h10";
-  g_families[AMDAT_TAG36H10].d = 6;
-  g_families[AMDAT_TAG36H10].ncodes = APRILTAG_AMD_TAG36H10_NCODES;
-  g_families[AMDAT_TAG36H10].codes = apriltag_amd_tag36h10_codes;
-#endif
+  // (AMDAT_TAG36H10 starts empty: see the header)
 }
+
+bool is_registrable_slot(int slot) { return slot == AMDAT_TAG36H10 || (slot >= AMDAT_CUSTOM0 && slot < AMDAT_ENUM_SIZE); }
 
 const char* kStageNames[AMDAT_NUM_STAGES] = {"upload_clear", "threshold", "cc_local",  "cc_border",
                                              "cc_sizes",   "points",    "cluster_select", "scatter",
@@ -222,16 +243,45 @@ void amdAprilTagsDefaultConfig(amdAprilTagsConfig_t* cfg, uint32_t width, uint32
 
 int amdAprilTagsRegisterFamily(amdAprilTagsFamily slot, const char* name, uint32_t d, const uint64_t* codes, uint32_t ncodes) {
   std::call_once(g_fam_once, init_families);
-  if (slot != AMDAT_CUSTOM0 && slot != AMDAT_CUSTOM1) return AMDAT_INVALID_ARGUMENT;
+  if (!is_registrable_slot((int)slot)) return AMDAT_INVALID_ARGUMENT;
   if (!name || !codes || ncodes == 0 || d < 3 || d > 7) return AMDAT_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> lk(g_fam_mutex);
   FamilyHost& f = g_families[slot];
   f.owned.assign(codes, codes + ncodes);
   strncpy(f.name_buf, name, sizeof(f.name_buf) - 1);
   f.name = f.name_buf;
-  f.d = d;
+  family_set_classic(f, d);
   f.ncodes = ncodes;
   f.codes = f.owned.data();
+  return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsRegisterFamilyEx(amdAprilTagsFamily slot, const char* name, uint32_t nbits, const int8_t* bit_x, const int8_t* bit_y,
+                                 uint32_t width_at_border, uint32_t total_width, int reversed_border, const uint64_t* codes,
+                                 uint32_t ncodes) {
+  std::call_once(g_fam_once, init_families);
+  if (!is_registrable_slot((int)slot)) return AMDAT_INVALID_ARGUMENT;
+  if (!name || !bit_x || !bit_y || !codes || ncodes == 0 || nbits == 0 || nbits > 64) return AMDAT_INVALID_ARGUMENT;
+  if (width_at_border < 3 || total_width < width_at_border || total_width > 12 || ((total_width - width_at_border) & 1u))
+    return AMDAT_INVALID_ARGUMENT;
+  FamilyHost f;
+  f.d = 0; f.nbits = nbits; f.width_at_border = width_at_border; f.total_width = total_width; f.reversed_border = reversed_border ? 1 : 0;
+  const int min_coord = ((int)width_at_border - (int)total_width) / 2;
+  for (uint32_t i = 0; i < nbits; i++) {
+    if (bit_x[i] < min_coord || bit_x[i] >= min_coord + (int)total_width || bit_y[i] < min_coord || bit_y[i] >= min_coord + (int)total_width)
+      return AMDAT_INVALID_ARGUMENT;
+    f.bit_x[i] = bit_x[i]; f.bit_y[i] = bit_y[i];
+  }
+  if (!family_finish_layout(f)) return AMDAT_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(g_fam_mutex);
+  FamilyHost& g = g_families[slot];
+  g = f;
+  g.owned.assign(codes, codes + ncodes);
+  strncpy(g.name_buf, name, sizeof(g.name_buf) - 1);
+  g.name_buf[sizeof(g.name_buf) - 1] = 0;
+  g.name = g.name_buf;
+  g.ncodes = ncodes;
+  g.codes = g.owned.data();
   return AMDAT_SUCCESS;
 }
 
@@ -249,7 +299,8 @@ int amdAprilTagsFamilyFromName(const char* name) {
   std::call_once(g_fam_once, init_families);
   if (!name) return -1;
   // registered tables take precedence over a built-in of the same name
-  static const int scan[AMDAT_ENUM_SIZE] = {AMDAT_CUSTOM0, AMDAT_CUSTOM1, AMDAT_TAG36H11, AMDAT_TAG25H9, AMDAT_TAG16H5, AMDAT_TAG36H10};
+  static const int scan[AMDAT_ENUM_SIZE] = {AMDAT_CUSTOM0, AMDAT_CUSTOM1, AMDAT_CUSTOM2, AMDAT_CUSTOM3, AMDAT_CUSTOM4,
+                                            AMDAT_TAG36H10, AMDAT_TAG36H11, AMDAT_TAG25H9, AMDAT_TAG16H5};
   for (int k = 0; k < AMDAT_ENUM_SIZE; k++) {
     const int i = scan[k];
     if (g_families[i].codes && g_families[i].name && !strcmp(g_families[i].name, name)) return i;
@@ -332,10 +383,11 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   int min_tag_width = 1000000;
   for (int i = 0; i < P.nfam; i++) {
     const FamilyHost& f = g_families[cfg.families[i]];
-    P.fam[i].d = f.d; P.fam[i].nbits = f.d * f.d; P.fam[i].width_at_border = f.d + 2; P.fam[i].total_width = f.d + 4;
-    P.fam[i].reversed_border = 0; P.fam[i].ncodes = f.ncodes;
+    P.fam[i].d = f.d; P.fam[i].nbits = f.nbits; P.fam[i].width_at_border = f.width_at_border; P.fam[i].total_width = f.total_width;
+    P.fam[i].reversed_border = f.reversed_border; P.fam[i].ncodes = f.ncodes;
+    memcpy(P.fam[i].bit_x, f.bit_x, 64); memcpy(P.fam[i].bit_y, f.bit_y, 64); memcpy(P.fam[i].rot_src, f.rot_src, 64);
     if ((int)P.fam[i].width_at_border < min_tag_width) min_tag_width = (int)P.fam[i].width_at_border;
-    P.normal_border |= 1;
+    if (f.reversed_border) P.reversed_border |= 1; else P.normal_border |= 1;
   }
   min_tag_width = (int)((float)min_tag_width / (float)P.decimate);
   if (min_tag_width < 3) min_tag_width = 3;

@@ -59,17 +59,6 @@ __device__ __forceinline__ double value_for_pixel_dev(ImgPtr im, int w, int h, i
          im[(size_t)y2 * pitch + x1] * (1 - x) * y + im[(size_t)y2 * pitch + x2] * x * y;
 }
 
-__device__ __forceinline__ uint64_t rotate90_dev(uint64_t w, int d) {
-  uint64_t o = 0;
-  const int nb = d * d;
-  for (int r = 0; r < d; r++)
-    for (int c = 0; c < d; c++) {
-      const int sr = c, sc = d - 1 - r;
-      if ((w >> (nb - 1 - (sr * d + sc))) & 1) o |= 1ull << (nb - 1 - (r * d + c));
-    }
-  return o;
-}
-
 // ---- S8 reconcile + S9 pose ---------------------------------------------------------------------
 __device__ __forceinline__ double orient2d_dev(const double* a, const double* b, const double* c) {
   return (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0]);

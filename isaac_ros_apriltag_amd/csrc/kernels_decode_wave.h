@@ -189,10 +189,10 @@ __global__ __launch_bounds__(64, DW_WPE) void k_decode_wave(const FrameDesc* __r
 
     // ---- S7 decode, once per enabled family ----------------------------------------------------
     for (int fi = 0; fi < P.nfam; fi++) {
-      const FamilyDev fam = P.fam[fi];
+      const FamilyDev& fam = P.fam[fi];   // (kernel argument: uniform loads)
       if ((fam.reversed_border != 0) != (q.reversed_border != 0)) continue;
       __syncthreads();
-      const int wb = (int)fam.width_at_border, tw = (int)fam.total_width, d = (int)fam.d, nbits = (int)fam.nbits;
+      const int wb = (int)fam.width_at_border, tw = (int)fam.total_width, nbits = (int)fam.nbits;
       // border samples of the two gray models: 8 lines x wb samples
       const int nsamp = 8 * wb;
       for (int sidx = lane; sidx < nsamp; sidx += 64) {
@@ -236,11 +236,14 @@ __global__ __launch_bounds__(64, DW_WPE) void k_decode_wave(const FrameDesc* __r
       blackmodel.C0 = s_C[1][0]; blackmodel.C1 = s_C[1][1]; blackmodel.C2 = s_C[1][2];
       if ((graymodel_interp_dev(whitemodel, 0, 0) - graymodel_interp_dev(blackmodel, 0, 0) < 0) != (fam.reversed_border != 0)) continue;
 
-      // data bits: one lane per bit (nbits <= 49)
+      // data bits: one lane per bit (nbits <= 64), cells from the family's layout
       const int min_coord = (wb - tw) / 2;
       int gx = 0, gy = 0;
+      // (the layout arrays are indexed per lane: packed four to a dword in the kernel arguments)
+      const int bitx = (int)(int8_t)(reinterpret_cast<const uint32_t*>(fam.bit_x)[(lane & 63) >> 2] >> (8 * (lane & 3)));
+      const int bity = (int)(int8_t)(reinterpret_cast<const uint32_t*>(fam.bit_y)[(lane & 63) >> 2] >> (8 * (lane & 3)));
+      const int rsrc = (int)(uint8_t)(reinterpret_cast<const uint32_t*>(fam.rot_src)[(lane & 63) >> 2] >> (8 * (lane & 3)));
       if (lane < nbits) {
-        const int bitx = 1 + lane % d, bity = 1 + lane / d;
         gx = bitx - min_coord; gy = bity - min_coord;
         const double tagx01 = (bitx + 0.5) / wb, tagy01 = (bity + 0.5) / wb;
         const double tagx = 2 * (tagx01 - 0.5), tagy = 2 * (tagy01 - 0.5);
@@ -289,7 +292,10 @@ __global__ __launch_bounds__(64, DW_WPE) void k_decode_wave(const FrameDesc* __r
           if (ob < best || (ob == best && oi < bid)) { best = ob; bid = oi; }
         }
         if (best <= P.max_hamming) { id = bid; hamming = best; rotation = r; found = true; }
-        else rcode = rotate90_dev(rcode, d);
+        else {   // pattern rotated by 90 degrees: bit i takes the value of bit rot_src[i]
+          const bool rb = lane < nbits && ((rcode >> (nbits - 1 - rsrc)) & 1ull);
+          rcode = __brevll(__ballot(rb)) >> (64 - nbits);
+        }
       }
       const float ma = white_score / white_count, mb = black_score / black_count;
       const float margin = ma < mb ? ma : mb;

@@ -61,6 +61,36 @@ int ato_builtin_family(const char* name, ato_family_t* out) {
   out->width_at_border = out->d + 2;
   out->total_width = out->d + 4;
   out->reversed_border = 0;
+  for (uint32_t i = 0; i < out->nbits; i++) { out->bit_x[i] = (int8_t)(1 + i % out->d); out->bit_y[i] = (int8_t)(1 + i / out->d); }
+  return 0;
+}
+
+/* index of the data bit that the 90-degree pattern rotation moves onto bit i: new(x, y) = old(wb - 1 - y, x)
+ * (for a classic d x d family this is new(r, c) = old(c, d - 1 - r)); -1 if the layout has no such cell */
+static int rot_source(const ato_family_t* f, int i) {
+  int sx = (int)f->width_at_border - 1 - f->bit_y[i], sy = f->bit_x[i];
+  for (uint32_t j = 0; j < f->nbits; j++)
+    if (f->bit_x[j] == sx && f->bit_y[j] == sy) return (int)j;
+  return -1;
+}
+
+int ato_custom_family(const char* name, uint32_t nbits, const int8_t* bit_x, const int8_t* bit_y, uint32_t width_at_border,
+                      uint32_t total_width, int reversed_border, const uint64_t* codes, uint32_t ncodes, ato_family_t* out) {
+  memset(out, 0, sizeof(*out));
+  if (!name || !bit_x || !bit_y || !codes || nbits == 0 || nbits > 64 || ncodes == 0) return -1;
+  if (width_at_border < 3 || total_width < width_at_border || total_width > 12 || ((total_width - width_at_border) & 1)) return -1;
+  strncpy(out->name, name, sizeof(out->name) - 1);
+  out->nbits = nbits; out->d = 0; out->width_at_border = width_at_border; out->total_width = total_width;
+  out->reversed_border = reversed_border ? 1 : 0; out->ncodes = ncodes; out->codes = codes;
+  int min_coord = ((int)width_at_border - (int)total_width) / 2;
+  for (uint32_t i = 0; i < nbits; i++) {
+    if (bit_x[i] < min_coord || bit_x[i] >= min_coord + (int)total_width || bit_y[i] < min_coord || bit_y[i] >= min_coord + (int)total_width) return -1;
+    out->bit_x[i] = bit_x[i]; out->bit_y[i] = bit_y[i];
+  }
+  for (uint32_t i = 0; i < nbits; i++) {
+    if (rot_source(out, (int)i) < 0) return -1;
+    for (uint32_t j = 0; j < i; j++) if (bit_x[j] == bit_x[i] && bit_y[j] == bit_y[i]) return -1;
+  }
   return 0;
 }
 
@@ -950,15 +980,14 @@ static double value_for_pixel(const uint8_t* im, int w, int h, int pitch, double
          im[(size_t)y2 * pitch + x1] * (1 - x) * y + im[(size_t)y2 * pitch + x2] * x * y;
 }
 
-/* pattern rotation used by the code lookup: new(r,c) = old(c, d-1-r) */
-static uint64_t rotate90(uint64_t w, int d) {
+/* pattern rotation used by the code lookup (see rot_source) */
+static uint64_t rotate90(const ato_family_t* f, uint64_t w) {
   uint64_t o = 0;
-  int nb = d * d;
-  for (int r = 0; r < d; r++)
-    for (int c = 0; c < d; c++) {
-      int sr = c, sc = d - 1 - r;
-      if ((w >> (nb - 1 - (sr * d + sc))) & 1) o |= 1ULL << (nb - 1 - (r * d + c));
-    }
+  int nb = (int)f->nbits;
+  for (int i = 0; i < nb; i++) {
+    int j = rot_source(f, i);
+    if (j >= 0 && ((w >> (nb - 1 - j)) & 1)) o |= 1ULL << (nb - 1 - i);
+  }
   return o;
 }
 
@@ -972,7 +1001,7 @@ static int decode_codeword(const ato_family_t* fam, uint64_t rcode, int max_hamm
       if (hd < best) { best = hd; bid = (int)i; }
     }
     if (best <= max_hamming) { *id = bid; *hamming = best; *rotation = r; return 1; }
-    rcode = rotate90(rcode, (int)fam->d);
+    rcode = rotate90(fam, rcode);
   }
   return 0;
 }
@@ -1020,7 +1049,7 @@ static float quad_decode(const ato_params_t* prm, const ato_family_t* fam, const
   int min_coord = (wb - tw) / 2;
   int d = (int)fam->d;
   for (int i = 0; i < (int)fam->nbits; i++) {
-    int bitx = 1 + i % d, bity = 1 + i / d;
+    int bitx = fam->bit_x[i], bity = fam->bit_y[i];
     double tagx01 = (bitx + 0.5) / wb, tagy01 = (bity + 0.5) / wb;
     double tagx = 2 * (tagx01 - 0.5), tagy = 2 * (tagy01 - 0.5);
     double px, py;
@@ -1048,7 +1077,7 @@ static float quad_decode(const ato_params_t* prm, const ato_family_t* fam, const
   }
   float black_score = 0, white_score = 0, black_count = 1, white_count = 1;
   uint64_t rcode = 0;
-  if (prm->variant & ATO_VAR_AT3_BIT_ORDER) {
+  if ((prm->variant & ATO_VAR_AT3_BIT_ORDER) && d > 0) {
     /* AprilTag 3 numbers the data bits quadrant by quadrant: rows y = 1 + l, x = 1 + l .. d - 1 - l of the top triangle,
      * then the same triangle rotated by 90, 180, 270 degrees ((x, y) -> (d + 1 - y, x)), the centre bit of an odd d last.
      * The code word itself stays row-major here (this restatement's tables are); only the order of the float score
@@ -1074,7 +1103,7 @@ static float quad_decode(const ato_params_t* prm, const ato_family_t* fam, const
     }
   } else
   for (int i = 0; i < (int)fam->nbits; i++) {
-    int bitx = 1 + i % d, bity = 1 + i / d;
+    int bitx = fam->bit_x[i], bity = fam->bit_y[i];
     rcode <<= 1;
     double v = values[(bity - min_coord) * tw + bitx - min_coord];
     if (v > 0) { white_score = (float)((double)white_score + v); white_count++; rcode |= 1; }

@@ -37,7 +37,11 @@ typedef struct {
   uint32_t total_width;      /* incl. white quiet ring (d + 4) */
   int32_t reversed_border;   /* 0 for the classic families */
   uint32_t ncodes;
-  const uint64_t* codes;     /* row-major, MSB = top-left data cell, 1 = white */
+  const uint64_t* codes;     /* bit (nbits-1-i) of a code is data cell i (classic: row-major), 1 = white */
+  /* AprilTag-3 layout: cell of data bit i in border coordinates ((0,0) = top-left cell of the border square, cells of the
+   * outer rings are negative or >= width_at_border).  Classic families: (1 + i % d, 1 + i / d); d = 0 for layouts that are
+   * not a d x d square.  A layout must map onto itself under (x, y) -> (width_at_border - 1 - y, x). */
+  int8_t bit_x[64], bit_y[64];
 } ato_family_t;
 
 typedef struct {
@@ -116,6 +120,10 @@ typedef struct {
 void ato_default_params(ato_params_t* p);
 /* Built-in family tables (include/apriltag_amd_families.h). Returns 0 on success. */
 int ato_builtin_family(const char* name, ato_family_t* out);
+/* A family given as data (AprilTag-3 style layout); codes must stay valid while the family is used.  Returns 0, or -1 if
+ * the layout is not closed under the 90-degree rotation or does not fit (nbits <= 64, total_width <= 12). */
+int ato_custom_family(const char* name, uint32_t nbits, const int8_t* bit_x, const int8_t* bit_y, uint32_t width_at_border,
+                      uint32_t total_width, int reversed_border, const uint64_t* codes, uint32_t ncodes, ato_family_t* out);
 
 /* stage entry points (each follows the cited public algorithm step) */
 void ato_decimate(const uint8_t* in, int w, int h, int pitch, int f, uint8_t* out, int* sw, int* sh);

@@ -17,7 +17,7 @@ class Family(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("nbits", C.c_uint32), ("d", C.c_uint32),
                 ("width_at_border", C.c_uint32), ("total_width", C.c_uint32),
                 ("reversed_border", C.c_int32), ("ncodes", C.c_uint32),
-                ("codes", C.POINTER(C.c_uint64))]
+                ("codes", C.POINTER(C.c_uint64)), ("bit_x", C.c_int8 * 64), ("bit_y", C.c_int8 * 64)]
 
 
 class Params(C.Structure):
@@ -77,6 +77,9 @@ def lib():
         _lib.ato_default_params.argtypes = [C.POINTER(Params)]
         _lib.ato_builtin_family.argtypes = [C.c_char_p, C.POINTER(Family)]
         _lib.ato_builtin_family.restype = C.c_int
+        _lib.ato_custom_family.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.c_uint32, C.c_uint32,
+                                           C.c_int, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(Family)]
+        _lib.ato_custom_family.restype = C.c_int
         _lib.ato_detect.argtypes = [C.POINTER(Params), C.POINTER(Family), C.c_int, C.c_void_p, C.c_int,
                                     C.c_int, C.c_int, C.POINTER(Detection), C.c_int, C.POINTER(Dump)]
         _lib.ato_detect.restype = C.c_int
@@ -109,6 +112,20 @@ def family(name):
     f = Family()
     if lib().ato_builtin_family(name.encode(), C.byref(f)) != 0:
         raise ValueError("unknown family %r" % name)
+    return f
+
+
+def custom_family(name, bit_x, bit_y, width_at_border, total_width, reversed_border, codes):
+    """An AprilTag-3 style family given as data (bit i of the layout <-> bit nbits-1-i of a code)."""
+    n = len(bit_x)
+    bx = (C.c_int8 * n)(*[int(v) for v in bit_x])
+    by = (C.c_int8 * n)(*[int(v) for v in bit_y])
+    cc = (C.c_uint64 * len(codes))(*[int(c) for c in codes])
+    f = Family()
+    if lib().ato_custom_family(name.encode(), n, bx, by, width_at_border, total_width, int(bool(reversed_border)), cc, len(codes),
+                               C.byref(f)) != 0:
+        raise ValueError("layout rejected (not closed under rotation, or out of range)")
+    f._keep = (bx, by, cc)   # the struct points into cc
     return f
 
 
@@ -192,7 +209,9 @@ def detect(img, families=("tag36h11",), params=None, max_det=1024, want_dump=Fal
     assert img.ndim == 2 and img.strides[1] == 1
     h, w = img.shape
     prm = params if params is not None else default_params()
-    fams = (Family * len(families))(*[family(n) for n in families])
+    fam_objs = [f if isinstance(f, Family) else family(f) for f in families]   # names of built-ins or custom_family() objects
+    fams = (Family * len(families))(*fam_objs)
+    families = [f.name.decode() if isinstance(f, Family) else f for f in families]
     out = (Detection * max_det)()
     dump = Dump() if want_dump else None
     n = lib().ato_detect(C.byref(prm), fams, len(families), img.ctypes.data, w, h, img.strides[0], out, max_det,

@@ -1,0 +1,121 @@
+"""AprilTag-3 style family layouts for tests (data only; no code tables of real families exist offline).
+
+standard_layout(total, border) -> (bit_x, bit_y): the shape of AprilTag 3's "standard" families -- data bits on the
+outermost ring of a total x total grid and in the square inside the border ring -- numbered the way AprilTag 3 numbers
+bits: four quarter-turn copies of one wedge, the centre cell last.  Coordinates are border coordinates ((0, 0) = top-left
+cell of the border square of `border` cells).  toy_codes() draws code words with a minimum Hamming distance over all four
+rotations, so that ids decode uniquely."""
+import numpy as np
+
+
+def _quarter_turns(cells, wb):
+    """cells of one wedge -> the four rotated copies, in AprilTag 3's order (wedge, then each quarter turn)."""
+    out = []
+    cur = list(cells)
+    for _ in range(4):
+        out += cur
+        cur = [(wb - 1 - y, x) for (x, y) in cur]
+    return out
+
+
+def standard_layout(total, border):
+    m = (border - total) // 2                     # min coordinate (negative)
+    hi = m + total - 1
+    wedge = [(x, m) for x in range(m, hi)]        # top row of the outer ring without its last cell
+    inner = border - 2                            # data square inside the border ring: cells 1 .. border - 2
+    for l in range((inner + 1) // 2):
+        y = 1 + l
+        for x in range(1 + l, border - 2 - l):
+            wedge.append((x, y))
+    cells = _quarter_turns(wedge, border)
+    if inner % 2 == 1:
+        c = (border - 1) // 2
+        cells = [p for p in cells if p != (c, c)] + [(c, c)]
+    seen = []
+    for p in cells:
+        if p not in seen:
+            seen.append(p)
+    return [p[0] for p in seen], [p[1] for p in seen]
+
+
+def rot_source(bx, by, wb):
+    idx = {(x, y): i for i, (x, y) in enumerate(zip(bx, by))}
+    return [idx[(wb - 1 - y, x)] for x, y in zip(bx, by)]
+
+
+def rotate_code(code, src):
+    n = len(src)
+    out = 0
+    for i in range(n):
+        if (code >> (n - 1 - src[i])) & 1:
+            out |= 1 << (n - 1 - i)
+    return out
+
+
+def toy_codes(nbits, count, seed=1, min_dist=10, layout=None):
+    """`count` random code words whose four rotations keep `min_dist` bits apart from every other word's (and from the
+    word's own other rotations).  layout = (bit_x, bit_y, width_at_border) of the family; without it only distinctness
+    is enforced."""
+    rng = np.random.default_rng(seed)
+    src = rot_source(layout[0], layout[1], layout[2]) if layout else None
+    codes, rots = [], []
+    while len(codes) < count:
+        c = int(rng.integers(0, 1 << 62)) & ((1 << nbits) - 1)
+        if src is None:
+            if c not in codes:
+                codes.append(c)
+            continue
+        r = [c]
+        for _ in range(3):
+            r.append(rotate_code(r[-1], src))
+        ok = all(bin(r[0] ^ r[k]).count("1") >= min_dist for k in (1, 2, 3))
+        ok = ok and all(bin(a ^ b).count("1") >= min_dist for a in r for prev in rots for b in prev)
+        if ok:
+            codes.append(c)
+            rots.append(r)
+    return codes
+
+
+def render_layout_tags(width, height, tags, background=150, sigma=0.0, seed=0, ss=4, black=25, white=230):
+    """Frames with tags of arbitrary layout (numpy; test sizes only).  tags: dicts {bit_x, bit_y, width_at_border,
+    total_width, reversed_border, code, H}; H maps tag coordinates ([-1, 1]^2 = the border square) to pixels.  Cells that
+    are neither data nor border: the ring just outside the border square has the opposite colour of the border (it is
+    what makes the border edge), everything else is white (black for a reversed border)."""
+    img = np.full((height, width), background, dtype=np.float64)
+    ys, xs = np.mgrid[0:height, 0:width]
+    for tg in tags:
+        wb, tw, rev = tg["width_at_border"], tg["total_width"], bool(tg["reversed_border"])
+        m = (wb - tw) // 2
+        n = len(tg["bit_x"])
+        border_col, outside_col = (white, black) if rev else (black, white)
+        grid = np.full((tw, tw), outside_col if False else (black if rev else white), dtype=np.float64)
+        for y in range(m, m + tw):
+            for x in range(m, m + tw):
+                ring = max(-x, -y, x - (wb - 1), y - (wb - 1))       # 0 on the border square's outer cells, < 0 inside
+                if ring == 0:
+                    grid[y - m, x - m] = border_col
+                elif ring == 1:
+                    grid[y - m, x - m] = outside_col
+        for i in range(n):
+            bit = (tg["code"] >> (n - 1 - i)) & 1
+            grid[tg["bit_y"][i] - m, tg["bit_x"][i] - m] = white if bit else black
+        Hi = np.linalg.inv(np.asarray(tg["H"], dtype=np.float64))
+        cell = 2.0 / wb
+        acc = np.zeros((height, width))
+        hit = np.zeros((height, width), dtype=bool)
+        for sy in range(ss):
+            for sx in range(ss):
+                u, v = xs + (sx + 0.5) / ss, ys + (sy + 0.5) / ss
+                X = Hi[0, 0] * u + Hi[0, 1] * v + Hi[0, 2]
+                Y = Hi[1, 0] * u + Hi[1, 1] * v + Hi[1, 2]
+                Z = Hi[2, 0] * u + Hi[2, 1] * v + Hi[2, 2]
+                cx = np.floor((X / Z + 1.0) / cell).astype(np.int64) - m
+                cy = np.floor((Y / Z + 1.0) / cell).astype(np.int64) - m
+                inside = (cx >= 0) & (cx < tw) & (cy >= 0) & (cy < tw)
+                val = np.where(inside, grid[np.clip(cy, 0, tw - 1), np.clip(cx, 0, tw - 1)], img)
+                acc += val
+                hit |= inside
+        img = np.where(hit, np.floor(acc / (ss * ss) + 0.5), img)
+    if sigma > 0:
+        img = img + np.random.default_rng(seed).normal(0.0, sigma, size=img.shape)
+    return np.clip(np.floor(img + 0.5), 0, 255).astype(np.uint8)

@@ -633,3 +633,66 @@ def test_c99_example_runs(built, tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "1 detection(s)" in r.stdout and r.stdout.startswith("id 0 ")
+
+
+def test_apriltag3_layout_families(built):
+    """Rows F13 / F17: the AprilTag-3 layout families of the reference's table (apriltag_node.cpp:47-58) are data for this
+    library -- amdAprilTagsRegisterFamilyEx.  No real code table exists offline, so the shapes are tested with toy code
+    words: a standard-41 shaped family (9 x 9 grid, 5-cell border square, REVERSED border: white square inside a black
+    ring) and a standard-52 shaped one with a normal border, next to built-in tag36h11 in the same frame, tags turned into
+    all four quadrants (the code rotation comes from the layout).  Stages and detections are bit-identical to the oracle
+    running the same family descriptors; ids, rotations and corners agree with the renderer's ground truth."""
+    import family_layouts as fl
+    from isaac_ros_apriltag_amd import capi
+    bx41, by41 = fl.standard_layout(9, 5)
+    bx52, by52 = fl.standard_layout(10, 6)
+    assert len(bx41) == 41 and len(bx52) == 52
+    c41 = fl.toy_codes(41, 5, seed=11, min_dist=12, layout=(bx41, by41, 5))
+    c52 = fl.toy_codes(52, 5, seed=12, min_dist=13, layout=(bx52, by52, 6))
+    capi.register_family_ex(7, "standard41h12", bx41, by41, 5, 9, True, c41)
+    capi.register_family_ex(8, "toy52_normal", bx52, by52, 6, 10, False, c52)
+    o41 = po.custom_family("standard41h12", bx41, by41, 5, 9, True, c41)
+    o52 = po.custom_family("toy52_normal", bx52, by52, 6, 10, False, c52)
+    codes36, _ = synth.family_codes("tag36h11")
+    bx36 = [1 + i % 6 for i in range(36)]
+    by36 = [1 + i // 6 for i in range(36)]
+    K = synth.default_K(960, 720)
+    rng = np.random.default_rng(99)
+    names = ("tag36h11", "standard41h12", "toy52_normal")
+    det = AprilTagDetector(960, 720, families=names, intrinsics=_k4(K), tag_size=0.1, max_batch=1)
+    total = 0
+    for case in range(4):
+        tags, want = [], []
+        slots = [(200, 190), (500, 200), (790, 210), (220, 520), (520, 530), (800, 520)]
+        for k, (cx, cy) in enumerate(slots):
+            fam = k % 3
+            idx = int(rng.integers(0, 5))
+            rz = (k + case) % 4 * (np.pi / 2) + float(rng.uniform(-0.5, 0.5))
+            R = synth.rot_xyz(float(rng.uniform(-0.35, 0.35)), float(rng.uniform(-0.35, 0.35)), rz)
+            side = float(rng.uniform(70, 100)) * (1.0 if fam else 1.2)
+            z = K[0, 0] * 0.1 / side
+            tvec = np.array([(cx - 480) / K[0, 0] * z, (cy - 360) / K[1, 1] * z, z])
+            H = synth.homography_from_pose(R, tvec, K, 0.1)
+            if fam == 0:
+                tags.append(dict(bit_x=bx36, bit_y=by36, width_at_border=8, total_width=10, reversed_border=False, code=codes36[100 + idx], H=H))
+                want.append(("tag36h11", 100 + idx))
+            elif fam == 1:
+                tags.append(dict(bit_x=bx41, bit_y=by41, width_at_border=5, total_width=9, reversed_border=True, code=c41[idx], H=H))
+                want.append(("standard41h12", idx))
+            else:
+                tags.append(dict(bit_x=bx52, bit_y=by52, width_at_border=6, total_width=10, reversed_border=False, code=c52[idx], H=H))
+                want.append(("toy52_normal", idx))
+        img = fl.render_layout_tags(960, 720, tags, background=120, sigma=1.0, seed=500 + case)
+        g = det.detect_batch_ex(torch.from_numpy(img).cuda(), max_dets=64)[0]
+        errs, odets = pu.compare_stages(det, 0, img, ("tag36h11", o41, o52), K, 1, tag_size=0.1)
+        errs += pu.compare_detections(g, odets)
+        assert not errs, (case, errs[:4])
+        assert sorted((d["family"], d["id"]) for d in odets) == sorted(want), (case, [(d["family"], d["id"], d["hamming"]) for d in odets])
+        for d in odets:   # corners against the renderer's homography (AprilRobotics order), within a pixel
+            H = min((t["H"] for t, w in zip(tags, want) if w == (d["family"], d["id"])),
+                    key=lambda Hc: float(np.abs(synth.project(Hc, 0, 0) - d["center"]).sum()))
+            truth = np.array([synth.project(H, -1, 1), synth.project(H, 1, 1), synth.project(H, 1, -1), synth.project(H, -1, -1)])
+            assert np.abs(d["p"] - truth).max() < 1.0
+        total += len(odets)
+    det.close()
+    assert total == 24
