@@ -175,19 +175,48 @@ def threshold_roofline(frames_dev, decimate, reps=20):
             "frames_per_launch": nb, "footprint_mib": round((big.numel() * 2) / 2 ** 20, 1)}
 
 
+STAGE_KERNELS = {"threshold": ("k_threshold",), "cc_local": ("k_cc_local",), "points": ("k_points",), "scatter": ("k_scatter",),
+                 "fit_quads": ("k_fit_prefilter", "k_fit_quads", "k_quad_finish")}
+
+
 def stage_rooflines(stage_ms, nframes, counts, decimate):
-    """Achieved HBM rate of the streaming stages from their algorithmic bytes:
-    per frame of N working pixels, P raw boundary points, Pk kept points."""
+    """Achieved HBM rate of the streaming stages IN THE PIPELINE (HIP-event stage times of this run) from their MINIMAL
+    algorithmic bytes, with the measured HBM traffic of the same kernels beside it (rocprofv3 --pmc FETCH_SIZE x 2 +
+    WRITE_SIZE on the 32-frame pipeline, committed under profiles/; bench.py cannot collect PMC counters itself).
+    Per frame of N working pixels, P raw boundary points, Pk points in kept clusters:
+      threshold  read N, write N                                                          2 N
+      cc_local   read N (threshold image), write 4 N (labels)                             5 N
+      points     read N + 4 N, write 12 B per raw point (slot, point, rank)               5 N + 12 P
+      scatter    read 12 P, write 4 Pk                                                    12 P + 4 Pk
+      fit_quads  read 4 B per point + the four gray bytes of its gradient                 8 Pk
+    Representative / size gathers (points), the offset gather (scatter) and the quad fit's cumulative-moment scratch
+    (48 B per point written and read back) are NOT algorithmic: they show up in traffic_ratio."""
     w, h = 1 + (W - 1) // decimate, 1 + (H - 1) // decimate
     N = float(w * h)
     P, Pk = counts["npoints_raw"], counts["npoints_kept"]
-    alg = {"cc_local": 5 * N, "points": 9 * N + 12 * P, "scatter": 16 * P, "fit_quads": 130 * Pk}
+    alg = {"threshold": 2 * N, "cc_local": 5 * N, "points": 5 * N + 12 * P, "scatter": 12 * P + 4 * Pk, "fit_quads": 8 * Pk}
+    pmc, pmc_src = None, None
+    path = os.path.join(ROOT, "profiles", "r03_pipeline_pmc.json")
+    if decimate == 1 and os.path.exists(path):
+        pmc, pmc_src = json.load(open(path)), "profiles/r03_pipeline_pmc.json"
     out = {}
     for k, b in alg.items():
         ms = stage_ms.get(k)
-        if ms and ms > 0:
-            gbs = b * nframes / (ms * 1e-3) / 1e9
-            out[k] = {"ms": round(ms, 3), "alg_bytes_per_frame": int(b), "GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4)}
+        if not (ms and ms > 0):
+            continue
+        gbs = b * nframes / (ms * 1e-3) / 1e9
+        rec = {"ms": round(ms, 3), "alg_bytes": int(b), "GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4),
+               "traffic_bytes": None, "traffic_ratio": None, "traffic_source": None}
+        if pmc:
+            per_frame = 1024.0 / (pmc["frames"] * pmc.get("submissions", 1))
+            t = 0.0
+            for kn in STAGE_KERNELS[k]:
+                kr = pmc["kernels"].get(kn)
+                if kr:
+                    t += (2.0 * kr.get("FETCH_SIZE", {}).get("sum_KB", 0.0) + kr.get("WRITE_SIZE", {}).get("sum_KB", 0.0)) * per_frame
+            if t > 0:
+                rec.update(traffic_bytes=int(t), traffic_ratio=round(t / b, 2), traffic_source=pmc_src)
+        out[k] = rec
     return out
 
 
@@ -339,6 +368,9 @@ def main():
             rec["cpu_baseline"] = cpu_rec
         if not args.no_roofline:
             rec["roofline"] = threshold_roofline(batch[:min(B, 160)], args.decimate)
+            thr = rec["stage_roofline"].get("threshold")
+            if thr:   # the same kernel inside the timed pipeline (B frames, HIP-event stage time of this run)
+                rec["roofline"]["in_pipeline"] = {"frames_per_launch": B, "ms": thr["ms"], "achieved": thr["GB/s"], "frac": thr["frac_of_8TBs"]}
         if byframe is not None:
             # correctness gate in the same run: ids exact; corners, rotation and translation bit-identical to the CPU restatement
             rec["parity_gate"] = "pass" if gate_all else "FAIL"

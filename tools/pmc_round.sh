@@ -13,6 +13,10 @@ for G in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_IN
   (cd /tmp && timeout 300 rocprofv3 --pmc $G -d $OUT/pmc_$N -o pmc -- python $GRAFT_REPO_ROOT/tools/pipeline_once.py 32 1 8 > $OUT/pmc_$N.log 2>&1)
   python $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT/pmc_$N $PATS >> $OUT/pmc_summary.md 2>&1
   echo >> $OUT/pmc_summary.md
-  find $OUT/pmc_$N -name "*.db" -delete
 done
+# FETCH / WRITE totals per kernel as JSON (bench.py's stage_roofline reads the committed copy under profiles/);
+# tools/pipeline_once.py 32 1 8 runs 1 + 1 submissions of 32 frames
+mkdir -p $OUT/pmc_rw && cp -r $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_rw/ 2>/dev/null
+python $GRAFT_REPO_ROOT/tools/pmc_json.py $OUT/pmc_rw 32 $OUT/pipeline_pmc.json
+find $OUT -name "*.db" -delete
 cat $OUT/pmc_summary.md
