@@ -96,7 +96,11 @@ def build_all(force=False):
     build_synth(force)
     build_amd(force)
     build_node(force)
-    build_host(force)
+    try:   # the multi-GPU example links RCCL; a machine without it still gets the product libraries
+        build_host(force)
+    except (subprocess.CalledProcessError, OSError) as e:
+        import sys
+        sys.stderr.write("isaac_ros_apriltag_amd.build: examples/multi_stream_host not built (%s); only its test needs it\n" % (e,))
 
 
 if __name__ == "__main__":

@@ -102,6 +102,7 @@ struct DetParams {
   double tag_size;
   // capacities per frame
   uint32_t pcap, hcap, hshift, ccap, qcap, dcap;
+  uint32_t rcap;     // tile-local roots per frame (CC root list)
   FamilyDev fam[AT_MAX_FAMILIES];
 };
 

@@ -171,6 +171,10 @@ struct amdAprilTagsDetector_st {
   unsigned long long* d_fqprof = nullptr;  // per-phase cycle counters of k_fit_quads (-DAMDAT_FQ_PROFILE builds only)
   FqClass cls[FQ_NCLS];
   FqWorkLayout work_layout;
+  bool grow_points = false;          // point capacity follows the content (no explicit max_points)
+  uint32_t pcap_hard = 0;            // 2 points per working pixel: what any content stays below
+  size_t point_buffer_bytes[5] = {0, 0, 0, 0, 0};
+  uint32_t grown = 0;                // number of times the point buffers grew (amdAprilTagsGetDeviceBytes reports the result)
   // pinned host buffers
   FrameDesc* h_frames = nullptr;
   FrameCounters* h_counters = nullptr;
@@ -181,9 +185,10 @@ struct amdAprilTagsDetector_st {
   bool fq_attr_set = false;
   // captured enqueue sequence of small submissions (see run_batch)
   uint32_t graph_max_frames = 8;
-  hipGraphExec_t graph_exec = nullptr;
-  uint32_t graph_n = 0, graph_ostride = 0;
-  hipStream_t graph_stream = nullptr;
+  struct GraphEntry { hipGraphExec_t exec = nullptr; uint32_t n = 0, ostride = 0; hipStream_t stream = nullptr; uint64_t last_use = 0; };
+  GraphEntry graphs[6];
+  uint64_t graph_clock = 0;
+  uint32_t graph_misses = 0;         // consecutive captures that had to evict an entry
   hipEvent_t ev[AMDAT_NUM_STAGES + 1] = {};
   float stage_ms[AMDAT_NUM_STAGES] = {};
   uint32_t last_n = 0;
@@ -311,7 +316,7 @@ int amdAprilTagsFamilyFromName(const char* name) {
 const char* amdAprilTagsStageName(uint32_t stage) { return stage < AMDAT_NUM_STAGES ? kStageNames[stage] : ""; }
 
 static void free_all(amdAprilTagsDetector_st* D) {
-  if (D->graph_exec) hipGraphExecDestroy(D->graph_exec);
+  for (auto& g : D->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
   hipFree(D->d_gray); hipFree(D->d_thr); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_roots); hipFree(D->d_hkeys);
   hipFree(D->d_hcnt); hipFree(D->d_hoff); hipFree(D->d_stage); hipFree(D->d_rank); hipFree(D->d_pts); hipFree(D->d_clusters);
   hipFree(D->d_work); hipFree(D->d_work2); hipFree(D->d_workctl); hipFree(D->d_keys_scr); hipFree(D->d_quads);
@@ -327,6 +332,38 @@ static void free_all(amdAprilTagsDetector_st* D) {
   for (auto& a : D->aux_stream) if (a) hipStreamDestroy(a);
   if (D->ev_fork) hipEventDestroy(D->ev_fork);
   for (auto& e : D->ev_join) if (e) hipEventDestroy(e);
+}
+
+// Buffers whose size follows the point capacity P.pcap: staging records, ranks, points and the quad fit's work lists (their
+// capacities are bounded by points / smallest cluster of the class).  Called at creation and again when the capacity grows.
+static int alloc_point_buffers(amdAprilTagsDetector_st* D) {
+  DetParams& P = D->P;
+  const size_t B = D->cfg.max_batch;
+  uint64_t off = 0;
+  for (int k = 0; k < FQ_NCLS; k++) {
+    const FqClass& c = D->cls[k];
+    D->work_layout.lo[k] = c.lo < 23 ? 23 : c.lo;
+    D->work_layout.hi[k] = c.hi;
+    const uint32_t per_frame = P.pcap / (uint32_t)(D->work_layout.lo[k] + 1) + 1;
+    const uint64_t cap = (uint64_t)B * (per_frame < P.ccap ? per_frame : P.ccap);
+    if (cap > 0x7FFFFFFFull || off + cap > 0xFFFFFFFFull) return AMDAT_BATCH_TOO_LARGE;   // offsets and cursors are 32-bit
+    D->work_layout.off[k] = (uint32_t)off;
+    D->work_layout.cap[k] = (uint32_t)cap;
+    off += cap;
+  }
+  void** bufs[5] = {(void**)&D->d_stage, (void**)&D->d_rank, (void**)&D->d_pts, (void**)&D->d_work, (void**)&D->d_work2};
+  const size_t bytes[5] = {B * (size_t)P.pcap * 8, B * (size_t)P.pcap * 4, B * (size_t)P.pcap * 4, (size_t)off * 4,
+                           ((size_t)off - D->work_layout.off[FQ_PREFILTER_CLASS]) * 4};
+  for (int i = 0; i < 5; i++) {
+    if (*bufs[i]) { hipFree(*bufs[i]); *bufs[i] = nullptr; D->device_bytes -= D->point_buffer_bytes[i]; D->point_buffer_bytes[i] = 0; }
+  }
+  for (int i = 0; i < 5; i++) {
+    const size_t nb = bytes[i] ? bytes[i] : 16;
+    if (hipMalloc(bufs[i], nb) != hipSuccess) return AMDAT_OUT_OF_MEMORY;
+    D->point_buffer_bytes[i] = nb;
+    D->device_bytes += nb;
+  }
+  return AMDAT_SUCCESS;
 }
 
 int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsConfig_t* cfg_in) {
@@ -394,10 +431,13 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   P.min_tag_width = min_tag_width;
   const uint32_t npx = (uint32_t)W * (uint32_t)H;
   // Boundary points per frame: 2 per pixel covers every content the fuzzer produces (thin diagonal lines come
-  // closest); frames that binarise completely (noise on every 4x4 tile) measure ~0.85 per pixel.  A smaller
-  // max_points trades memory (16 bytes per point and batch slot) for the chance of a reported overflow
-  // (AMDAT_FLAG_POINTS_OVERFLOW) on adversarial content.
-  P.pcap = cfg.max_points ? cfg.max_points : 2u * npx;
+  // closest); frames that binarise completely (noise on every 4x4 tile) measure ~0.85 per pixel.
+  // Default: 1 per pixel, and the handle GROWS the point buffers (up to the hard 2 per pixel) and repeats the submission
+  // when a frame reports AMDAT_FLAG_POINTS_OVERFLOW -- results never depend on the capacity, memory follows the content
+  // (15 GB instead of 27 GB for the 256-frame 1080p handle).  An explicit max_points is taken as given and never grown.
+  D->grow_points = cfg.max_points == 0;
+  D->pcap_hard = 2u * npx;
+  P.pcap = cfg.max_points ? cfg.max_points : npx;
   P.hcap = cfg.hash_slots ? next_pow2(cfg.hash_slots) : next_pow2(npx / 8 > 4096 ? npx / 8 : 4096);
   if (P.hcap < 256) P.hcap = 256;
   { uint32_t lg = 0; while ((1u << lg) < P.hcap) lg++; P.hshift = 64 - lg; }
@@ -443,16 +483,6 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
     c[4] = {FQ_NT_BIG, 16384, 8192, 0x7FFFFFFF, minu(cus, 16u * (unsigned)B), P.max_cluster_points, 1};
     if (P.max_cluster_points > 16384 && P.max_cluster_points <= 18432) c[4].sort_cap = (P.max_cluster_points + 63) & ~63;
     if (c[4].slot_cap < 8193) c[4].slot_cap = 8193;
-    uint32_t off = 0;
-    for (int k = 0; k < FQ_NCLS; k++) {
-      D->work_layout.lo[k] = c[k].lo < 23 ? 23 : c[k].lo;
-      D->work_layout.hi[k] = c[k].hi;
-      const uint32_t per_frame = P.pcap / (uint32_t)(D->work_layout.lo[k] + 1) + 1;
-      const uint64_t cap = (uint64_t)B * (per_frame < P.ccap ? per_frame : P.ccap);
-      D->work_layout.off[k] = off;
-      D->work_layout.cap[k] = (uint32_t)(cap > 0x7FFFFFFFull ? 0x7FFFFFFFull : cap);
-      off += D->work_layout.cap[k];
-    }
   }
 
   bool ok = true;
@@ -465,16 +495,15 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   alloc((void**)&D->d_thr, B * (size_t)H * P.WS);
   alloc((void**)&D->d_label, B * (size_t)npx * 4);
   alloc((void**)&D->d_csize, B * (size_t)npx * 4);
-  alloc((void**)&D->d_roots, B * (size_t)npx * 4);
+  // tile-local roots that go to the list touch their 64 x 64 tile's perimeter, and components are disjoint: at most
+  // 252 (perimeter pixels) per tile
+  P.rcap = (uint32_t)(((W + CC_T - 1) / CC_T) * ((H + CC_T - 1) / CC_T)) * (4u * CC_T - 4u);
+  alloc((void**)&D->d_roots, B * (size_t)P.rcap * 4);
   alloc((void**)&D->d_hkeys, B * (size_t)P.hcap * 8);
   alloc((void**)&D->d_hcnt, B * (size_t)P.hcap * 4);
   alloc((void**)&D->d_hoff, B * (size_t)P.hcap * 4);
-  alloc((void**)&D->d_stage, B * (size_t)P.pcap * 8);
-  alloc((void**)&D->d_rank, B * (size_t)P.pcap * 4);
-  alloc((void**)&D->d_pts, B * (size_t)P.pcap * 4);
   alloc((void**)&D->d_clusters, B * (size_t)P.ccap * sizeof(ClusterRec));
-  alloc((void**)&D->d_work, ((size_t)D->work_layout.off[FQ_NCLS - 1] + D->work_layout.cap[FQ_NCLS - 1]) * 4);
-  alloc((void**)&D->d_work2, ((size_t)D->work_layout.off[FQ_NCLS - 1] + D->work_layout.cap[FQ_NCLS - 1] - D->work_layout.off[FQ_PREFILTER_CLASS]) * 4);
+  if (ok) { const int rc = alloc_point_buffers(D); if (rc == AMDAT_BATCH_TOO_LARGE) { free_all(D); delete D; return rc; } ok = rc == AMDAT_SUCCESS; }
   alloc((void**)&D->d_workctl, 32 * 4);
   for (int k = 0; k < FQ_NCLS; k++) {
     FqClass& c = D->cls[k];
@@ -795,26 +824,36 @@ static int enqueue_submission(amdAprilTagsDetector_st* D, uint32_t n, uint32_t o
   return AMDAT_SUCCESS;
 }
 
-// One batched submission; results land in h_out / h_counters with `ostride` records per frame.
-static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images,
-                     const amdAprilTagsCameraIntrinsics_t* intr, uint32_t ostride, hipStream_t s) {
-  const DetParams& P = D->P;
-  DeviceGuard guard(D->device);
-  if (!guard.ok) return AMDAT_HIP_ERROR;
-  fill_frames(D, n, images, intr);   // image pointers, pitches and intrinsics travel through the pinned descriptor block
-  D->last_n = n;
-  if (ostride > P.dcap) ostride = P.dcap;
+// One pass of a submission over the device: captured-graph replay for small submissions, plain enqueues otherwise.
+static int run_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s) {
   const bool prof = D->profiling;
   int evi = 0;
   const std::function<void()> mark = [&]() { if (prof) hipEventRecord(D->ev[evi++], s); };
   const std::function<void()> nomark = []() {};
 
-  // Small submissions (the node's one-frame calls) are launch-bound: ~17 enqueues for well under a millisecond of
+  // Small submissions (the node's one-frame calls) are launch-bound: ~20 enqueues for well under a millisecond of
   // device work.  Their enqueue sequence is captured once per (frames, output stride, stream) into a hipGraph and
-  // replayed; everything that changes between calls lives in the descriptor block the graph's first node uploads.
+  // replayed; everything that changes between calls lives in the descriptor block the graph's first node uploads.  A
+  // handful of instantiated graphs is kept (a host that alternates batch sizes or streams would otherwise re-capture on
+  // every call, far slower than the plain enqueues the graph replaces); after a few consecutive misses with the cache
+  // full, or one failed capture, the handle falls back to plain enqueues for good.
   if (D->graph_max_frames && n <= D->graph_max_frames && !prof) {
-    if (!(D->graph_exec && D->graph_n == n && D->graph_ostride == ostride && D->graph_stream == s)) {
-      if (D->graph_exec) { hipGraphExecDestroy(D->graph_exec); D->graph_exec = nullptr; }
+    amdAprilTagsDetector_st::GraphEntry* hit = nullptr;
+    for (auto& g : D->graphs)
+      if (g.exec && g.n == n && g.ostride == ostride && g.stream == s) hit = &g;
+    if (hit) {
+      D->graph_misses = 0;
+      hit->last_use = ++D->graph_clock;
+    } else if (D->graph_misses < 8) {
+      amdAprilTagsDetector_st::GraphEntry* slot = nullptr;
+      for (auto& g : D->graphs) if (!g.exec) { slot = &g; break; }
+      if (!slot) {   // evict the least recently used entry
+        D->graph_misses++;
+        slot = &D->graphs[0];
+        for (auto& g : D->graphs) if (g.last_use < slot->last_use) slot = &g;
+        hipGraphExecDestroy(slot->exec);
+        slot->exec = nullptr;
+      }
       hipGraph_t graph = nullptr;
       bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
       if (ok) {
@@ -822,17 +861,17 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
         const hipError_t e = hipStreamEndCapture(s, &graph);
         ok = rc == AMDAT_SUCCESS && e == hipSuccess && graph != nullptr;
       }
-      if (ok) ok = hipGraphInstantiate(&D->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (ok) ok = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess;
       if (graph) hipGraphDestroy(graph);
-      if (ok) { D->graph_n = n; D->graph_ostride = ostride; D->graph_stream = s; }
+      if (ok) { slot->n = n; slot->ostride = ostride; slot->stream = s; slot->last_use = ++D->graph_clock; hit = slot; }
       else {
         (void)hipGetLastError();
-        D->graph_exec = nullptr;
+        slot->exec = nullptr;
         D->graph_max_frames = 0;   // capture is not usable here: plain enqueues from now on
       }
     }
-    if (D->graph_exec) {
-      HIP_TRY(hipGraphLaunch(D->graph_exec, s));
+    if (hit) {
+      HIP_TRY(hipGraphLaunch(hit->exec, s));
       HIP_TRY(hipStreamSynchronize(s));
       return AMDAT_SUCCESS;
     }
@@ -851,6 +890,41 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
     }
   }
   return AMDAT_SUCCESS;
+}
+
+static void drop_graphs(amdAprilTagsDetector_st* D) {
+  for (auto& g : D->graphs) if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+}
+
+// One batched submission; results land in h_out / h_counters with `ostride` records per frame.
+static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images,
+                     const amdAprilTagsCameraIntrinsics_t* intr, uint32_t ostride, hipStream_t s) {
+  DeviceGuard guard(D->device);
+  if (!guard.ok) return AMDAT_HIP_ERROR;
+  fill_frames(D, n, images, intr);   // image pointers, pitches and intrinsics travel through the pinned descriptor block
+  D->last_n = n;
+  if (ostride > D->P.dcap) ostride = D->P.dcap;
+  for (;;) {
+    const int rc = run_once(D, n, ostride, s);
+    if (rc) return rc;
+    // A frame whose boundary points did not fit yields no clusters at all (flag 0x1).  Unless the host fixed the capacity,
+    // the point buffers grow -- doubling, up to the 2 points per pixel no content exceeds -- and the submission runs again.
+    if (!D->grow_points || D->P.pcap >= D->pcap_hard) return AMDAT_SUCCESS;
+    bool overflow = false;
+    for (uint32_t f = 0; f < n; f++) overflow |= (D->h_counters[f].flags & 0x1u) != 0;
+    if (!overflow) return AMDAT_SUCCESS;
+    const uint64_t want = (uint64_t)D->P.pcap * 2;
+    const uint32_t before = D->P.pcap;
+    D->P.pcap = want > D->pcap_hard ? D->pcap_hard : (uint32_t)want;
+    drop_graphs(D);   // captured launches carry the old pointers and capacities
+    const int grc = alloc_point_buffers(D);
+    if (grc != AMDAT_SUCCESS) {   // not enough memory to grow: keep reporting the overflow with the old capacity
+      D->P.pcap = before;
+      D->grow_points = false;
+      return alloc_point_buffers(D) == AMDAT_SUCCESS ? AMDAT_SUCCESS : AMDAT_OUT_OF_MEMORY;
+    }
+    D->grown++;
+  }
 }
 
 int amdAprilTagsDetectBatchEx(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   // ---- 4. write global labels (index of the local root), local sizes at the roots, root list -------
   uint32_t* label = label_all + (size_t)frame * W * H;
   uint32_t* csize = csize_all + (size_t)frame * W * H;
-  uint32_t* roots = roots_all + (size_t)frame * W * H;
+  uint32_t* roots = roots_all + (size_t)frame * P.rcap;
   if (tid == 0) s_nroots = 0;
   __syncthreads();
   // Only roots of components that touch the perimeter go to the root list: every other component is complete inside
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void k_cc_sizes(uint32_t* __restrict__ label_a
   const size_t n = (size_t)P.W * P.H;
   uint32_t* label = label_all + (size_t)frame * n;
   uint32_t* csize = csize_all + (size_t)frame * n;
-  const uint32_t* roots = roots_all + (size_t)frame * n;
+  const uint32_t* roots = roots_all + (size_t)frame * P.rcap;
   const uint32_t nroots = counters[frame].nroots;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nroots; i += gridDim.x * 256) {
     const uint32_t p = roots[i];
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void k_cc_resolve(const uint32_t* __restrict__
   const size_t n = (size_t)P.W * P.H;
   const uint32_t* label = label_all + (size_t)frame * n;
   uint32_t* csize = csize_all + (size_t)frame * n;
-  const uint32_t* roots = roots_all + (size_t)frame * n;
+  const uint32_t* roots = roots_all + (size_t)frame * P.rcap;
   const uint32_t nroots = counters[frame].nroots;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nroots; i += gridDim.x * 256) {
     const uint32_t p = roots[i];

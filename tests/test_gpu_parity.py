@@ -19,7 +19,8 @@ torch = pytest.importorskip("torch")
 from isaac_ros_apriltag_amd import capi, synth  # noqa: E402
 from isaac_ros_apriltag_amd.detector import AprilTagDetector  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
-import parity_util as pu  # noqa: E402
+import parity_util as pu
+from isaac_ros_apriltag_amd import capi as capi_mod  # noqa: E402
 
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.json")))
 
@@ -696,3 +697,63 @@ def test_apriltag3_layout_families(built):
         total += len(odets)
     det.close()
     assert total == 24
+
+
+def test_small_submissions_alternating_shapes_and_streams(built):
+    """The captured-graph path of small submissions keeps several instantiated graphs: a host that alternates batch
+    sizes, output strides and streams gets the same results on every call (one cache entry re-captured
+    on every call)."""
+    img_a, K, _ = synth.scene_c2(seed=1234, sigma=2.0)
+    img_b, _, _ = synth.scene_c2(seed=1235, sigma=0.0)
+    ta, tb = torch.from_numpy(img_a).cuda(), torch.from_numpy(img_b).cuda()
+    both = torch.stack([ta, tb])
+    det = AprilTagDetector(1920, 1080, intrinsics=_k4(K), max_batch=2)
+    side = torch.cuda.Stream()
+    ref_a = det.detect_batch_ex(ta, max_dets=64)[0]
+    ref_ab = det.detect_batch_ex(both, max_dets=64)
+    assert len(ref_a) == 10 and [len(r) for r in ref_ab] == [10, 10]
+    oa, _ = po.detect(img_a, params=pu.oracle_params(K, 1, 0.22))
+    assert not pu.compare_detections(ref_a, oa)
+
+    def same(x, y):
+        return len(x) == len(y) and all(a["id"] == b["id"] and np.array_equal(a["p"], b["p"]) and np.array_equal(a["t"], b["t"]) for a, b in zip(x, y))
+    for it in range(12):
+        stream = None if it % 3 else side.cuda_stream
+        max_dets = 64 if it % 2 else 32
+        if stream is not None:
+            side.wait_stream(torch.cuda.current_stream())
+        r1 = det.detect_batch_ex(ta, max_dets=max_dets, stream=stream)[0]
+        r2 = det.detect_batch_ex(both, max_dets=max_dets, stream=stream)
+        assert same(r1, ref_a) and same(r2[0], ref_ab[0]) and same(r2[1], ref_ab[1]), it
+        assert det.frame_flags(2) == [0, 0]
+    det.close()
+
+
+def test_point_capacity_grows_with_the_content(built):
+    """Default handles start at one boundary point per working pixel and grow (doubling, up to two per pixel) when a frame
+    overflows; the submission is repeated, so results never depend on the capacity.  One-pixel horizontal stripes
+    have about two points per pixel: the first call grows the buffers, labels / points / detections equal the oracle's,
+    no overflow flag is left, and an explicit max_points still reports the overflow instead of growing."""
+    w, h = 640, 480
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.where(yy % 2 == 0, 40, 215).astype(np.uint8) + 0 * xx.astype(np.uint8)
+    tag_img, K, _ = synth.scene_c1()
+    img[150:330, 230:410] = tag_img[150:330, 230:410]            # the config-1 tag in the middle
+    K = synth.default_K(w, h)
+    t = torch.from_numpy(np.ascontiguousarray(img)).cuda()
+    det = AprilTagDetector(w, h, intrinsics=_k4(K), max_batch=1)
+    before = det.device_bytes()
+    g = det.detect_batch_ex(t, max_dets=64)[0]
+    assert det.frame_flags(1) == [0]
+    assert det.device_bytes() > before                             # grown
+    counts = det.debug(0, capi_mod.DBG_COUNTS)
+    assert counts[0] > w * h                                       # more than one point per pixel
+    errs, odets = pu.compare_stages(det, 0, img, ("tag36h11",), K, 1)
+    errs += pu.compare_detections(g, odets)
+    assert not errs, errs[:4]
+    assert [d["id"] for d in odets] == [0]
+    det.close()
+    fixed = AprilTagDetector(w, h, intrinsics=_k4(K), max_batch=1, max_points=w * h)
+    fixed.detect_batch_ex(t, max_dets=64)
+    assert fixed.frame_flags(1)[0] & 1                             # reported, not grown
+    fixed.close()
