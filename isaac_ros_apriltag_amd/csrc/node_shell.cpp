@@ -28,6 +28,7 @@ struct DetectorApi {
   decltype(&amdCreateAprilTagsDetectorEx) create_ex = nullptr;
   decltype(&amdAprilTagsDefaultConfig) default_config = nullptr;
   decltype(&amdAprilTagsDetect) detect = nullptr;
+  decltype(&amdAprilTagsDetectBatch) detect_batch = nullptr;
   decltype(&amdAprilTagsDestroy) destroy = nullptr;
   decltype(&amdAprilTagsFamilyFromName) family_from_name = nullptr;
   decltype(&amdAprilTagsConvertToMono8) to_mono8 = nullptr;
@@ -54,6 +55,7 @@ DetectorApi& api() {
   BIND(create_ex, "amdCreateAprilTagsDetectorEx")
   BIND(default_config, "amdAprilTagsDefaultConfig")
   BIND(detect, "amdAprilTagsDetect")
+  BIND(detect_batch, "amdAprilTagsDetectBatch")
   BIND(destroy, "amdAprilTagsDestroy")
   BIND(family_from_name, "amdAprilTagsFamilyFromName")
   BIND(to_mono8, "amdAprilTagsConvertToMono8")
@@ -129,6 +131,67 @@ Quaternion quaternion_from_colmajor(const float* o) {
   return out;
 }
 
+// AprilTagDetectionArray + TF transforms of one frame from the detector's records (src/apriltag_node.cpp:499-549)
+void assemble_messages(const amdAprilTagsID_t* tags, uint32_t num_detections, const Header& info_header, const std::string& family,
+                       AprilTagDetectionArray* msg_out, std::vector<TransformStamped>* tfs_out) {
+  AprilTagDetectionArray& msg = *msg_out;
+  std::vector<TransformStamped>& tfs = *tfs_out;
+  msg.header = info_header;  // camera_info header, not the image header (src/apriltag_node.cpp:501)
+  for (uint32_t i = 0; i < num_detections; i++) {
+    const amdAprilTagsID_t& d = tags[i];
+    AprilTagDetection det;
+    det.family = family;
+    det.id = d.id;
+    for (int c = 0; c < 4; c++) {
+      det.corners[c].x = d.corners[c].x;
+      det.corners[c].y = d.corners[c].y;
+    }
+    // The reference intersects the diagonals in slope/intercept form, which divides by zero when a
+    // diagonal is vertical (src/apriltag_node.cpp:519-530); the library reports H(0,0) directly.
+    det.center.x = d.center.x;
+    det.center.y = d.center.y;
+    TransformStamped tf;
+    tf.header = info_header;
+    tf.child_frame_id = family + ":" + std::to_string(d.id);
+    tf.transform.translation.x = d.translation[0];
+    tf.transform.translation.y = d.translation[1];
+    tf.transform.translation.z = d.translation[2];
+    tf.transform.rotation = quaternion_from_colmajor(d.orientation);
+    tfs.push_back(tf);
+    det.pose.pose.pose.position.x = tf.transform.translation.x;
+    det.pose.pose.pose.position.y = tf.transform.translation.y;
+    det.pose.pose.pose.position.z = tf.transform.translation.z;
+    det.pose.pose.pose.orientation = tf.transform.rotation;
+    msg.detections.push_back(det);
+  }
+}
+
+// Backend / family validation of the constructor (src/apriltag_node.cpp:575-599): returns the family enum, throws with
+// the reference's text otherwise.  cuapriltags_mode: exactly {CUDA} was asked for (tag36h11 only).
+int validate_family(const NodeOptions& options, bool* cuapriltags_mode) {
+  const std::set<std::string> backends = parse_backends(options.backends);
+  *cuapriltags_mode = backends.size() == 1 && *backends.begin() == "CUDA";
+  std::set<std::string> supported;
+  if (*cuapriltags_mode) {
+    supported.insert("tag36h11");
+  } else {
+    // any other backend list: the reference runs VPI, whose family table is src/apriltag_node.cpp:47-58;
+    // here the families this library can decode = those with a code table (built in or registered by the host)
+    for (const char* f : kKnownFamilyStrings)
+      if (api().family_from_name(f) >= 0) supported.insert(f);
+    if (api().family_from_name(options.tag_family.c_str()) >= 0) supported.insert(options.tag_family);
+  }
+  if (supported.find(options.tag_family) == supported.end()) {
+    std::ostringstream os;
+    os << "Tag family not supported by specified backend: '" << options.tag_family << "'" << std::endl;
+    os << "'tag_family' parameter must be one of:" << std::endl;
+    for (const auto& f : supported) os << f << std::endl;
+    std::fprintf(stderr, "[apriltag_node] FATAL: Tag family not supported by specified backend: '%s'\n", options.tag_family.c_str());
+    throw std::runtime_error(os.str());
+  }
+  return api().family_from_name(options.tag_family.c_str());
+}
+
 }  // namespace
 
 struct AprilTagNode::Impl {
@@ -147,21 +210,6 @@ struct AprilTagNode::Impl {
 
   // exactly {CUDA}: the reference runs cuAprilTags, which decodes tag36h11 only (src/apriltag_node.cpp:429-432)
   bool cuapriltags_mode = false;
-
-  std::set<std::string> SupportedTagFamilies() const {
-    std::set<std::string> out;
-    if (cuapriltags_mode) {
-      out.insert("tag36h11");
-      return out;
-    }
-    // any other backend list: the reference runs VPI, whose family table is src/apriltag_node.cpp:47-58;
-    // here the families this library can decode = those with a code table
-    for (const char* f : kKnownFamilyStrings)
-      if (api().family_from_name(f) >= 0) out.insert(f);
-    // user-registered tables
-    if (api().family_from_name(opt.tag_family.c_str()) >= 0) out.insert(opt.tag_family);
-    return out;
-  }
 
   void Initialize(const Image& image, const CameraInfo& info) {
     if (opt.max_tags <= 0) throw std::runtime_error("'max_tags' must be positive");
@@ -249,35 +297,8 @@ struct AprilTagNode::Impl {
       return;
     }
     AprilTagDetectionArray msg;
-    msg.header = info.header;  // camera_info header, not the image header (src/apriltag_node.cpp:501)
     std::vector<TransformStamped> tfs;
-    for (uint32_t i = 0; i < num_detections; i++) {
-      const amdAprilTagsID_t& d = tags[i];
-      AprilTagDetection det;
-      det.family = opt.tag_family;
-      det.id = d.id;
-      for (int c = 0; c < 4; c++) {
-        det.corners[c].x = d.corners[c].x;
-        det.corners[c].y = d.corners[c].y;
-      }
-      // The reference intersects the diagonals in slope/intercept form, which divides by zero when a
-      // diagonal is vertical (src/apriltag_node.cpp:519-530); the library reports H(0,0) directly.
-      det.center.x = d.center.x;
-      det.center.y = d.center.y;
-      TransformStamped tf;
-      tf.header = info.header;
-      tf.child_frame_id = opt.tag_family + ":" + std::to_string(d.id);
-      tf.transform.translation.x = d.translation[0];
-      tf.transform.translation.y = d.translation[1];
-      tf.transform.translation.z = d.translation[2];
-      tf.transform.rotation = quaternion_from_colmajor(d.orientation);
-      tfs.push_back(tf);
-      det.pose.pose.pose.position.x = tf.transform.translation.x;
-      det.pose.pose.pose.position.y = tf.transform.translation.y;
-      det.pose.pose.pose.position.z = tf.transform.translation.z;
-      det.pose.pose.pose.orientation = tf.transform.rotation;
-      msg.detections.push_back(det);
-    }
+    assemble_messages(tags.data(), num_detections, info.header, opt.tag_family, &msg, &tfs);
     if (on_detections) on_detections(msg);
     if (on_transforms) on_transforms(tfs);
   }
@@ -289,18 +310,7 @@ AprilTagNode::AprilTagNode(const NodeOptions& options) : impl_(new Impl()) {
   // HIP detector; CPU / PVA backends of VPI do not exist here and support no family.
   // cuAprilTags when exactly CUDA was asked for, VPI otherwise; the HIP detector stands behind both, whatever
   // names the list holds (there is one implementation and no CPU fallback).
-  const std::set<std::string> backends = parse_backends(options.backends);
-  impl_->cuapriltags_mode = backends.size() == 1 && *backends.begin() == "CUDA";
-  const std::set<std::string> supported = impl_->SupportedTagFamilies();
-  if (supported.find(options.tag_family) == supported.end()) {
-    std::ostringstream os;
-    os << "Tag family not supported by specified backend: '" << options.tag_family << "'" << std::endl;
-    os << "'tag_family' parameter must be one of:" << std::endl;
-    for (const auto& f : supported) os << f << std::endl;
-    std::fprintf(stderr, "[apriltag_node] FATAL: Tag family not supported by specified backend: '%s'\n", options.tag_family.c_str());
-    throw std::runtime_error(os.str());
-  }
-  impl_->family_enum = api().family_from_name(options.tag_family.c_str());
+  impl_->family_enum = validate_family(options, &impl_->cuapriltags_mode);
 }
 
 AprilTagNode::~AprilTagNode() {
@@ -322,6 +332,160 @@ bool AprilTagNode::CameraImageCallback(const Image& image, const CameraInfo& cam
   if (!impl_->initialized) impl_->Initialize(image, camera_info);
   impl_->OnCameraFrame(image, camera_info);
   return true;
+}
+
+// ---- AprilTagMultiCameraNode: S streams, one submission per round -----------------------------------------------------
+struct AprilTagMultiCameraNode::Impl {
+  NodeOptions opt;
+  uint32_t S = 0;
+  DetectionsCallback on_detections;
+  TransformsCallback on_transforms;
+  bool cuapriltags_mode = false, auto_flush = true, initialized = false;
+  int family_enum = -1;
+  amdAprilTagsHandle detector = nullptr;
+  uint32_t width = 0, height = 0;
+  uint8_t* d_mono = nullptr;       // S mono8 slots
+  size_t pitch = 0, slot_bytes = 0;
+  void* d_input = nullptr;         // staging for host / colour frames
+  size_t d_input_bytes = 0;
+  struct Slot { bool pending = false; Header info_header; std::array<double, 9> k{}; };
+  std::vector<Slot> slots;
+
+  void Initialize(const CameraInfo& info) {
+    if (opt.max_tags <= 0) throw std::runtime_error("'max_tags' must be positive");
+    amdAprilTagsConfig_t cfg;
+    api().default_config(&cfg, info.width, info.height);
+    cfg.tile_size = opt.tile_size;
+    cfg.decimate = opt.decimate;
+    cfg.num_families = 1;
+    cfg.families[0] = static_cast<amdAprilTagsFamily>(family_enum);
+    cfg.intrinsics.fx = static_cast<float>(info.k[0]);
+    cfg.intrinsics.fy = static_cast<float>(info.k[4]);
+    cfg.intrinsics.cx = static_cast<float>(info.k[2]);
+    cfg.intrinsics.cy = static_cast<float>(info.k[5]);
+    cfg.skew = cuapriltags_mode ? 0.0f : static_cast<float>(info.k[1]);   // (one skew per handle: the first stream's)
+    cfg.tag_size = static_cast<float>(opt.size);
+    cfg.max_batch = S;
+    const int error = api().create_ex(&detector, &cfg);
+    if (error != 0) throw std::runtime_error("Failed to create AprilTags detector (error code " + std::to_string(error) + ")");
+    width = info.width;
+    height = info.height;
+    pitch = (static_cast<size_t>(width) + 63) & ~static_cast<size_t>(63);
+    slot_bytes = pitch * height;
+    void* p = nullptr;
+    if (api().dev_alloc(&p, slot_bytes * S) != 0) throw std::runtime_error("device allocation failed");
+    d_mono = static_cast<uint8_t*>(p);
+    initialized = true;
+  }
+
+  // the frame of `stream` ends up as mono8 in its device slot
+  bool Stage(uint32_t stream, const Image& image, const CameraInfo& info) {
+    const int bpp = bytes_per_pixel(image.encoding);
+    if (bpp == 0) {
+      std::fprintf(stderr, "[apriltag_node] Unsupported image encoding: %s\n", image.encoding.c_str());
+      throw std::runtime_error("AprilTags detector only supports 'mono8', 'rgb8', 'bgr8', 'rgba8' or 'bgra8' image input");
+    }
+    if (image.width != width || image.height != height || info.width != width || info.height != height ||
+        static_cast<size_t>(image.step) < static_cast<size_t>(image.width) * bpp || image.data == nullptr) {
+      std::fprintf(stderr, "[apriltag_node] stream %u: image %ux%u (step %u) does not match the initialised size %ux%u: frame dropped\n",
+                   stream, image.width, image.height, image.step, width, height);
+      return false;
+    }
+    const uint8_t* dev_src = image.data;
+    uint8_t* slot = d_mono + slot_bytes * stream;
+    if (!image.is_device) {
+      const size_t bytes = static_cast<size_t>(image.step) * image.height;
+      if (bpp == 1 && image.step == pitch) {   // straight into the slot
+        if (api().copy_to_device(slot, image.data, bytes, nullptr) != 0) return false;
+        return true;
+      }
+      if (bytes > d_input_bytes) {
+        if (d_input) api().dev_free(d_input);
+        d_input = nullptr;
+        if (api().dev_alloc(&d_input, bytes) != 0) throw std::runtime_error("device allocation failed");
+        d_input_bytes = bytes;
+      }
+      if (api().copy_to_device(d_input, image.data, bytes, nullptr) != 0) return false;
+      dev_src = static_cast<const uint8_t*>(d_input);
+    }
+    // mono8 with another pitch is repacked by the conversion entry point as well (one 8-bit channel in, one out)
+    return api().to_mono8(dev_src, image.step, image.encoding.c_str(), image.width, image.height, slot, pitch, nullptr) == 0;
+  }
+};
+
+AprilTagMultiCameraNode::AprilTagMultiCameraNode(const NodeOptions& options, uint32_t num_streams) : impl_(new Impl()) {
+  if (num_streams == 0 || num_streams > 65535) throw std::runtime_error("'num_streams' must be 1..65535");
+  impl_->opt = options;
+  impl_->S = num_streams;
+  impl_->slots.resize(num_streams);
+  impl_->family_enum = validate_family(options, &impl_->cuapriltags_mode);
+}
+
+AprilTagMultiCameraNode::~AprilTagMultiCameraNode() {
+  if (impl_) {
+    if (impl_->detector) api().destroy(impl_->detector);
+    if (impl_->d_input) api().dev_free(impl_->d_input);
+    if (impl_->d_mono) api().dev_free(impl_->d_mono);
+  }
+}
+
+void AprilTagMultiCameraNode::set_detections_callback(DetectionsCallback cb) { impl_->on_detections = std::move(cb); }
+void AprilTagMultiCameraNode::set_transforms_callback(TransformsCallback cb) { impl_->on_transforms = std::move(cb); }
+void AprilTagMultiCameraNode::set_auto_flush(bool on) { impl_->auto_flush = on; }
+uint32_t AprilTagMultiCameraNode::num_streams() const { return impl_->S; }
+const NodeOptions& AprilTagMultiCameraNode::options() const { return impl_->opt; }
+
+bool AprilTagMultiCameraNode::CameraImageCallback(uint32_t stream, const Image& image, const CameraInfo& camera_info) {
+  if (stream >= impl_->S) throw std::runtime_error("stream index out of range");
+  if (image.header.stamp.sec != camera_info.header.stamp.sec || image.header.stamp.nanosec != camera_info.header.stamp.nanosec)
+    return false;  // ExactTime synchroniser would not fire
+  if (!impl_->initialized) impl_->Initialize(camera_info);
+  if (!impl_->Stage(stream, image, camera_info)) return false;
+  Impl::Slot& sl = impl_->slots[stream];
+  sl.pending = true;
+  sl.info_header = camera_info.header;
+  sl.k = camera_info.k;
+  if (impl_->auto_flush) {
+    bool all = true;
+    for (const auto& x : impl_->slots) all &= x.pending;
+    if (all) Flush();
+  }
+  return true;
+}
+
+uint32_t AprilTagMultiCameraNode::Flush() {
+  Impl& I = *impl_;
+  std::vector<uint32_t> who;
+  for (uint32_t s = 0; s < I.S; s++) if (I.slots[s].pending) who.push_back(s);
+  if (who.empty() || !I.initialized) return 0;
+  const uint32_t n = static_cast<uint32_t>(who.size());
+  std::vector<amdAprilTagsImageInput_t> imgs(n);
+  std::vector<amdAprilTagsCameraIntrinsics_t> intr(n);
+  for (uint32_t i = 0; i < n; i++) {
+    const Impl::Slot& sl = I.slots[who[i]];
+    imgs[i].width = I.width; imgs[i].height = I.height; imgs[i].dev_ptr = I.d_mono + I.slot_bytes * who[i]; imgs[i].pitch = I.pitch;
+    // K of the stream's own CameraInfo, double -> float as the reference does (src/apriltag_node.cpp:442-447)
+    intr[i].fx = static_cast<float>(sl.k[0]); intr[i].fy = static_cast<float>(sl.k[4]);
+    intr[i].cx = static_cast<float>(sl.k[2]); intr[i].cy = static_cast<float>(sl.k[5]);
+  }
+  const uint32_t max_tags = static_cast<uint32_t>(I.opt.max_tags);
+  std::vector<amdAprilTagsID_t> tags(static_cast<size_t>(n) * max_tags);
+  std::vector<uint32_t> counts(n, 0);
+  const int error = api().detect_batch(I.detector, n, imgs.data(), intr.data(), tags.data(), counts.data(), max_tags, nullptr);
+  for (uint32_t s : who) I.slots[s].pending = false;
+  if (error != 0) {
+    // the reference logs and drops the frame (src/apriltag_node.cpp:494-497); here: the round
+    std::fprintf(stderr, "[apriltag_node] Failed to run AprilTags detector (error code %d)\n", error);
+    return 0;
+  }
+  for (uint32_t i = 0; i < n; i++) {
+    AprilTagDetectionArray msg;
+    std::vector<TransformStamped> tfs;
+    assemble_messages(tags.data() + static_cast<size_t>(i) * max_tags, counts[i], I.slots[who[i]].info_header, I.opt.tag_family, &msg, &tfs);
+    if (I.on_detections) I.on_detections(who[i], msg);
+    if (I.on_transforms) I.on_transforms(who[i], tfs);
+  }
+  return n;
 }
 
 }  // namespace apriltag
@@ -413,6 +577,81 @@ int node_shell_on_frame(NodeShellHarness* h, const uint8_t* data, int is_device,
     if (err && err_len) { std::strncpy(err, e.what(), err_len - 1); err[err_len - 1] = 0; }
     return -2;
   }
+}
+
+// ---- the multi-camera node through the same flat view ----
+struct MultiShellHarness {
+  std::unique_ptr<amd::isaac_ros::apriltag::AprilTagMultiCameraNode> node;
+  std::vector<AprilTagDetectionArray> last;
+  std::vector<std::vector<TransformStamped>> last_tf;
+  std::vector<int> publishes;
+};
+
+MultiShellHarness* node_shell_multi_create(int num_streams, int max_tags, double size, int tile_size, const char* tag_family,
+                                           const char* backends, int decimate, int auto_flush, char* err, size_t err_len) {
+  try {
+    NodeOptions o;
+    o.max_tags = max_tags; o.size = size; o.tile_size = static_cast<uint16_t>(tile_size);
+    o.tag_family = tag_family; o.backends = backends; o.decimate = static_cast<uint32_t>(decimate);
+    auto* h = new MultiShellHarness();
+    h->node.reset(new amd::isaac_ros::apriltag::AprilTagMultiCameraNode(o, static_cast<uint32_t>(num_streams)));
+    h->node->set_auto_flush(auto_flush != 0);
+    h->last.resize(num_streams); h->last_tf.resize(num_streams); h->publishes.assign(num_streams, 0);
+    h->node->set_detections_callback([h](uint32_t s, const AprilTagDetectionArray& m) { h->last[s] = m; h->publishes[s]++; });
+    h->node->set_transforms_callback([h](uint32_t s, const std::vector<TransformStamped>& t) { h->last_tf[s] = t; });
+    return h;
+  } catch (const std::exception& e) {
+    if (err && err_len) { std::strncpy(err, e.what(), err_len - 1); err[err_len - 1] = 0; }
+    return nullptr;
+  }
+}
+
+void node_shell_multi_destroy(MultiShellHarness* h) { delete h; }
+
+// 1 staged, 0 not (stamps differ / dropped), -2 exception
+int node_shell_multi_on_frame(MultiShellHarness* h, int stream, const uint8_t* data, int is_device, const char* encoding, uint32_t width,
+                              uint32_t height, uint32_t step, const double* k9, const char* frame_id, int32_t sec, uint32_t nanosec,
+                              int32_t info_sec, uint32_t info_nanosec, char* err, size_t err_len) {
+  try {
+    Image img;
+    img.header.frame_id = "image_frame"; img.header.stamp.sec = sec; img.header.stamp.nanosec = nanosec;
+    img.width = width; img.height = height; img.step = step; img.encoding = encoding; img.data = data; img.is_device = is_device != 0;
+    CameraInfo info;
+    info.header.frame_id = frame_id; info.header.stamp.sec = info_sec; info.header.stamp.nanosec = info_nanosec;
+    info.width = width; info.height = height;
+    for (int i = 0; i < 9; i++) info.k[i] = k9[i];
+    return h->node->CameraImageCallback(static_cast<uint32_t>(stream), img, info) ? 1 : 0;
+  } catch (const std::exception& e) {
+    if (err && err_len) { std::strncpy(err, e.what(), err_len - 1); err[err_len - 1] = 0; }
+    return -2;
+  }
+}
+
+int node_shell_multi_flush(MultiShellHarness* h) { return static_cast<int>(h->node->Flush()); }
+int node_shell_multi_publishes(MultiShellHarness* h, int stream) { return h->publishes[stream]; }
+
+// the last message published for `stream`: number of detections (records in out), header frame / stamp through the outputs
+int node_shell_multi_last(MultiShellHarness* h, int stream, NodeShellDetection* out, int max_out, char* out_frame_id, size_t frame_id_len,
+                          int32_t* sec, uint32_t* nanosec) {
+  const auto& m = h->last[stream];
+  if (out_frame_id && frame_id_len) { std::strncpy(out_frame_id, m.header.frame_id.c_str(), frame_id_len - 1); out_frame_id[frame_id_len - 1] = 0; }
+  if (sec) *sec = m.header.stamp.sec;
+  if (nanosec) *nanosec = m.header.stamp.nanosec;
+  const int n = static_cast<int>(m.detections.size());
+  for (int i = 0; i < n && i < max_out; i++) {
+    const auto& d = m.detections[i];
+    NodeShellDetection& o = out[i];
+    std::memset(&o, 0, sizeof(o));
+    o.id = d.id;
+    std::strncpy(o.family, d.family.c_str(), sizeof(o.family) - 1);
+    o.center[0] = d.center.x; o.center[1] = d.center.y;
+    for (int c = 0; c < 4; c++) { o.corners[c][0] = d.corners[c].x; o.corners[c][1] = d.corners[c].y; }
+    o.position[0] = d.pose.pose.pose.position.x; o.position[1] = d.pose.pose.pose.position.y; o.position[2] = d.pose.pose.pose.position.z;
+    o.orientation_xyzw[0] = d.pose.pose.pose.orientation.x; o.orientation_xyzw[1] = d.pose.pose.pose.orientation.y;
+    o.orientation_xyzw[2] = d.pose.pose.pose.orientation.z; o.orientation_xyzw[3] = d.pose.pose.pose.orientation.w;
+    std::strncpy(o.child_frame_id, h->last_tf[stream][i].child_frame_id.c_str(), sizeof(o.child_frame_id) - 1);
+  }
+  return n;
 }
 
 }  // extern "C"

@@ -757,3 +757,68 @@ def test_point_capacity_grows_with_the_content(built):
     fixed.detect_batch_ex(t, max_dets=64)
     assert fixed.frame_flags(1)[0] & 1                             # reported, not grown
     fixed.close()
+
+
+def test_multi_camera_node(built):
+    """AprilTagMultiCameraNode: eight camera streams with their own intrinsics, frame ids and
+    stamps go through ONE node that stages the latest frame of each and submits them as one batch.  Every stream's message
+    -- header (the stream's camera_info header), detections, poses, TF child names -- equals, field for field, what an
+    AprilTagNode of its own publishes for the same frame; a mismatched stamp stages nothing; a partial round is served
+    by flush().  The wall time of both ways is printed (one batched submission against eight one-frame submissions)."""
+    import time
+    from isaac_ros_apriltag_amd import build as b
+    from isaac_ros_apriltag_amd import node, streams
+    b.build_node()
+    S = 8
+    block = streams.make_param_block(S)
+    frames, Ks = [], []
+    for s_ in range(S):
+        sp = streams.stream_params(block, s_)
+        frames.append(np.ascontiguousarray(synth.scene_c2(seed=int(sp["seed"]), sigma=2.0)[0]))
+        Ks.append([sp["fx"], 0.0, sp["cx"], 0.0, sp["fy"], sp["cy"], 0.0, 0.0, 1.0])
+    multi = node.AprilTagMultiCameraNode(S)
+    singles = [node.AprilTagNode() for _ in range(S)]
+    try:
+        # a pair whose stamps differ is not a pair
+        assert not multi.on_frame(0, frames[0].ctypes.data, False, "mono8", 1920, 1080, 1920, Ks[0], "cam0", (5, 1), (5, 2))
+        want = []
+        for s_ in range(S):   # warm-up + reference messages from eight independent nodes
+            dets, fid = singles[s_].on_frame(frames[s_].ctypes.data, False, "mono8", 1920, 1080, 1920, Ks[s_], "cam%d" % s_, (7, 100 + s_))
+            assert fid == "cam%d" % s_ and len(dets) == 10
+            want.append(dets)
+        for rnd in range(3):
+            for s_ in range(S):
+                assert multi.publishes(s_) == rnd
+                assert multi.on_frame(s_, frames[s_].ctypes.data, False, "mono8", 1920, 1080, 1920, Ks[s_], "cam%d" % s_, (7 + rnd, 100 + s_))
+            for s_ in range(S):   # the eighth frame completed the round: everything is published
+                assert multi.publishes(s_) == rnd + 1
+                dets, fid, stamp = multi.last(s_)
+                assert fid == "cam%d" % s_ and stamp == (7 + rnd, 100 + s_)
+                assert dets == want[s_], (rnd, s_)
+        # a partial round: three streams, served by flush()
+        for s_ in (1, 4, 6):
+            assert multi.on_frame(s_, frames[s_].ctypes.data, False, "mono8", 1920, 1080, 1920, Ks[s_], "cam%d" % s_, (20, s_))
+        assert multi.publishes(4) == 3 and multi.flush() == 3 and multi.publishes(4) == 4 and multi.publishes(0) == 3
+        assert multi.last(6)[0] == want[6] and multi.last(6)[2] == (20, 6)
+        # timing: frames already on the device, so that both ways measure submissions, not the H2D copy
+        dev = [torch.from_numpy(f).cuda() for f in frames]
+        torch.cuda.synchronize()
+        reps = 20
+        t0 = time.perf_counter()
+        for r in range(reps):
+            for s_ in range(S):
+                singles[s_].on_frame(dev[s_].data_ptr(), True, "mono8", 1920, 1080, 1920, Ks[s_], "cam%d" % s_, (30 + r, s_))
+        t_single = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for r in range(reps):
+            for s_ in range(S):
+                multi.on_frame(s_, dev[s_].data_ptr(), True, "mono8", 1920, 1080, 1920, Ks[s_], "cam%d" % s_, (30 + r, s_))
+        t_multi = (time.perf_counter() - t0) / reps
+        print("\n8 streams, one round: eight AprilTagNode calls %.2f ms (%.0f frames/s), one AprilTagMultiCameraNode round %.2f ms (%.0f frames/s)"
+              % (t_single * 1e3, S / t_single, t_multi * 1e3, S / t_multi))
+        assert multi.last(3)[0] == want[3]
+        assert t_multi < t_single
+    finally:
+        multi.close()
+        for n_ in singles:
+            n_.close()
