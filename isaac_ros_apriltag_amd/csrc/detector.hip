@@ -171,6 +171,7 @@ struct amdAprilTagsDetector_st {
   unsigned long long* d_fqprof = nullptr;  // per-phase cycle counters of k_fit_quads (-DAMDAT_FQ_PROFILE builds only)
   FqClass cls[FQ_NCLS];
   FqWorkLayout work_layout;
+  int prefilter_class = 2;           // first size class whose clusters go through k_fit_prefilter (those above 2048 points)
   bool grow_points = false;          // point capacity follows the content (no explicit max_points)
   uint32_t pcap_hard = 0;            // 2 points per working pixel: what any content stays below
   size_t point_buffer_bytes[5] = {0, 0, 0, 0, 0};
@@ -353,7 +354,7 @@ static int alloc_point_buffers(amdAprilTagsDetector_st* D) {
   }
   void** bufs[5] = {(void**)&D->d_stage, (void**)&D->d_rank, (void**)&D->d_pts, (void**)&D->d_work, (void**)&D->d_work2};
   const size_t bytes[5] = {B * (size_t)P.pcap * 8, B * (size_t)P.pcap * 4, B * (size_t)P.pcap * 4, (size_t)off * 4,
-                           ((size_t)off - D->work_layout.off[FQ_PREFILTER_CLASS]) * 4};
+                           ((size_t)off - D->work_layout.off[D->prefilter_class]) * 4};
   for (int i = 0; i < 5; i++) {
     if (*bufs[i]) { hipFree(*bufs[i]); *bufs[i] = nullptr; D->device_bytes -= D->point_buffer_bytes[i]; D->point_buffer_bytes[i] = 0; }
   }
@@ -480,6 +481,10 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
     c[1] = {128, FQ_B12, FQ_B01, FQ_B12, minu((unsigned)FQ_GRID_128 * cus, 1024u * (unsigned)B), FQ_B12, FQ_POP1};
     c[2] = {256, 4096, FQ_B12, 4096, minu(4u * cus, 256u * (unsigned)B), 4096, FQ_POP2};
     c[3] = {512, 8192, 4096, 8192, minu(2u * cus, 64u * (unsigned)B), 8192, 1};
+    // (a "latency layout" for small-batch handles -- about three times the threads per cluster: 64 up to 256 points, 128 up
+    // to 768, 256 up to 2048, 512 up to 8192 -- measured slower on one-frame submissions, 0.36 against 0.28 ms for the
+    // stage: the larger workgroups' barriers cost more than the shorter per-lane runs save)
+    D->prefilter_class = 2;
     c[4] = {FQ_NT_BIG, 16384, 8192, 0x7FFFFFFF, minu(cus, 16u * (unsigned)B), P.max_cluster_points, 1};
     if (P.max_cluster_points > 16384 && P.max_cluster_points <= 18432) c[4].sort_cap = (P.max_cluster_points + 63) & ~63;
     if (c[4].slot_cap < 8193) c[4].slot_cap = 8193;
@@ -691,7 +696,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
   {
     // keys | pair-table region
     // skewed key array (later: errors, candidates, pair tables) | group prefixes of the early-exit test (not in the one-wave class)
-    auto lds_bytes = [](const FqClass& c) { return (size_t)FQ_KP(c.sort_cap) * 8 + (c.nt > 64 ? (size_t)FQ_TABLE_DOUBLES * 8 : 0); };
+    auto lds_bytes = [](const FqClass& c) { return FQ_KEY_BYTES(c.sort_cap) + (c.nt > 64 ? (size_t)FQ_TABLE_DOUBLES * 8 : 0); };
 
     // The classes are independent (they only append to the quad list).  Every class's persistent grid can fill the
     // chip's register file by itself, so whichever workgroups are placed first stay until their list is empty, and the
@@ -705,17 +710,32 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
     // cheap exits of the large classes (bounding box, border direction, sector test) at full occupancy, ahead of their
     // persistent workgroups, which pop the survivors from the compact lists it writes (d_work2, counts at d_workctl + 16)
 #ifndef AMDAT_FQ_NO_PREFILTER
-    const bool prefilter = P.max_cluster_points > D->cls[FQ_PREFILTER_CLASS].lo && D->d_work2;
+    const bool prefilter = P.max_cluster_points > D->cls[D->prefilter_class].lo && D->d_work2;
 #else
     const bool prefilter = false;
 #endif
-    uint32_t* const work2 = D->d_work2 ? D->d_work2 - D->work_layout.off[FQ_PREFILTER_CLASS] : nullptr;   // (indexed with the common layout)
+    uint32_t* const work2 = D->d_work2 ? D->d_work2 - D->work_layout.off[D->prefilter_class] : nullptr;   // (indexed with the common layout)
+    // A small submission (the node's one-frame calls) is over when its slowest chain is: there the 256-thread class starts
+    // at once beside the small classes (its in-kernel test after the first walk still drops most of its clusters) and
+    // only the two largest classes wait for the prefilter -- prefilter, then the survivors' sort, was the longest chain.
+    const bool small = (uint64_t)n * (uint64_t)P.W * (uint64_t)P.H < (16ull << 20);
+    const int pf_first = small ? D->prefilter_class + 1 : D->prefilter_class;
     auto launch_prefilter = [&](hipStream_t sp) {
       if (!prefilter) return;
-      unsigned gp = (2048u / FQ_PF_NT) * (unsigned)D->num_cus;
-      if (gp > 256u * n) gp = 256u * n;
-      hipLaunchKernelGGL(k_fit_prefilter, dim3(gp), dim3(FQ_PF_NT), 0, sp, D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work,
-                         D->d_workctl, work2, D->d_workctl + 16, D->work_layout, FQ_PREFILTER_CLASS, (D->fq_counters ? D->d_fqprof : nullptr), P);
+      // small submissions: one cluster per CU-wide workgroup (latency); otherwise one per wave (throughput)
+      const bool wide = small;
+#define PF_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work, D->d_workctl, work2, D->d_workctl + 16, D->work_layout,   \
+                pf_first, (D->fq_counters ? D->d_fqprof : nullptr), P
+      if (wide) {
+        unsigned gp = 2u * (unsigned)D->num_cus;
+        if (gp > 256u * n) gp = 256u * n;
+        hipLaunchKernelGGL(k_fit_prefilter<1024>, dim3(gp), dim3(1024), 0, sp, PF_ARGS);
+      } else {
+        unsigned gp = 32u * (unsigned)D->num_cus;
+        if (gp > 256u * n) gp = 256u * n;
+        hipLaunchKernelGGL(k_fit_prefilter<64>, dim3(gp), dim3(64), 0, sp, PF_ARGS);
+      }
+#undef PF_ARGS
     };
     auto launch_class = [&](int c, hipStream_t sc) {
       const FqClass& cl = D->cls[c];
@@ -725,7 +745,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
       const bool big = c == FQ_NCLS - 1;
       // a small submission spreads its clusters over the workgroups one by one (latency); large ones pop in chunks
       const int pop = cl.pop < (int)(n / 16u) ? cl.pop : ((int)(n / 16u) < 1 ? 1 : (int)(n / 16u));
-      const bool filtered = prefilter && c >= FQ_PREFILTER_CLASS;
+      const bool filtered = prefilter && c >= pf_first;
 #define FQ_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, (filtered ? work2 : D->d_work) + D->work_layout.off[c],                 \
                 D->d_workctl + (filtered ? 16 : 0) + c,                                                                                \
                 D->work_layout.cap[c], D->d_workctl + 8 + c, cl.d_lf, (big ? D->d_keys_scr : nullptr), cl.d_errs,                        \
@@ -755,12 +775,14 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
       // classes first on the submission stream -- they find only the prefilter's few survivors in their lists and are gone
       // before the small classes have filled the chip -- and the two small classes on side streams, the 128-thread class
       // (the longest chain) first.
-      launch_prefilter(s);
+      // A small submission leaves most of the chip empty either way: its classes below the prefilter start at once on the
+      // side streams, beside the prefilter.
+      if (!small) launch_prefilter(s);
       HIP_TRY(hipEventRecord(D->ev_fork, s));
       for (int a = 0; a < 3; a++) HIP_TRY(hipStreamWaitEvent(aux[a], D->ev_fork, 0));
-      for (int c = FQ_PREFILTER_CLASS; c < FQ_NCLS; c++) launch_class(c, s);   // (nearly all survivors are in the first of them)
-      launch_class(1, aux[0]);
-      launch_class(0, aux[1]);
+      if (small) launch_prefilter(s);
+      for (int c = pf_first; c < FQ_NCLS; c++) launch_class(c, s);   // (nearly all survivors are in the first of them)
+      for (int c = pf_first - 1, a = 0; c >= 0; c--, a++) launch_class(c, aux[a % 3]);   // the longest chains first
     } else {
     if (large_first) {
       launch_class(3, s);

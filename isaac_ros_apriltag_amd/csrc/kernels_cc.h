@@ -237,56 +237,47 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   }
 }
 
-// Links of pixel (gx,gy) selected by `which` (bit0 left, bit1 up, bit2 up-left, bit3 up-right),
-// evaluated on the global threshold image with the same first-overlap rules as the tile kernel.
-__device__ __forceinline__ void cc_global_links(const uint8_t* thr, uint32_t* label, int W, int H, int WS, int gx, int gy,
-                                                int which) {
-  if (gx < 1 || gx > W - 2 || gy >= H) return;
+// Link requests of the border pass: up to three (pixel, partner) pairs per thread; a slot without a link holds
+// AT_NO_LABEL.  Pixel (gx, gy) on a tile-top row: its up, up-left and up-right links, evaluated on the global threshold
+// image with the same first-overlap rules as the tile kernel.
+__device__ __forceinline__ void cc_row_requests(const uint8_t* thr, int W, int H, int WS, int gx, int gy, uint32_t (&ra)[3], uint32_t (&rb)[3]) {
+  if (gx < 1 || gx > W - 2 || gy >= H || gy == 0) return;
   const uint32_t v = thr[(size_t)gy * WS + gx];
   if (v == 127) return;
   const uint32_t me = (uint32_t)(gy * W + gx);
-  // The entry of a pixel that is not a tile-local root never changes in this kernel (only root entries are
-  // lowered by atomicMin), so the first hop of either endpoint -- pixel -> its tile-local root -- is a plain cached
-  // load; the device-scope loads of the find start at the roots.
-  auto link = [&](uint32_t other) { glb_union(label, label[me], label[other]); };
   const uint32_t vl = thr[(size_t)gy * WS + gx - 1];
-  if ((which & 1) && vl == v) link(me - 1);
-  if (gy == 0) return;
   const uint32_t vu = thr[(size_t)(gy - 1) * WS + gx];
   const uint32_t vul = thr[(size_t)(gy - 1) * WS + gx - 1];
   const bool left_src = gx - 1 >= 1;
-  if ((which & 2) && vu == v && !(left_src && vl == v && vul == v)) link(me - W);
+  if (vu == v && !(left_src && vl == v && vul == v)) { ra[0] = me; rb[0] = me - W; }
   if (v == 255) {
-    if ((which & 4) && vul == 255 && vu != 255 && !(left_src && vl == 255)) link(me - W - 1);
-    if (which & 8) {
-      const uint32_t vur = thr[(size_t)(gy - 1) * WS + gx + 1];
-      const uint32_t vr = thr[(size_t)gy * WS + gx + 1];
-      const bool right_src = gx + 1 <= W - 2;
-      if (vur == 255 && !(right_src && (vu == 255 || vr == 255))) link(me - W + 1);
-    }
+    if (vul == 255 && vu != 255 && !(left_src && vl == 255)) { ra[1] = me; rb[1] = me - W - 1; }
+    const uint32_t vur = thr[(size_t)(gy - 1) * WS + gx + 1];
+    const uint32_t vr = thr[(size_t)gy * WS + gx + 1];
+    const bool right_src = gx + 1 <= W - 2;
+    if (vur == 255 && !(right_src && (vu == 255 || vr == 255))) { ra[2] = me; rb[2] = me - W + 1; }
   }
 }
 
 // Links across the vertical border between column gx - 1 (last of the left tile) and gx (first of the right tile) in
-// row gy, with the rules of cc_global_links: the left link and the up-left link of pixel (gx, gy), and the up-right link
-// of pixel (gx - 1, gy).  All three read the same 2 x 2 block of the threshold image, so one thread takes them (on
-// tile-top rows only the left link: the row pass owns every upward link of those rows).
-__device__ __forceinline__ void cc_column_links(const uint8_t* thr, uint32_t* label, int W, int H, int WS, int gx, int gy) {
+// row gy: the left link and the up-left link of pixel (gx, gy), and the up-right link of pixel (gx - 1, gy).  All three
+// read the same 2 x 2 block of the threshold image, so one thread takes them (on tile-top rows only the left link: the
+// row pass owns every upward link of those rows).
+__device__ __forceinline__ void cc_column_requests(const uint8_t* thr, int W, int H, int WS, int gx, int gy, uint32_t (&ra)[3], uint32_t (&rb)[3]) {
   if (gy >= H) return;
   const uint32_t vL = thr[(size_t)gy * WS + gx - 1], vR = thr[(size_t)gy * WS + gx];
   const bool upward = (gy % CC_T) != 0;
   uint32_t vLu = 127, vRu = 127;
   if (upward) { vLu = thr[(size_t)(gy - 1) * WS + gx - 1]; vRu = thr[(size_t)(gy - 1) * WS + gx]; }
   const uint32_t meR = (uint32_t)(gy * W + gx), meL = meR - 1;
-  auto link = [&](uint32_t a, uint32_t b2) { glb_union(label, label[a], label[b2]); };
   if (gx <= W - 2 && vR != 127) {                      // (gx, gy) is a link source
     // (the same link one row up, with both pixels joined to their upper neighbours inside their tiles, already implies it)
-    if (vL == vR && !(upward && vLu == vR && vRu == vR)) link(meR, meL);
-    if (upward && vR == 255 && vLu == 255 && vRu != 255 && vL != 255) link(meR, meR - W - 1);
+    if (vL == vR && !(upward && vLu == vR && vRu == vR)) { ra[0] = meR; rb[0] = meL; }
+    if (upward && vR == 255 && vLu == 255 && vRu != 255 && vL != 255) { ra[1] = meR; rb[1] = meR - W - 1; }
   }
   if (upward && vL == 255) {                            // (gx - 1, gy) is a source (1 <= gx - 1 <= W - 2 always)
     const bool right_src = gx <= W - 2;
-    if (vRu == 255 && !(right_src && (vLu == 255 || vR == 255))) link(meL, meL - W + 1);
+    if (vRu == 255 && !(right_src && (vLu == 255 || vR == 255))) { ra[2] = meL; rb[2] = meL - W + 1; }
   }
 }
 
@@ -300,13 +291,37 @@ __global__ __launch_bounds__(256) void k_cc_border(const uint8_t* __restrict__ t
   const int nrows = (H - 1) / CC_T;  // tile-top rows at y = 64, 128, ...
   const int ncols = (W - 1) / CC_T;  // tile-left columns at x = 64, 128, ...
   int i = blockIdx.x * 256 + threadIdx.x;
+  uint32_t ra[3] = {AT_NO_LABEL, AT_NO_LABEL, AT_NO_LABEL}, rb[3] = {AT_NO_LABEL, AT_NO_LABEL, AT_NO_LABEL};
   if (i < nrows * W) {
-    const int gy = (i / W + 1) * CC_T, gx = i % W;
-    cc_global_links(thr, label, W, H, P.WS, gx, gy, 2 | 4 | 8);
-    return;
+    cc_row_requests(thr, W, H, P.WS, i % W, (i / W + 1) * CC_T, ra, rb);
+  } else {
+    i -= nrows * W;
+    if (i < ncols * H) cc_column_requests(thr, W, H, P.WS, (i / H + 1) * CC_T, i % H, ra, rb);
   }
-  i -= nrows * W;
-  if (i < ncols * H) cc_column_links(thr, label, W, H, P.WS, (i / H + 1) * CC_T, i % H);
+  // The entry of a pixel that is not a tile-local root never changes in this kernel (only root entries are lowered by
+  // atomicMin), so the first hop of either endpoint -- pixel -> its tile-local root -- is a plain cached load; the
+  // device-scope loads of the find start at the roots.  Along a tile border most links join the SAME two tile-local
+  // roots again and again (the big components of a textured background cross it dozens of times): a wave keeps one
+  // request per distinct pair of roots (a few leader rounds; what they do not cover is simply linked twice).
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    uint32_t a = AT_NO_LABEL, b2 = AT_NO_LABEL;
+    if (ra[k] != AT_NO_LABEL) {
+      a = label[ra[k]]; b2 = label[rb[k]];
+      if (a > b2) { const uint32_t t = a; a = b2; b2 = t; }
+      if (a == b2) a = b2 = AT_NO_LABEL;   // already the same tile-local root
+    }
+    unsigned long long todo = __ballot(a != AT_NO_LABEL);
+    bool mine = a != AT_NO_LABEL;
+    for (int round = 0; round < 6 && todo; round++) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const uint32_t la = (uint32_t)__builtin_amdgcn_readlane((int)a, leader), lb = (uint32_t)__builtin_amdgcn_readlane((int)b2, leader);
+      const bool same = a == la && b2 == lb;
+      if (same && (int)lane_id() != leader) mine = false;
+      todo &= ~__ballot(same);
+    }
+    if (mine) glb_union(label, a, b2);
+  }
 }
 
 // one thread per tile-local root of the frame
@@ -319,14 +334,42 @@ __global__ __launch_bounds__(256) void k_cc_sizes(uint32_t* __restrict__ label_a
   uint32_t* csize = csize_all + (size_t)frame * n;
   const uint32_t* roots = roots_all + (size_t)frame * P.rcap;
   const uint32_t nroots = counters[frame].nroots;
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nroots; i += gridDim.x * 256) {
-    const uint32_t p = roots[i];
-    uint32_t r = p, q;
-    while ((q = glb_load(&label[r])) != r) r = q;
-    if (r != p) {
-      label[p] = r;  // every chain through p now ends in one more hop
-      atomicAdd(&csize[r], csize[p]);
+  // A frame with textured background has a few giant components with tens of thousands of tile-local roots each: one
+  // atomicAdd per root on the representative's size serialised on a single address (most of this kernel's time, 80 us
+  // of a single frame's latency).  The adds of a wave are combined per representative first: leader rounds over the
+  // distinct representatives of the wave (bounded; the rest add directly), so a hot representative sees one add per wave.
+  const uint32_t stride = gridDim.x * 256;
+  for (uint32_t i0 = blockIdx.x * 256; i0 < nroots; i0 += stride) {   // (uniform trip count per wave: ballots below)
+    const uint32_t i = i0 + threadIdx.x;
+    uint32_t r = AT_NO_LABEL, add = 0;
+    if (i < nroots) {
+      const uint32_t p = roots[i];
+      uint32_t q;
+      r = p;
+      while ((q = glb_load(&label[r])) != r) r = q;
+      if (r != p) {
+        label[p] = r;  // every chain through p now ends in one more hop
+        add = csize[p];
+      } else {
+        r = AT_NO_LABEL;
+      }
     }
+    unsigned long long todo = __ballot(r != AT_NO_LABEL);
+    for (int round = 0; round < 4 && todo; round++) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const uint32_t rl = (uint32_t)__builtin_amdgcn_readlane((int)r, leader);
+      const bool mine = r == rl;
+      const unsigned long long grp = __ballot(mine);
+      uint32_t v = mine ? add : 0u;
+#define OP(Cc, Mm) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, Cc, Mm, 0xF, true);
+      OP(0x111, 0xF) OP(0x112, 0xF) OP(0x114, 0xF) OP(0x118, 0xF) OP(0x142, 0xA) OP(0x143, 0xC)
+#undef OP
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+      if ((int)lane_id() == leader) atomicAdd(&csize[rl], total);
+      if (mine) r = AT_NO_LABEL;
+      todo &= ~grp;
+    }
+    if (r != AT_NO_LABEL) atomicAdd(&csize[r], add);
   }
 }
 

@@ -287,14 +287,13 @@ __device__ __forceinline__ void fit_line_dev(const double* lf, int sz, int i0, i
 // test rejects with 64 groups, 68 % with 32 (tools/early_exit_power.py, CPU restatement); the one-wave class (up to
 // 768 points) gains nothing from it and does not run it.
 #define FQ_XG 32
-// The pre-sort sector test runs in k_fit_prefilter for the classes from FQ_PREFILTER_CLASS on.  (Inside k_fit_quads --
+// The pre-sort sector test runs in k_fit_prefilter for the clusters above 2048 points.  (Inside k_fit_quads --
 // kept for comparison builds, -DFQ_PRESORT_MIN_NT=256 -- the large classes paid for it with one or two workgroups per CU;
 // the 128-thread class gains nothing from it either way: 7 % of its points rejected for 27 % of its cycles, its clusters
 // are small against the 64 x 16 tiles the points arrive in, so the sector changes at almost every point.)
 #ifndef FQ_PRESORT_MIN_NT
 #define FQ_PRESORT_MIN_NT (1 << 20)
 #endif
-#define FQ_PREFILTER_CLASS 2
 // Moments m = hi - lo (+ add) of the groups strictly between two cuts; returns false only if lambda_min of their scatter
 // certainly exceeds thr * Wc.  Division- and root-free: with W = m5, A = W m2 - m0^2, B = W m3 - m0 m1, C = W m4 - m1^2 (W times
 // the scatter matrix) and c = thr * Wc, both eigenvalues of the scatter exceed c exactly when (A - cW) + (C - cW) > 0 and
@@ -623,6 +622,8 @@ template <int NT, bool SPLIT>
 #define FQ_SEL_REGS 8          // maxima candidates per lane held in registers during the top-10 selection
 #define FQ_SMOOTH_REGS_OF(NT) ((NT) >= 1024 ? 8 : 16)   // smoothed errors per thread kept in registers (clusters up to that many x threads)
 #define FQ_TABLE_DOUBLES ((FQ_XG + 1) * 7)   // prefixes over FQ_XG groups, up to seven sums each
+// bytes of the key array region: the skewed keys, and at least the twelve pair tables that take the region over later
+#define FQ_KEY_BYTES(sort_cap) ((size_t)FQ_KP(sort_cap) * 8 > (size_t)(12 * 45 * 8) ? (size_t)FQ_KP(sort_cap) * 8 : (size_t)(12 * 45 * 8))
 #define FQ_PIDX(a, b) ((((a) * (19 - (a))) >> 1) + (b) - (a) - 1)   // a < b < 10 -> 0..44
 #ifndef FQ_WPE_64
 #define FQ_WPE_64 4
@@ -646,10 +647,10 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
                                                    int pop, DetParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fq_smem[];
   unsigned long long* skeys = reinterpret_cast<unsigned long long*>(fq_smem);
-  double* chunk = reinterpret_cast<double*>(fq_smem + (size_t)FQ_KP(sort_cap) * 8);   // (the key array is skewed); prefixes of the early-exit tests
+  double* chunk = reinterpret_cast<double*>(fq_smem + FQ_KEY_BYTES(sort_cap));   // (the key array is skewed); prefixes of the early-exit tests
   // Twelve tables over the 45 index pairs a < b < 10 (triangular index FQ_PIDX): error, mse and the four line parameters
   // of the forward segment a -> b and of the wrap-around segment b -> a.  They live in the key array, which is dead once
-  // the maxima are selected (4320 bytes; the smallest class's key array holds 6336).
+  // the maxima are selected (4320 bytes: FQ_KEY_BYTES keeps the region at least that large).
   double* const s_tab = reinterpret_cast<double*>(fq_smem);
   double* const s_ferr = s_tab; double* const s_fmse = s_tab + 45; double* const s_fex = s_tab + 90; double* const s_fey = s_tab + 135;
   double* const s_fnx = s_tab + 180; double* const s_fny = s_tab + 225;
@@ -1497,16 +1498,17 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
 // here decides anything k_fit_quads would decide differently: bounding box and border direction are its own tests, and the
 // sector test only fires when no corner choice can be admissible.  Items are taken in a fixed stride (largest class
 // first, so that neighbouring items are of similar size): a shared cursor would saturate here as well.
-#ifndef FQ_PF_NT
-#define FQ_PF_NT 64      // one wave per cluster: no workgroup barriers, and four times as many clusters in flight per CU as with
-                         // 256 threads (a cluster's chain of dependent loads, reductions and LDS round trips is what takes the time)
-#endif
-#define FQ_PF_CHUNK (8 * FQ_PF_NT)     // points staged in LDS per round (eight per thread)
+// Two instances: 64 threads -- one wave per cluster, no workgroup barriers, as many clusters in flight as the chip holds
+// waves (throughput-sized submissions: tens of thousands of clusters) -- and 1024 threads, where one cluster's points are
+// spread over a whole CU (small submissions: a single frame has ~120 such clusters and 256 CUs to put them on; with one
+// wave each the largest cluster alone took 0.2 ms).
+template <int FQ_PF_NT>
 __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
                                                        const uint32_t* __restrict__ pts_all, const ClusterRec* __restrict__ clusters_all,
                                                        const uint32_t* __restrict__ work, const uint32_t* __restrict__ work_n,
                                                        uint32_t* __restrict__ work_out, uint32_t* __restrict__ work_n_out,
                                                        FqWorkLayout L, int first_class, unsigned long long* __restrict__ prof, DetParams P) {
+  constexpr int FQ_PF_CHUNK = 8 * FQ_PF_NT;     // points staged in LDS per round (eight per thread)
   __shared__ __attribute__((aligned(16))) uint32_t spts[FQ_PF_CHUNK];
   __shared__ double sB[(64 + 1) * 7];   // sums of the 64 sectors, then their prefixes
   __shared__ long long s_dot[FQ_PF_NT / 64][3];
@@ -1684,7 +1686,11 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
       // with all 64 (config 2: 84 % of the points above 2048 per cluster fail the first test, 96 % the second)
       reject = !fq_feasible<FQ_PF_NT, 14, 6>(sB, P.max_line_fit_mse, W, H, s_okf, s_okw, &s_feasible);
       PF_TICK(62)
-      if (!reject && FQ_PF_NT == 64) reject = !fq_feasible64<7, 6>(sB, P.max_line_fit_mse, W, H);
+      if (!reject) {   // (one wave evaluates the 64 x 64 relation; a larger workgroup waits for its verdict)
+        if (tid < 64) { const bool f64 = fq_feasible64<7, 6>(sB, P.max_line_fit_mse, W, H); if (tid == 0) s_feasible = f64 ? 1 : 0; }
+        __syncthreads();
+        reject = s_feasible == 0;
+      }
       PF_TICK(63)
     }
     if (!reject && tid == 0) {
