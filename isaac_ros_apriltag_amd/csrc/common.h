@@ -6,6 +6,8 @@
 #include <stdint.h>
 
 #define AT_NO_LABEL 0xFFFFFFFFu
+#define AT_LABEL_BIG 0x80000000u    // on a root's own label entry: the component has at least min_component_size pixels
+#define AT_LABEL_MASK 0x7FFFFFFFu
 #define AT_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 #define AT_INVALID_SLOT 0xFFFFFFFFu
 #define AT_MAX_FAMILIES 4

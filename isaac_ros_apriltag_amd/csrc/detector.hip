@@ -168,6 +168,7 @@ struct amdAprilTagsDetector_st {
   FrameCounters* d_counters = nullptr;
   FrameDesc* d_frames = nullptr;
   uint64_t* d_codes[AT_MAX_FAMILIES] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned long long* d_ptprof = nullptr;  // per-phase cycle counters of k_points (same builds), inside d_fqprof's allocation
   unsigned long long* d_fqprof = nullptr;  // per-phase cycle counters of k_fit_quads (-DAMDAT_FQ_PROFILE builds only)
   FqClass cls[FQ_NCLS];
   FqWorkLayout work_layout;
@@ -528,7 +529,8 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   alloc((void**)&D->d_order, B * (size_t)P.dcap * 2);
   alloc((void**)&D->d_counters, B * sizeof(FrameCounters));
   alloc((void**)&D->d_frames, B * sizeof(FrameDesc));
-  alloc((void**)&D->d_fqprof, 64 * 8);
+  alloc((void**)&D->d_fqprof, (64 + 8) * 8);
+  D->d_ptprof = D->d_fqprof + 64;   // k_points' phase counters follow the quad fit's
   for (int i = 0; ok && i < P.nfam; i++) {
     const FamilyHost& f = g_families[cfg.families[i]];
     alloc((void**)&D->d_codes[i], (size_t)f.ncodes * 8);
@@ -676,7 +678,8 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
   }
   mark();
   hipLaunchKernelGGL(k_points, dim3((P.W + PT_TW - 1) / PT_TW, (P.H + PT_TH - 1) / PT_TH, n), dim3(256), 0, s, D->d_thr,
-                     D->d_label, D->d_csize, D->d_hkeys, D->d_hcnt, D->d_stage, D->d_rank, D->d_counters, P);
+                     D->d_label, D->d_csize, D->d_hkeys, D->d_hcnt, D->d_stage, D->d_rank, D->d_counters,
+                     (D->fq_counters ? D->d_ptprof : nullptr), P);
   mark();
   hipLaunchKernelGGL(k_cluster_select, dim3((P.hcap + 1023) / 1024, 1, n), dim3(256), 0, s, D->d_hkeys, D->d_hcnt, D->d_hoff,
                      D->d_clusters, D->d_counters, P);
@@ -833,7 +836,7 @@ static int enqueue_submission(amdAprilTagsDetector_st* D, uint32_t n, uint32_t o
   HIP_TRY(hipMemsetAsync(D->d_workctl, 0, 32 * 4, s));
   HIP_TRY(hipMemsetAsync(D->d_hkeys, 0xFF, (size_t)n * P.hcap * 8, s));
   HIP_TRY(hipMemsetAsync(D->d_hcnt, 0, (size_t)n * P.hcap * 4, s));
-  if (D->fq_counters) HIP_TRY(hipMemsetAsync(D->d_fqprof, 0, 64 * 8, s));
+  if (D->fq_counters) HIP_TRY(hipMemsetAsync(D->d_fqprof, 0, (64 + 8) * 8, s));
   mark();
   {
     const int rc = issue_pipeline(D, n, s, mark);
@@ -1152,7 +1155,7 @@ int amdAprilTagsDebugCopy(amdAprilTagsHandle handle, uint32_t frame, amdAprilTag
       sz = (size_t)(fc.nquads < P.qcap ? fc.nquads : P.qcap) * sizeof(QuadRec);
       break;
     case AMDAT_DBG_FQPROF:
-      src = handle->d_fqprof; sz = 64 * 8;
+      src = handle->d_fqprof; sz = (64 + 8) * 8;
       break;
     case AMDAT_DBG_COUNTS: {
       uint32_t c[8] = {fc.npoints_raw, fc.nclusters, fc.npoints_kept, fc.nquads, fc.ndets, fc.flags, (uint32_t)P.W, (uint32_t)P.H};

@@ -15,7 +15,12 @@
 //                and its pixel count is added there.  Pixels keep the index of their tile-local root, so
 //                a consumer reaches the representative with two loads (label[label[p]]) and the image-wide
 //                flatten pass (12 B/pixel of traffic) is not needed.
-//   k_cc_resolve second pass over the root list: non-representative roots receive the component's total size.
+//   k_cc_resolve second pass over the root list: every listed root's entry becomes representative | AT_LABEL_BIG (bit 31 set
+//                when the component has at least min_component_size pixels).  Roots of components that lie inside one tile
+//                got the bit from k_cc_local already.  A consumer then needs ONE dependent load per pixel --
+//                e = label[label[p] & AT_LABEL_MASK]: representative e & AT_LABEL_MASK, "large enough" e >> 31 -- and no
+//                size gather at all (k_points used to fetch label[l] and csize[l]: two cache lines per root, a quarter of
+//                its HBM traffic).
 //   k_cc_flatten only used on demand by the stage-inspection call (writes representatives per pixel).
 #pragma once
 #include "common.h"
@@ -43,6 +48,8 @@ __device__ __forceinline__ void lds_union(uint32_t* L, uint32_t a, uint32_t b) {
   }
 }
 
+// (entries that take part in the global unions never carry AT_LABEL_BIG: only roots of components inside one tile get it
+// before k_cc_resolve, and those touch no tile border)
 __device__ __forceinline__ uint32_t glb_load(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -227,12 +234,14 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
       const size_t gi = (size_t)gy * W + gx;
       if (root[k] == AT_NO_LABEL) { label[gi] = AT_NO_LABEL; continue; }
       const uint32_t rr = root[k] / CC_T, rc = root[k] % CC_T;
-      label[gi] = (uint32_t)((Y0 + rr) * W + X0 + rc);
+      uint32_t lab = (uint32_t)((Y0 + rr) * W + X0 + rc);
       if (root[k] == me) {
         const uint32_t cs = sl[me];
         csize[gi] = cs & 0x7FFFFFFFu;
         if (cs >> 31) roots[rpos++] = (uint32_t)gi;
+        else if ((int)cs >= P.min_component_size) lab |= AT_LABEL_BIG;   // complete inside this tile: size and representative are final
       }
+      label[gi] = lab;
     }
   }
 }
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(256) void k_cc_border(const uint8_t* __restrict__ t
   for (int k = 0; k < 3; k++) {
     uint32_t a = AT_NO_LABEL, b2 = AT_NO_LABEL;
     if (ra[k] != AT_NO_LABEL) {
-      a = label[ra[k]]; b2 = label[rb[k]];
+      a = label[ra[k]] & AT_LABEL_MASK; b2 = label[rb[k]] & AT_LABEL_MASK;
       if (a > b2) { const uint32_t t = a; a = b2; b2 = t; }
       if (a == b2) a = b2 = AT_NO_LABEL;   // already the same tile-local root
     }
@@ -373,24 +382,22 @@ __global__ __launch_bounds__(256) void k_cc_sizes(uint32_t* __restrict__ label_a
   }
 }
 
-// Second pass over the root list, after every k_cc_sizes thread has finished: a tile-local root that is not
-// its component's representative receives the component's TOTAL pixel count (until here it held the tile-local
-// count, which nothing reads any more).  A consumer then needs only two dependent loads per pixel --
-// l = label[p], then label[l] (the representative) and csize[l] (the component size) side by side -- instead
-// of three.
-__global__ __launch_bounds__(256) void k_cc_resolve(const uint32_t* __restrict__ label_all, uint32_t* __restrict__ csize_all,
+// Second pass over the root list, after every k_cc_sizes thread has finished: the entry of every listed root -- the
+// representative included -- becomes representative | AT_LABEL_BIG-if-large-enough (see the header of this file).
+__global__ __launch_bounds__(256) void k_cc_resolve(uint32_t* __restrict__ label_all, const uint32_t* __restrict__ csize_all,
                                                     const uint32_t* __restrict__ roots_all,
                                                     const FrameCounters* __restrict__ counters, DetParams P) {
   const int frame = (int)blockIdx.z + P.frame0;
   const size_t n = (size_t)P.W * P.H;
-  const uint32_t* label = label_all + (size_t)frame * n;
-  uint32_t* csize = csize_all + (size_t)frame * n;
+  uint32_t* label = label_all + (size_t)frame * n;
+  const uint32_t* csize = csize_all + (size_t)frame * n;
   const uint32_t* roots = roots_all + (size_t)frame * P.rcap;
   const uint32_t nroots = counters[frame].nroots;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nroots; i += gridDim.x * 256) {
     const uint32_t p = roots[i];
-    const uint32_t r = label[p];
-    if (r != p) csize[p] = csize[r];   // representatives are never written here, only read
+    // (k_cc_sizes left label[p] = representative; another thread may already have flagged a representative's own entry)
+    const uint32_t r = __hip_atomic_load(&label[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & AT_LABEL_MASK;
+    if ((int)csize[r] >= P.min_component_size) atomicOr(&label[p], AT_LABEL_BIG);
   }
 }
 
@@ -403,7 +410,8 @@ __global__ __launch_bounds__(256) void k_cc_flatten(uint32_t* __restrict__ label
   if (i >= n) return;
   const uint32_t l = label[i];
   if (l == AT_NO_LABEL) return;
-  uint32_t r = l, q;
-  while ((q = glb_load(&label[r])) != r) r = q;
-  if (r != l) label[i] = r;
+  // (idempotent under concurrent execution: every entry on a chain keeps pointing at an ancestor, with or without the bit)
+  uint32_t r = l & AT_LABEL_MASK, q;
+  while ((q = glb_load(&label[r]) & AT_LABEL_MASK) != r) r = q;
+  if (r != l) label[i] = r;   // representative, without the size bit
 }

@@ -81,7 +81,15 @@ __device__ __forceinline__ int ltab_find(const unsigned long long* tkey, uint64_
 __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_all, const uint32_t* __restrict__ label_all,
                                                 const uint32_t* __restrict__ csize_all, unsigned long long* __restrict__ hkeys_all,
                                                 uint32_t* __restrict__ hcnt_all, uint2* __restrict__ stage_all,
-                                                uint32_t* __restrict__ rank_all, FrameCounters* __restrict__ counters, DetParams P) {
+                                                uint32_t* __restrict__ rank_all, FrameCounters* __restrict__ counters,
+                                                unsigned long long* __restrict__ prof, DetParams P) {
+#ifdef AMDAT_FQ_PROFILE   // tools-only: shader cycles per phase, prof[0..5] (tile load, emission tests + scan, list, block table, frame table, stores)
+#define PT_TICK(slot) if (prof && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&prof[slot], now_ - t_prev_); t_prev_ = now_; }
+  unsigned long long t_prev_ = prof ? __builtin_readcyclecounter() : 0ull;
+#else
+#define PT_TICK(slot)
+  (void)prof;
+#endif
   __shared__ uint8_t sv[PT_LH * PT_LW];
   __shared__ uint32_t slab[PT_LH * PT_LW];
   __shared__ uint32_t sscan[4];
@@ -99,16 +107,15 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   const int tid = threadIdx.x;
 
   {
-    // tile + halo: 17 x 66 = 1122 entries, up to 5 per thread.  Two dependent gather levels per entry (pixel ->
-    // tile-local root l, then label[l] = representative and csize[l] = component size side by side; k_cc_resolve
-    // has put the total size at every root), issued level by level for all of a thread's entries so that their
-    // latencies overlap instead of adding up.
+    // tile + halo: 17 x 66 = 1122 entries, up to 5 per thread.  Two dependent loads per entry (pixel -> tile-local root l,
+    // then label[l] = representative | size bit, kernels_cc.h), issued level by level for all of a thread's entries so
+    // that their latencies overlap instead of adding up.
     constexpr int NE = (PT_LH * PT_LW + 255) / 256;
-    uint32_t v[NE], l[NE], r[NE], cs[NE];
+    uint32_t v[NE], l[NE], r[NE];
 #pragma unroll
     for (int e = 0; e < NE; e++) {
       const int i = tid + e * 256;
-      v[e] = 127; l[e] = AT_NO_LABEL; r[e] = AT_NO_LABEL; cs[e] = 0;
+      v[e] = 127; l[e] = AT_NO_LABEL; r[e] = 0;
       if (i < PT_LH * PT_LW) {
         const int ly = i / PT_LW, lx = i % PT_LW;
         const int gx = X0 + lx - 1, gy = Y0 + ly;
@@ -120,17 +127,18 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     }
 #pragma unroll
     for (int e = 0; e < NE; e++)
-      if (v[e] != 127 && l[e] != AT_NO_LABEL) { r[e] = label[l[e]]; cs[e] = csize[l[e]]; }
+      if (v[e] != 127 && l[e] != AT_NO_LABEL) r[e] = label[l[e] & AT_LABEL_MASK];
 #pragma unroll
     for (int e = 0; e < NE; e++) {
       const int i = tid + e * 256;
-      const uint32_t lab = (r[e] != AT_NO_LABEL && (int)cs[e] >= P.min_component_size) ? r[e] : AT_NO_LABEL;
+      const uint32_t lab = (r[e] >> 31) ? (r[e] & AT_LABEL_MASK) : AT_NO_LABEL;
       if (i < PT_LH * PT_LW) { sv[i] = (uint8_t)v[e]; slab[i] = lab; }
     }
   }
   tkey[tid] = AT_EMPTY_KEY;
   tcnt[tid] = 0;
   __syncthreads();
+  PT_TICK(0)
 #if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 1   // tools-only: instruction counts per phase (tools/pt_phase_insts.sh)
   if (P.max_nmaxima == 10) return;
 #endif
@@ -170,6 +178,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   }
   uint32_t total;
   const uint32_t off = block_excl_scan256(cnt, sscan, &total);  // contains __syncthreads
+  PT_TICK(1)
   if (total == 0) return;
 #if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 2   // (pass 1's results are written out so that they stay live)
   if (P.max_nmaxima == 10) { rank_all[(size_t)frame * P.pcap + blockIdx.x * 256 + tid] = emask ^ off; return; }
@@ -188,6 +197,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     }
   }
   __syncthreads();
+  PT_TICK(2)
   // pass 2, DENSE over the list (entry q belongs to thread q mod 256): pair key -> block table entry e (one insert), and
   // the emission's rank inside its (block, pair) group from the value the counting atomic returns -- on a full wave of
   // real emissions the returning LDS atomic costs what a leader loop over the wave's distinct entries does, and the
@@ -207,6 +217,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     elist[q] = rec | (ee << 12) | (rk << 20);
   }
   __syncthreads();
+  PT_TICK(3)
 #if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 3
   if (P.max_nmaxima == 10) { rank_all[(size_t)frame * P.pcap + blockIdx.x * 256 + tid] = emask ^ off ^ elist[tid] ^ sbase; return; }
 #endif
@@ -224,6 +235,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     }
   }
   __syncthreads();
+  PT_TICK(4)
   const uint32_t base = sbase;
   if (base + total > P.pcap) {
     if (tid == 0) atomicOr(&counters[frame].flags, 0x1u);
@@ -266,6 +278,8 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
       q++;
     }
   }
+  PT_TICK(5)
+#undef PT_TICK
 }
 
 // one thread per hash slot; 1024-thread blocks so that the two allocation counters see one atomic each
