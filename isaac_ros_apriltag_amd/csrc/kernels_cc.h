@@ -31,7 +31,15 @@
 
 // (relaxed workgroup-scope atomic loads, not volatile ones: a volatile access keeps the generic address space and
 // compiles to flat_load ... sc0 sc1 through the shared aperture instead of ds_read_b32)
+// A root maps to itself, so hops past the root are harmless: the first CC_FIND_HOPS hops are taken unconditionally (a load
+// and an address shift each -- no compare, no exec-mask bookkeeping; the divergent loop's scalar instructions were as many as
+// the kernel's vector instructions), the loop only finishes the rare longer chains.
+#ifndef CC_FIND_HOPS
+#define CC_FIND_HOPS 3
+#endif
 __device__ __forceinline__ uint32_t lds_find(const uint32_t* L, uint32_t i) {
+#pragma unroll
+  for (int h = 0; h < CC_FIND_HOPS; h++) i = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   uint32_t p;
   while ((p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != i) i = p;
   return i;

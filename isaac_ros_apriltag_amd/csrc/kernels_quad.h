@@ -262,6 +262,7 @@ __device__ __forceinline__ void fit_line_dev(const double* lf, int sz, int i0, i
     if (M1 > M2) { nx = nx1; ny = ny1; M = M1; } else { nx = nx2; ny = ny2; M = M2; }
     const double length = (double)at_sqrtf_rn((float)M);
     if (fabs(length) < 1e-12) { lineparm[2] = 0; lineparm[3] = 0; }
+    // (the two divisions through one shared reciprocal refinement -- bit-identical, checked -- measured no gain)
     else { lineparm[2] = nx / length; lineparm[3] = ny / length; }
   }
   if (err) *err = N * eig_small;
