@@ -11,6 +11,7 @@
 #define AT_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 #define AT_INVALID_SLOT 0xFFFFFFFFu
 #define AT_MAX_FAMILIES 4
+#define AT_FLAG_CANDS 0x20u   // internal frame flag: quad-candidate list full (never reported; see run_batch)
 
 // Per-frame descriptor (device copy of amdAprilTagsImageInput_t + intrinsics), one per batch slot.
 struct FrameDesc {
@@ -105,6 +106,9 @@ struct DetParams {
   // capacities per frame
   uint32_t pcap, hcap, hshift, ccap, qcap, dcap;
   uint32_t rcap;     // tile-local roots per frame (CC root list)
+  uint32_t cand_cap; // quad candidates per frame (k_fit_quads -> k_quad_finish); grows on demand up to ccap
+  int pack_stage;    // staging record = {slot | rank << 16, point} (8 bytes) instead of {slot, point} + rank (12): needs
+                     // hcap <= 65536 and kept clusters below 65534 points
   FamilyDev fam[AT_MAX_FAMILIES];
 };
 

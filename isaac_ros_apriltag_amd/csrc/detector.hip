@@ -174,6 +174,11 @@ struct amdAprilTagsDetector_st {
   FqWorkLayout work_layout;
   int prefilter_class = 2;           // first size class whose clusters go through k_fit_prefilter (those above 2048 points)
   bool grow_points = false;          // point capacity follows the content (no explicit max_points)
+  bool grow_hash = false;            // the same for the component-pair table (no explicit hash_slots)
+  bool pending_hash_grow = false;
+  size_t cands_bytes = 0;
+  uint32_t hcap_hard = 0;
+  size_t hash_buffer_bytes[3] = {0, 0, 0};
   uint32_t pcap_hard = 0;            // 2 points per working pixel: what any content stays below
   size_t point_buffer_bytes[5] = {0, 0, 0, 0, 0};
   uint32_t grown = 0;                // number of times the point buffers grew (amdAprilTagsGetDeviceBytes reports the result)
@@ -336,6 +341,24 @@ static void free_all(amdAprilTagsDetector_st* D) {
   for (auto& e : D->ev_join) if (e) hipEventDestroy(e);
 }
 
+// The component-pair table of P.hcap slots per frame; also decides the staging format (DetParams::pack_stage).
+static int alloc_hash_buffers(amdAprilTagsDetector_st* D) {
+  DetParams& P = D->P;
+  const size_t B = D->cfg.max_batch;
+  { uint32_t lg = 0; while ((1u << lg) < P.hcap) lg++; P.hshift = 64 - lg; }
+  P.pack_stage = (P.hcap <= 65536u && P.max_cluster_points < 65534) ? 1 : 0;
+  void** bufs[3] = {(void**)&D->d_hkeys, (void**)&D->d_hcnt, (void**)&D->d_hoff};
+  const size_t bytes[3] = {B * (size_t)P.hcap * 8, B * (size_t)P.hcap * 4, B * (size_t)P.hcap * 4};
+  for (int i = 0; i < 3; i++)
+    if (*bufs[i]) { hipFree(*bufs[i]); *bufs[i] = nullptr; D->device_bytes -= D->hash_buffer_bytes[i]; D->hash_buffer_bytes[i] = 0; }
+  for (int i = 0; i < 3; i++) {
+    if (hipMalloc(bufs[i], bytes[i]) != hipSuccess) return AMDAT_OUT_OF_MEMORY;
+    D->hash_buffer_bytes[i] = bytes[i];
+    D->device_bytes += bytes[i];
+  }
+  return AMDAT_SUCCESS;
+}
+
 // Buffers whose size follows the point capacity P.pcap: staging records, ranks, points and the quad fit's work lists (their
 // capacities are bounded by points / smallest cluster of the class).  Called at creation and again when the capacity grows.
 static int alloc_point_buffers(amdAprilTagsDetector_st* D) {
@@ -354,7 +377,7 @@ static int alloc_point_buffers(amdAprilTagsDetector_st* D) {
     off += cap;
   }
   void** bufs[5] = {(void**)&D->d_stage, (void**)&D->d_rank, (void**)&D->d_pts, (void**)&D->d_work, (void**)&D->d_work2};
-  const size_t bytes[5] = {B * (size_t)P.pcap * 8, B * (size_t)P.pcap * 4, B * (size_t)P.pcap * 4, (size_t)off * 4,
+  const size_t bytes[5] = {B * (size_t)P.pcap * 8, P.pack_stage ? 0 : B * (size_t)P.pcap * 4, B * (size_t)P.pcap * 4, (size_t)off * 4,
                            ((size_t)off - D->work_layout.off[D->prefilter_class]) * 4};
   for (int i = 0; i < 5; i++) {
     if (*bufs[i]) { hipFree(*bufs[i]); *bufs[i] = nullptr; D->device_bytes -= D->point_buffer_bytes[i]; D->point_buffer_bytes[i] = 0; }
@@ -440,10 +463,15 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   D->grow_points = cfg.max_points == 0;
   D->pcap_hard = 2u * npx;
   P.pcap = cfg.max_points ? cfg.max_points : npx;
-  P.hcap = cfg.hash_slots ? next_pow2(cfg.hash_slots) : next_pow2(npx / 8 > 4096 ? npx / 8 : 4096);
-  if (P.hcap < 256) P.hcap = 256;
-  { uint32_t lg = 0; while ((1u << lg) < P.hcap) lg++; P.hshift = 64 - lg; }
-  P.ccap = cfg.max_clusters ? cfg.max_clusters : (P.hcap < 65536 ? P.hcap : 65536);
+  // Component-pair table: one slot per N/8 pixels is what no content overflowed; a sigma-2 1080p frame has ~4 000 pairs, so
+  // the table starts at N/32 slots (1 MB instead of 4 MB per frame to clear, probe and scan) and, like the point buffers,
+  // doubles when a frame reports AMDAT_FLAG_HASH_OVERFLOW or fills beyond a quarter (an explicit hash_slots is never grown).
+  D->grow_hash = cfg.hash_slots == 0;
+  D->hcap_hard = cfg.hash_slots ? next_pow2(cfg.hash_slots) : next_pow2(npx / 8 > 4096 ? npx / 8 : 4096);
+  if (D->hcap_hard < 256) D->hcap_hard = 256;
+  P.hcap = cfg.hash_slots ? D->hcap_hard : next_pow2(npx / 32 > 4096 ? npx / 32 : 4096);
+  if (P.hcap > D->hcap_hard) P.hcap = D->hcap_hard;
+  P.ccap = cfg.max_clusters ? cfg.max_clusters : (D->hcap_hard < 65536 ? D->hcap_hard : 65536);
   if (P.ccap > 65536) P.ccap = 65536;                 // a work item carries the cluster index in 16 bits
   P.qcap = cfg.max_quads ? cfg.max_quads : (P.ccap < 16384 ? P.ccap : 16384);
   P.dcap = cfg.max_detections ? cfg.max_detections : 1024;
@@ -505,9 +533,7 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   // 252 (perimeter pixels) per tile
   P.rcap = (uint32_t)(((W + CC_T - 1) / CC_T) * ((H + CC_T - 1) / CC_T)) * (4u * CC_T - 4u);
   alloc((void**)&D->d_roots, B * (size_t)P.rcap * 4);
-  alloc((void**)&D->d_hkeys, B * (size_t)P.hcap * 8);
-  alloc((void**)&D->d_hcnt, B * (size_t)P.hcap * 4);
-  alloc((void**)&D->d_hoff, B * (size_t)P.hcap * 4);
+  if (ok) ok = alloc_hash_buffers(D) == AMDAT_SUCCESS;   // (before the point buffers: it decides the staging format)
   alloc((void**)&D->d_clusters, B * (size_t)P.ccap * sizeof(ClusterRec));
   if (ok) { const int rc = alloc_point_buffers(D); if (rc == AMDAT_BATCH_TOO_LARGE) { free_all(D); delete D; return rc; } ok = rc == AMDAT_SUCCESS; }
   alloc((void**)&D->d_workctl, 32 * 4);
@@ -523,7 +549,10 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
     alloc((void**)&D->d_keys_scr, (size_t)c.grid * c.slot_cap * 8);
   }
   alloc((void**)&D->d_quads, B * (size_t)P.qcap * sizeof(QuadRec));
-  alloc((void**)&D->d_cands, B * (size_t)P.qcap * sizeof(FitCand));
+  // every kept cluster can become a candidate (ccap); the list starts at the quad capacity and grows when a frame fills it
+  P.cand_cap = P.qcap;
+  alloc((void**)&D->d_cands, B * (size_t)P.cand_cap * sizeof(FitCand));
+  D->cands_bytes = B * (size_t)P.cand_cap * sizeof(FitCand);
   alloc((void**)&D->d_dets, B * (size_t)P.dcap * sizeof(DetRec));
   alloc((void**)&D->d_out, B * (size_t)P.dcap * sizeof(DetRec));
   alloc((void**)&D->d_order, B * (size_t)P.dcap * 2);
@@ -929,24 +958,73 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
   fill_frames(D, n, images, intr);   // image pointers, pitches and intrinsics travel through the pinned descriptor block
   D->last_n = n;
   if (ostride > D->P.dcap) ostride = D->P.dcap;
+  if (D->pending_hash_grow) {   // the pair table of the previous submission was crowded: grow it now (its buffers are dead)
+    D->pending_hash_grow = false;
+    if (D->grow_hash && D->P.hcap < D->hcap_hard) {
+      drop_graphs(D);
+      const uint32_t before = D->P.hcap;
+      D->P.hcap = D->P.hcap * 2 > D->hcap_hard ? D->hcap_hard : D->P.hcap * 2;
+      if (alloc_hash_buffers(D) != AMDAT_SUCCESS || alloc_point_buffers(D) != AMDAT_SUCCESS) {
+        D->P.hcap = before; D->grow_hash = false;
+        if (alloc_hash_buffers(D) != AMDAT_SUCCESS || alloc_point_buffers(D) != AMDAT_SUCCESS) return AMDAT_OUT_OF_MEMORY;
+      } else {
+        D->grown++;
+      }
+    }
+  }
   for (;;) {
     const int rc = run_once(D, n, ostride, s);
     if (rc) return rc;
-    // A frame whose boundary points did not fit yields no clusters at all (flag 0x1).  Unless the host fixed the capacity,
-    // the point buffers grow -- doubling, up to the 2 points per pixel no content exceeds -- and the submission runs again.
-    if (!D->grow_points || D->P.pcap >= D->pcap_hard) return AMDAT_SUCCESS;
-    bool overflow = false;
-    for (uint32_t f = 0; f < n; f++) overflow |= (D->h_counters[f].flags & 0x1u) != 0;
-    if (!overflow) return AMDAT_SUCCESS;
-    const uint64_t want = (uint64_t)D->P.pcap * 2;
-    const uint32_t before = D->P.pcap;
-    D->P.pcap = want > D->pcap_hard ? D->pcap_hard : (uint32_t)want;
+    // A frame whose boundary points did not fit yields no clusters at all (flag 0x1), one whose component pairs did not fit
+    // loses clusters (0x2).  Unless the host fixed the capacities, the buffers grow -- doubling, up to what no content
+    // exceeds -- and the submission runs again; a pair table filled beyond a quarter grows for the next submission.
+    bool pts_over = false, hash_over = false, hash_crowded = false;
+    for (uint32_t f = 0; f < n; f++) {
+      pts_over |= (D->h_counters[f].flags & 0x1u) != 0;
+      hash_over |= (D->h_counters[f].flags & 0x2u) != 0;
+      hash_crowded |= D->h_counters[f].nclusters > D->P.hcap / 4;
+    }
+    bool cands_over = false;
+    for (uint32_t f = 0; f < n; f++) cands_over |= (D->h_counters[f].flags & AT_FLAG_CANDS) != 0;
+    if (cands_over) {
+      if (D->P.cand_cap < D->P.ccap) {   // grow the candidate list and repeat
+        drop_graphs(D);
+        const uint64_t want = (uint64_t)D->P.cand_cap * 2;
+        const uint32_t ncap = want > D->P.ccap ? D->P.ccap : (uint32_t)want;
+        FitCand* nb = nullptr;
+        const size_t nbytes = (size_t)D->cfg.max_batch * ncap * sizeof(FitCand);
+        if (hipMalloc((void**)&nb, nbytes) == hipSuccess) {
+          hipFree(D->d_cands);
+          D->d_cands = nb;
+          D->device_bytes += nbytes - D->cands_bytes;
+          D->cands_bytes = nbytes;
+          D->P.cand_cap = ncap;
+          D->grown++;
+          continue;
+        }
+      }
+      // cannot grow: report it as what it is for the caller, a quad-list overflow
+      for (uint32_t f = 0; f < n; f++)
+        if (D->h_counters[f].flags & AT_FLAG_CANDS) D->h_counters[f].flags = (D->h_counters[f].flags & ~AT_FLAG_CANDS) | 0x8u;
+    }
+    const bool can_pts = D->grow_points && D->P.pcap < D->pcap_hard;
+    const bool can_hash = D->grow_hash && D->P.hcap < D->hcap_hard;
+    const bool redo = (pts_over && can_pts) || (hash_over && can_hash);
+    if (!redo) {   // (a crowded table grows before the next submission: this one's buffers may still be inspected)
+      if (hash_crowded && can_hash) D->pending_hash_grow = true;
+      return AMDAT_SUCCESS;
+    }
     drop_graphs(D);   // captured launches carry the old pointers and capacities
-    const int grc = alloc_point_buffers(D);
-    if (grc != AMDAT_SUCCESS) {   // not enough memory to grow: keep reporting the overflow with the old capacity
-      D->P.pcap = before;
-      D->grow_points = false;
-      return alloc_point_buffers(D) == AMDAT_SUCCESS ? AMDAT_SUCCESS : AMDAT_OUT_OF_MEMORY;
+    const uint32_t pcap_before = D->P.pcap, hcap_before = D->P.hcap;
+    if (pts_over && can_pts) { const uint64_t want = (uint64_t)D->P.pcap * 2; D->P.pcap = want > D->pcap_hard ? D->pcap_hard : (uint32_t)want; }
+    if (hash_over && can_hash) D->P.hcap = D->P.hcap * 2 > D->hcap_hard ? D->hcap_hard : D->P.hcap * 2;
+    int grc = alloc_hash_buffers(D);
+    if (grc == AMDAT_SUCCESS) grc = alloc_point_buffers(D);   // (also when only the staging format changed)
+    if (grc != AMDAT_SUCCESS) {   // not enough memory to grow: keep reporting the overflow with the old capacities
+      D->P.pcap = pcap_before; D->P.hcap = hcap_before;
+      D->grow_points = false; D->grow_hash = false;
+      if (alloc_hash_buffers(D) != AMDAT_SUCCESS || alloc_point_buffers(D) != AMDAT_SUCCESS) return AMDAT_OUT_OF_MEMORY;
+      return AMDAT_SUCCESS;
     }
     D->grown++;
   }

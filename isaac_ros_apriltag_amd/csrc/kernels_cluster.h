@@ -263,15 +263,18 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
       else rk = atomicAdd(&hcnt[slot], 1u);
     }
     if (pos < P.pcap) {
-#ifndef AMDAT_PT_PLAIN_STORES
-      // written once, read once by k_scatter two kernels later, 5 GB per 256-frame step: keep it out of the caches' way
+      // written once, read once by k_scatter two kernels later, 3.5 GB per 256-frame step: non-temporal stores keep it out
+      // of the caches' way
       const uint32_t pk = pack_point(2 * (X0 + plx) + ddx, 2 * (Y0 + ly) + ddy, ddx * (v1 - v0), ddy * (v1 - v0));
-      __builtin_nontemporal_store((unsigned long long)slot | ((unsigned long long)pk << 32), reinterpret_cast<unsigned long long*>(stage + pos));
-      __builtin_nontemporal_store(rk, rank + pos);
-#else
-      stage[pos] = make_uint2(slot, pack_point(2 * (X0 + plx) + ddx, 2 * (Y0 + ly) + ddy, ddx * (v1 - v0), ddy * (v1 - v0)));
-      rank[pos] = rk;
-#endif
+      if (P.pack_stage) {
+        // slot (< 2^16) and rank in one word; a rank that does not fit belongs to a cluster too large to be kept, and
+        // 0xFFFFFFFF stays free for "no slot"
+        const uint32_t w0 = (slot == AT_INVALID_SLOT) ? 0xFFFFFFFFu : (slot | ((rk < 0xFFFEu ? rk : 0xFFFEu) << 16));
+        __builtin_nontemporal_store((unsigned long long)w0 | ((unsigned long long)pk << 32), reinterpret_cast<unsigned long long*>(stage + pos));
+      } else {
+        __builtin_nontemporal_store((unsigned long long)slot | ((unsigned long long)pk << 32), reinterpret_cast<unsigned long long*>(stage + pos));
+        __builtin_nontemporal_store(rk, rank + pos);
+      }
     }
   };
   for (uint32_t q = tid; q < nlist; q += 256) emit(elist[q], base + q);
@@ -399,9 +402,11 @@ __global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ stage
   if (n > P.pcap) n = P.pcap;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const uint2 rec = stage_all[(size_t)frame * P.pcap + i];
-    const uint32_t rk = rank_all[(size_t)frame * P.pcap + i];
     if (rec.x == AT_INVALID_SLOT) continue;
-    const uint32_t off = hoff_all[(size_t)frame * P.hcap + rec.x];
+    uint32_t slot = rec.x, rk;
+    if (P.pack_stage) { slot = rec.x & 0xFFFFu; rk = rec.x >> 16; }
+    else rk = rank_all[(size_t)frame * P.pcap + i];
+    const uint32_t off = hoff_all[(size_t)frame * P.hcap + slot];
     if (off == AT_INVALID_SLOT) continue;
     pts_all[(size_t)frame * P.pcap + off + rk] = rec.y;
   }

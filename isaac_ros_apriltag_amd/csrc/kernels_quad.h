@@ -1462,8 +1462,8 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
         uint32_t ci = 0;
         if (lane == 0) ci = atomicAdd(&counters[frame].ncand, 1u);
         ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)ci);
-        if (ci < P.qcap) {
-          FitCand* const cd = cands_all + (size_t)frame * P.qcap + ci;
+        if (ci < P.cand_cap) {
+          FitCand* const cd = cands_all + (size_t)frame * P.cand_cap + ci;
           if (lane < 4) {
             const int pi = lane == 0 ? FQ_PIDX(q0, q1) : lane == 1 ? FQ_PIDX(q1, q2) : lane == 2 ? FQ_PIDX(q2, q3) : FQ_PIDX(q0, q3);
             const bool wrap = lane == 3;
@@ -1477,7 +1477,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
             cd->pad = 0;
           }
         } else if (lane == 0) {
-          atomicOr(&counters[frame].flags, 0x8u);
+          atomicOr(&counters[frame].flags, AT_FLAG_CANDS);   // (internal: the host grows the list and repeats, or reports 0x8)
         }
       }
     }
@@ -1710,9 +1710,9 @@ __global__ __launch_bounds__(256) void k_quad_finish(const FitCand* __restrict__
                                                      FrameCounters* __restrict__ counters, DetParams P) {
   const int frame = (int)blockIdx.y + P.frame0;
   uint32_t ncand = counters[frame].ncand;
-  if (ncand > P.qcap) ncand = P.qcap;
+  if (ncand > P.cand_cap) ncand = P.cand_cap;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < ncand; i += gridDim.x * 256) {
-    const FitCand cd = cands_all[(size_t)frame * P.qcap + i];
+    const FitCand cd = cands_all[(size_t)frame * P.cand_cap + i];
     float corner[4][2];
     bool ok = true;
 #pragma unroll

@@ -822,3 +822,36 @@ def test_multi_camera_node(built):
         multi.close()
         for n_ in singles:
             n_.close()
+
+
+def test_pair_table_grows_with_the_content(built):
+    """The component-pair table starts at N/32 slots and doubles (before the next submission) when a frame fills it beyond
+    a quarter; a full table (flag 0x2) grows at once and repeats the submission.  19 200 black squares on white are 19 200
+    pairs: the first call runs in the 32 768-slot table, the second in 65 536 slots -- results equal the oracle's both
+    times; an explicit hash_slots below the content reports the overflow instead.  The same frame has more quad candidates
+    than the candidate list's initial capacity: that list grows inside the first call (the submission is repeated)."""
+    w, h = 960, 720
+    img = np.full((h, w), 220, dtype=np.uint8)
+    for y0 in range(0, h - 5, 6):
+        img[y0:y0 + 5] = np.where((np.arange(w) % 6) < 5, 30, 220).astype(np.uint8)[None, :]
+    img[h - h % 6:] = 220
+    K = synth.default_K(w, h)
+    t = torch.from_numpy(img).cuda()
+    det = AprilTagDetector(w, h, intrinsics=_k4(K), max_batch=1)
+    b0 = det.device_bytes()
+    for call in range(2):
+        g = det.detect_batch_ex(t, max_dets=64)[0]
+        assert det.frame_flags(1) == [0]
+        errs, odets = pu.compare_stages(det, 0, img, ("tag36h11",), K, 1)
+        errs += pu.compare_detections(g, odets)
+        assert not errs, (call, errs[:4])
+        if call == 0:
+            assert det.debug(0, capi_mod.DBG_COUNTS)[1] > 8192      # kept clusters: beyond a quarter of the initial table
+            b1 = det.device_bytes()                                  # (the quad-candidate list has grown: 19 200 candidates)
+            assert b1 > b0
+    assert det.device_bytes() > b1                                   # the pair table grew before the second submission
+    det.close()
+    fixed = AprilTagDetector(w, h, intrinsics=_k4(K), max_batch=1, hash_slots=4096)
+    fixed.detect_batch_ex(t, max_dets=64)
+    assert fixed.frame_flags(1)[0] & 2
+    fixed.close()
