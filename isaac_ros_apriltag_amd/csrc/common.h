@@ -147,6 +147,21 @@ __device__ __forceinline__ double sqrt_u18(uint32_t G) {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// Block -> (frame, block of the frame) for kernels whose blocks of ONE frame meet on a few hot addresses (the roots of a
+// giant component, the pair-table slot of the two big components of a textured background): a 1-D grid of bpf * n blocks in
+// which the frames of a group of G take turns, so that blocks running at the same time belong to G different frames.  (G = 1
+// is the plain frame-major order; G bounds the number of per-frame tables the blocks in flight touch.)
+__device__ __forceinline__ void at_frame_block(uint32_t lin, uint32_t bpf, uint32_t n, uint32_t G, uint32_t* frame, uint32_t* blk) {
+  if (G <= 1) { *frame = lin / bpf; *blk = lin - *frame * bpf; return; }
+  const uint32_t ngroups = (n + G - 1) / G;
+  uint32_t group = lin / (bpf * G);
+  if (group >= ngroups) group = ngroups - 1;
+  const uint32_t rem = lin - group * bpf * G;
+  const uint32_t gsize = (group == ngroups - 1) ? n - group * G : G;
+  *blk = rem / gsize;
+  *frame = group * G + (rem - *blk * gsize);
+}
+
 // wave-level inclusive scan (wave64)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   int lane = lane_id();

@@ -695,7 +695,8 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
     const int nrows = (P.H - 1) / CC_T, ncols = (P.W - 1) / CC_T;
     const long total = (long)nrows * P.W + (long)ncols * P.H;
     if (total > 0)
-      hipLaunchKernelGGL(k_cc_border, dim3((unsigned)((total + 255) / 256), 1, n), dim3(256), 0, s, D->d_thr, D->d_label, P);
+      hipLaunchKernelGGL(k_cc_border, dim3((unsigned)((total + 255) / 256) * n), dim3(256), 0, s, D->d_thr, D->d_label,
+                         (uint32_t)((total + 255) / 256), n, P);
   }
   mark();
   {
@@ -706,9 +707,11 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
     hipLaunchKernelGGL(k_cc_resolve, dim3(gr, 1, n), dim3(256), 0, s, D->d_label, D->d_csize, D->d_roots, D->d_counters, P);
   }
   mark();
-  hipLaunchKernelGGL(k_points, dim3((P.W + PT_TW - 1) / PT_TW, (P.H + PT_TH - 1) / PT_TH, n), dim3(256), 0, s, D->d_thr,
-                     D->d_label, D->d_csize, D->d_hkeys, D->d_hcnt, D->d_stage, D->d_rank, D->d_counters,
-                     (D->fq_counters ? D->d_ptprof : nullptr), P);
+  {
+    const uint32_t gxt = (uint32_t)((P.W + PT_TW - 1) / PT_TW), gyt = (uint32_t)((P.H + PT_TH - 1) / PT_TH);
+    hipLaunchKernelGGL(k_points, dim3(gxt * gyt * n), dim3(256), 0, s, D->d_thr, D->d_label, D->d_csize, D->d_hkeys, D->d_hcnt,
+                       D->d_stage, D->d_rank, D->d_counters, (D->fq_counters ? D->d_ptprof : nullptr), gxt, gyt, n, P);
+  }
   mark();
   hipLaunchKernelGGL(k_cluster_select, dim3((P.hcap + 1023) / 1024, 1, n), dim3(256), 0, s, D->d_hkeys, D->d_hcnt, D->d_hoff,
                      D->d_clusters, D->d_counters, P);

@@ -66,6 +66,13 @@ __device__ __forceinline__ uint32_t glb_find(const uint32_t* L, uint32_t i) {
   while ((p = glb_load(&L[i])) != i) i = p;
   return i;
 }
+// Lock-free union (the larger root is pointed at the smaller one; entries only ever decrease towards the root, which is
+// what keeps concurrent unions correct).  Trees are never rebalanced, so a giant component's chain of tile-local roots
+// grows with the number of tiles it has crossed.  Two shortcuts were measured and dropped: path halving inside the find
+// (grandparent links at every hop: 1.27-1.36 vs 1.35-1.39 ms, noise) and pointing both START entries at the final root
+// with an atomicMin after the union (1.54 ms: two more atomics on entries that are already contended).  What does help
+// is launching the frames of a submission interleaved (at_frame_block): the unions of one frame then contend with the
+// unions of other frames for the atomic units instead of with each other for the same few roots.
 __device__ __forceinline__ void glb_union(uint32_t* L, uint32_t a, uint32_t b) {
   for (;;) {
     a = glb_find(L, a);
@@ -299,15 +306,20 @@ __device__ __forceinline__ void cc_column_requests(const uint8_t* thr, int W, in
 }
 
 // grid.x covers [border rows: nrows*W pixels][tile columns: ncols*H]
+#ifndef CC_ILEAVE
+#define CC_ILEAVE 256
+#endif
 __global__ __launch_bounds__(256) void k_cc_border(const uint8_t* __restrict__ thr_all, uint32_t* __restrict__ label_all,
-                                                   DetParams P) {
-  const int frame = (int)blockIdx.z + P.frame0;
+                                                   uint32_t bpf, uint32_t nframes, DetParams P) {
+  uint32_t fr_, blk_;
+  at_frame_block(blockIdx.x, bpf, nframes, CC_ILEAVE, &fr_, &blk_);
+  const int frame = (int)fr_ + P.frame0;
   const int W = P.W, H = P.H;
   const uint8_t* thr = thr_all + (size_t)frame * H * P.WS;
   uint32_t* label = label_all + (size_t)frame * W * H;
   const int nrows = (H - 1) / CC_T;  // tile-top rows at y = 64, 128, ...
   const int ncols = (W - 1) / CC_T;  // tile-left columns at x = 64, 128, ...
-  int i = blockIdx.x * 256 + threadIdx.x;
+  int i = (int)blk_ * 256 + threadIdx.x;
   uint32_t ra[3] = {AT_NO_LABEL, AT_NO_LABEL, AT_NO_LABEL}, rb[3] = {AT_NO_LABEL, AT_NO_LABEL, AT_NO_LABEL};
   if (i < nrows * W) {
     cc_row_requests(thr, W, H, P.WS, i % W, (i / W + 1) * CC_T, ra, rb);

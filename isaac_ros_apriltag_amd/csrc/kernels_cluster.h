@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
                                                 const uint32_t* __restrict__ csize_all, unsigned long long* __restrict__ hkeys_all,
                                                 uint32_t* __restrict__ hcnt_all, uint2* __restrict__ stage_all,
                                                 uint32_t* __restrict__ rank_all, FrameCounters* __restrict__ counters,
-                                                unsigned long long* __restrict__ prof, DetParams P) {
+                                                unsigned long long* __restrict__ prof, uint32_t gx_tiles, uint32_t gy_tiles, uint32_t nframes,
+                                                DetParams P) {
 #ifdef AMDAT_FQ_PROFILE   // tools-only: shader cycles per phase, prof[0..5] (tile load, emission tests + scan, list, block table, frame table, stores)
 #define PT_TICK(slot) if (prof && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&prof[slot], now_ - t_prev_); t_prev_ = now_; }
   unsigned long long t_prev_ = prof ? __builtin_readcyclecounter() : 0ull;
@@ -97,13 +98,19 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   __shared__ unsigned long long tkey[PT_TB];
   __shared__ uint32_t tcnt[PT_TB], tslot[PT_TB], tbase[PT_TB];
   __shared__ uint32_t elist[PT_ELIST];
-  const int frame = (int)blockIdx.z + P.frame0;
+#ifndef PT_ILEAVE
+#define PT_ILEAVE 256
+#endif
+  uint32_t fr_, blk_;
+  at_frame_block(blockIdx.x, gx_tiles * gy_tiles, nframes, PT_ILEAVE, &fr_, &blk_);
+  const int frame = (int)fr_ + P.frame0;
+  const int bx_ = (int)(blk_ % gx_tiles), by_ = (int)(blk_ / gx_tiles);
   const int W = P.W, H = P.H;
   const size_t npx = (size_t)W * H;
   const uint8_t* thr = thr_all + (size_t)frame * H * P.WS;
   const uint32_t* label = label_all + (size_t)frame * npx;
   const uint32_t* csize = csize_all + (size_t)frame * npx;
-  const int X0 = blockIdx.x * PT_TW, Y0 = blockIdx.y * PT_TH;
+  const int X0 = bx_ * PT_TW, Y0 = by_ * PT_TH;
   const int tid = threadIdx.x;
 
   {
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   PT_TICK(1)
   if (total == 0) return;
 #if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 2   // (pass 1's results are written out so that they stay live)
-  if (P.max_nmaxima == 10) { rank_all[(size_t)frame * P.pcap + blockIdx.x * 256 + tid] = emask ^ off; return; }
+  if (P.max_nmaxima == 10) { rank_all[(size_t)frame * P.pcap + (blk_ % 64u) * 256 + tid] = emask ^ off; return; }
 #endif
   unsigned long long* hkeys = hkeys_all + (size_t)frame * P.hcap;
   uint32_t* hcnt = hcnt_all + (size_t)frame * P.hcap;
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   __syncthreads();
   PT_TICK(3)
 #if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 3
-  if (P.max_nmaxima == 10) { rank_all[(size_t)frame * P.pcap + blockIdx.x * 256 + tid] = emask ^ off ^ elist[tid] ^ sbase; return; }
+  if (P.max_nmaxima == 10) { rank_all[(size_t)frame * P.pcap + (blk_ % 64u) * 256 + tid] = emask ^ off ^ elist[tid] ^ sbase; return; }
 #endif
   {
     // one global insert + one global add per distinct pair of this block; the add's return value is the base rank of
