@@ -157,6 +157,7 @@ struct amdAprilTagsDetector_st {
   uint32_t* d_pts = nullptr;
   ClusterRec* d_clusters = nullptr;
   uint32_t* d_work = nullptr;        // work lists of the quad fit (all classes, FqWorkLayout)
+  bool tables_dirty = false;         // a submission was cut short after k_points: the pair table is not empty
   uint32_t* d_workctl = nullptr;     // [0..7] items per class, [8..15] pop cursors, [16..23] items per class after k_fit_prefilter
   uint32_t* d_work2 = nullptr;       // compact work lists of the prefiltered classes (same layout as d_work)
   unsigned long long* d_keys_scr = nullptr;  // only when a cluster can exceed the LDS key array (large images)
@@ -329,7 +330,7 @@ static void free_all(amdAprilTagsDetector_st* D) {
   hipFree(D->d_work); hipFree(D->d_work2); hipFree(D->d_workctl); hipFree(D->d_keys_scr); hipFree(D->d_quads);
   for (auto& c : D->cls) { hipFree(c.d_lf); hipFree(c.d_errs); }
   hipFree(D->d_fqprof);
-  hipFree(D->d_cands); hipFree(D->d_dets); hipFree(D->d_out); hipFree(D->d_order); hipFree(D->d_counters); hipFree(D->d_frames);
+  hipFree(D->d_cands); hipFree(D->d_dets); hipFree(D->d_out); hipFree(D->d_order); hipFree(D->d_frames);   // (d_counters lives behind d_workctl)
   for (int i = 0; i < AT_MAX_FAMILIES; i++) hipFree(D->d_codes[i]);
   if (D->h_frames) hipHostFree(D->h_frames);
   if (D->h_counters) hipHostFree(D->h_counters);
@@ -339,6 +340,19 @@ static void free_all(amdAprilTagsDetector_st* D) {
   for (auto& a : D->aux_stream) if (a) hipStreamDestroy(a);
   if (D->ev_fork) hipEventDestroy(D->ev_fork);
   for (auto& e : D->ev_join) if (e) hipEventDestroy(e);
+}
+
+// The pair table is empty between submissions: k_cluster_select, its last reader, empties every slot it finds used (a few
+// per cent of the table), so a submission starts without the two table-sized fills it used to open with (201 MB per 256
+// frames; on a one-frame call two of five 4-5 us fill launches ahead of the first kernel).  The whole table is only
+// written here: after (re)allocation, and after a submission that did not run to its end (tables_dirty).
+static int clear_hash_tables(amdAprilTagsDetector_st* D) {
+  const size_t B = D->cfg.max_batch;
+  if (hipMemset(D->d_hkeys, 0xFF, B * (size_t)D->P.hcap * 8) != hipSuccess) return AMDAT_HIP_ERROR;
+  if (hipMemset(D->d_hcnt, 0, B * (size_t)D->P.hcap * 4) != hipSuccess) return AMDAT_HIP_ERROR;
+  if (hipDeviceSynchronize() != hipSuccess) return AMDAT_HIP_ERROR;
+  D->tables_dirty = false;
+  return AMDAT_SUCCESS;
 }
 
 // The component-pair table of P.hcap slots per frame; also decides the staging format (DetParams::pack_stage).
@@ -356,7 +370,7 @@ static int alloc_hash_buffers(amdAprilTagsDetector_st* D) {
     D->hash_buffer_bytes[i] = bytes[i];
     D->device_bytes += bytes[i];
   }
-  return AMDAT_SUCCESS;
+  return clear_hash_tables(D);
 }
 
 // Buffers whose size follows the point capacity P.pcap: staging records, ranks, points and the quad fit's work lists (their
@@ -514,6 +528,16 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
     // to 768, 256 up to 2048, 512 up to 8192 -- measured slower on one-frame submissions, 0.36 against 0.28 ms for the
     // stage: the larger workgroups' barriers cost more than the shorter per-lane runs save)
     D->prefilter_class = 2;
+#ifdef AMDAT_LAT_B01   // experiment: class boundaries of a handle that only ever sees small submissions
+    if ((uint64_t)B * (uint64_t)P.W * (uint64_t)P.H < (16ull << 20)) {
+      c[0].hi = c[1].lo = AMDAT_LAT_B01;
+      c[1].hi = c[2].lo = AMDAT_LAT_B12;
+#ifdef AMDAT_LAT_B23
+      c[2].hi = c[3].lo = AMDAT_LAT_B23;
+      c[3].hi = c[4].lo = AMDAT_LAT_B34;
+#endif
+    }
+#endif
     c[4] = {FQ_NT_BIG, 16384, 8192, 0x7FFFFFFF, minu(cus, 16u * (unsigned)B), P.max_cluster_points, 1};
     if (P.max_cluster_points > 16384 && P.max_cluster_points <= 18432) c[4].sort_cap = (P.max_cluster_points + 63) & ~63;
     if (c[4].slot_cap < 8193) c[4].slot_cap = 8193;
@@ -536,7 +560,6 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   if (ok) ok = alloc_hash_buffers(D) == AMDAT_SUCCESS;   // (before the point buffers: it decides the staging format)
   alloc((void**)&D->d_clusters, B * (size_t)P.ccap * sizeof(ClusterRec));
   if (ok) { const int rc = alloc_point_buffers(D); if (rc == AMDAT_BATCH_TOO_LARGE) { free_all(D); delete D; return rc; } ok = rc == AMDAT_SUCCESS; }
-  alloc((void**)&D->d_workctl, 32 * 4);
   for (int k = 0; k < FQ_NCLS; k++) {
     FqClass& c = D->cls[k];
     if (P.max_cluster_points <= c.lo) continue;
@@ -556,7 +579,9 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   alloc((void**)&D->d_dets, B * (size_t)P.dcap * sizeof(DetRec));
   alloc((void**)&D->d_out, B * (size_t)P.dcap * sizeof(DetRec));
   alloc((void**)&D->d_order, B * (size_t)P.dcap * 2);
-  alloc((void**)&D->d_counters, B * sizeof(FrameCounters));
+  // work-list control words and frame counters share one allocation, cleared by ONE fill per submission
+  alloc((void**)&D->d_workctl, 32 * 4 + B * sizeof(FrameCounters));
+  if (ok) D->d_counters = reinterpret_cast<FrameCounters*>(D->d_workctl + 32);
   alloc((void**)&D->d_frames, B * sizeof(FrameDesc));
   alloc((void**)&D->d_fqprof, (64 + 8) * 8);
   D->d_ptprof = D->d_fqprof + 64;   // k_points' phase counters follow the quad fit's
@@ -757,6 +782,9 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
     const int pf_first = small ? D->prefilter_class + 1 : D->prefilter_class;
     auto launch_prefilter = [&](hipStream_t sp) {
       if (!prefilter) return;
+#ifdef AMDAT_FQ_SKIP
+      if ((AMDAT_FQ_SKIP >> 5) & 1) return;
+#endif
       // small submissions: one cluster per CU-wide workgroup (latency); otherwise one per wave (throughput)
       const bool wide = small;
 #define PF_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work, D->d_workctl, work2, D->d_workctl + 16, D->work_layout,   \
@@ -775,6 +803,9 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
     auto launch_class = [&](int c, hipStream_t sc) {
       const FqClass& cl = D->cls[c];
       if (P.max_cluster_points <= cl.lo || !cl.d_lf) return;
+#ifdef AMDAT_FQ_SKIP   // tools-only: leave out size classes (bits 0..4) or the prefilter (bit 5) to time the others alone
+      if ((AMDAT_FQ_SKIP >> c) & 1) return;
+#endif
       const dim3 grid(cl.grid);   // (a submission of n < max_batch frames still gets the handle's persistent grid)
       const size_t lds = lds_bytes(cl);
       const bool big = c == FQ_NCLS - 1;
@@ -812,11 +843,24 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
       // (the longest chain) first.
       // A small submission leaves most of the chip empty either way: its classes below the prefilter start at once on the
       // side streams, beside the prefilter.
+#ifdef AMDAT_SMALL_SERIAL
+      if (small) {
+        launch_prefilter(s);
+        for (int c = pf_first; c < FQ_NCLS; c++) launch_class(c, s);
+        for (int c = pf_first - 1; c >= 0; c--) launch_class(c, s);
+        hipLaunchKernelGGL(k_quad_finish, dim3(16, n), dim3(256), 0, s, D->d_cands, D->d_quads, D->d_counters, P);
+        goto fit_done;
+      }
+#endif
       if (!small) launch_prefilter(s);
       HIP_TRY(hipEventRecord(D->ev_fork, s));
       for (int a = 0; a < 3; a++) HIP_TRY(hipStreamWaitEvent(aux[a], D->ev_fork, 0));
       if (small) launch_prefilter(s);
       for (int c = pf_first; c < FQ_NCLS; c++) launch_class(c, s);   // (nearly all survivors are in the first of them)
+#ifdef AMDAT_SMALL_PLAN   // experiment: stream of each class below the prefilter, one nibble per class (0 = s, 1..3 = side streams)
+      if (small) { for (int c = pf_first - 1; c >= 0; c--) { const int w = (AMDAT_SMALL_PLAN >> (4 * c)) & 15; launch_class(c, w ? aux[w - 1] : s); } }
+      else
+#endif
       for (int c = pf_first - 1, a = 0; c >= 0; c--, a++) launch_class(c, aux[a % 3]);   // the longest chains first
     } else {
     if (large_first) {
@@ -844,6 +888,9 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
     }
     // corners + area / angle checks of the candidates, one thread each
     hipLaunchKernelGGL(k_quad_finish, dim3(16, n), dim3(256), 0, s, D->d_cands, D->d_quads, D->d_counters, P);
+#ifdef AMDAT_SMALL_SERIAL
+  fit_done:;
+#endif
   }
   mark();
   {
@@ -864,10 +911,7 @@ static int enqueue_submission(amdAprilTagsDetector_st* D, uint32_t n, uint32_t o
   const DetParams& P = D->P;
   mark();
   HIP_TRY(hipMemcpyAsync(D->d_frames, D->h_frames, n * sizeof(FrameDesc), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(D->d_counters, 0, n * sizeof(FrameCounters), s));
-  HIP_TRY(hipMemsetAsync(D->d_workctl, 0, 32 * 4, s));
-  HIP_TRY(hipMemsetAsync(D->d_hkeys, 0xFF, (size_t)n * P.hcap * 8, s));
-  HIP_TRY(hipMemsetAsync(D->d_hcnt, 0, (size_t)n * P.hcap * 4, s));
+  HIP_TRY(hipMemsetAsync(D->d_workctl, 0, 32 * 4 + n * sizeof(FrameCounters), s));   // control words + the counters behind them
   if (D->fq_counters) HIP_TRY(hipMemsetAsync(D->d_fqprof, 0, (64 + 8) * 8, s));
   mark();
   {
@@ -976,8 +1020,11 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
     }
   }
   for (;;) {
+    if (D->tables_dirty) { const int crc = clear_hash_tables(D); if (crc) return crc; }
+    D->tables_dirty = true;
     const int rc = run_once(D, n, ostride, s);
     if (rc) return rc;
+    D->tables_dirty = false;   // ran to its end: k_cluster_select left the pair table empty
     // A frame whose boundary points did not fit yields no clusters at all (flag 0x1), one whose component pairs did not fit
     // loses clusters (0x2).  Unless the host fixed the capacities, the buffers grow -- doubling, up to what no content
     // exceeds -- and the submission runs again; a pair table filled beyond a quarter grows for the next submission.
@@ -1250,6 +1297,21 @@ int amdAprilTagsDebugCopy(amdAprilTagsHandle handle, uint32_t frame, amdAprilTag
   if (host_dst && sz) HIP_TRY(hipMemcpy(host_dst, src, sz < capacity ? sz : capacity, hipMemcpyDeviceToHost));
   return AMDAT_SUCCESS;
 }
+
+#ifdef AMDAT_FQ_TIMELINE
+// tools-only: returns and clears the quad fit's per-cluster wall-clock log (start tick, duration << 32 | threads << 20 | points)
+extern "C" int amdAprilTagsDebugTimeline(unsigned long long* out, unsigned int cap) {
+  unsigned int n = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_fq_tl_n), 4) != hipSuccess) return -1;
+  if (n > (1u << 16)) n = 1u << 16;
+  if (n > cap) n = cap;
+  if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fq_tl), (size_t)n * 16) != hipSuccess) return -1;
+  const unsigned int zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_fq_tl_n), &zero, 4) != hipSuccess) return -1;
+  return (int)n;
+}
+#endif
 
 int amdAprilTagsDebugMath(int op, uint32_t n, const double* a, const double* b, double* out) {
   if (!a || !b || !out || n == 0) return AMDAT_INVALID_ARGUMENT;

@@ -301,8 +301,8 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
 
 // one thread per hash slot; 1024-thread blocks so that the two allocation counters see one atomic each
 // per block
-__global__ __launch_bounds__(256) void k_cluster_select(const unsigned long long* __restrict__ hkeys_all,
-                                                        const uint32_t* __restrict__ hcnt_all, uint32_t* __restrict__ hoff_all,
+__global__ __launch_bounds__(256) void k_cluster_select(unsigned long long* __restrict__ hkeys_all,
+                                                        uint32_t* __restrict__ hcnt_all, uint32_t* __restrict__ hoff_all,
                                                         ClusterRec* __restrict__ clusters_all,
                                                         FrameCounters* __restrict__ counters, DetParams P) {
   // 1024 table slots per block, four consecutive ones per thread (16-byte loads and stores; hcap is a power of two >= 256)
@@ -317,6 +317,7 @@ __global__ __launch_bounds__(256) void k_cluster_select(const unsigned long long
   uint4 c4 = make_uint4(0, 0, 0, 0);
   if (in_range) c4 = *reinterpret_cast<const uint4*>(hcnt_all + hi);
   const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+  if (c4.x | c4.y | c4.z | c4.w) *reinterpret_cast<uint4*>(hcnt_all + hi) = make_uint4(0, 0, 0, 0);
   // a frame whose point staging overflowed has pair counts that exceed what was staged: it yields no
   // clusters at all (the overflow bit is reported), never an out-of-range range
   const bool frame_ok = (counters[frame].flags & 0x1u) == 0;
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(256) void k_cluster_select(const unsigned long long
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     key[j] = c[j] ? hkeys_all[hi + j] : AT_EMPTY_KEY;
+    if (c[j]) hkeys_all[hi + j] = AT_EMPTY_KEY;   // this kernel is the table's last reader: it leaves it empty for the next submission
     keep[j] = frame_ok && key[j] != AT_EMPTY_KEY && (int)c[j] >= P.min_cluster_points && (int)c[j] <= P.max_cluster_points;
     if (keep[j]) { tsum += c[j]; tcnt++; }
   }

@@ -12,18 +12,23 @@
 #include "kernels_decode.h"
 
 #define DW_MAXS 64  // samples per chunk
+#ifndef DW_KB
+#define DW_KB 9     // steps of the normal search whose image gathers are in flight together (17 steps at full resolution)
+#endif
 
 // 6 waves per SIMD (80 registers, a few spilled): the per-quad work is chains of dependent double-precision operations in
 // the CPU definition's order, so the stage's rate is set by how many quads are in flight (1.16 -> 0.80 ms per 256 noisy
 // frames together with the larger grid; 5 and 7 waves measured slower)
+#ifndef DW_WPE
 #define DW_WPE 6
+#endif
 __global__ __launch_bounds__(64, DW_WPE) void k_decode_wave(const FrameDesc* __restrict__ frames, const QuadRec* __restrict__ quads_all,
                                                     DetRec* __restrict__ dets_all, FrameCounters* __restrict__ counters,
                                                     DetParams P) {
   __shared__ double s_bx[DW_MAXS], s_by[DW_MAXS];
   __shared__ int s_bok[DW_MAXS];
   __shared__ double s_lines[16];
-  __shared__ float s_p[4][2];
+  __shared__ float s_p[4][2], s_p0[4][2];   // corners: refined (or as fitted), and as fitted
   __shared__ double s_A[72];
   __shared__ double s_gx[80], s_gy[80], s_gv[80];
   __shared__ int s_gflag[80];  // bit0: valid, bit1: white
@@ -42,76 +47,110 @@ __global__ __launch_bounds__(64, DW_WPE) void k_decode_wave(const FrameDesc* __r
   for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
     __syncthreads();
     const QuadRec q = quads_all[(size_t)frame * P.qcap + qi];
-    if (lane < 4) { s_p[lane][0] = q.p[lane][0]; s_p[lane][1] = q.p[lane][1]; }
+    if (lane < 4) { s_p[lane][0] = s_p0[lane][0] = q.p[lane][0]; s_p[lane][1] = s_p0[lane][1] = q.p[lane][1]; }
     __syncthreads();
 
     // ---- S6 edge refinement -------------------------------------------------------------------
+    // The four edges are refined TOGETHER: the lanes take the (edge, sample) pairs of all four edges, flattened edge by
+    // edge (a tag side below 136 px has the minimum of 16 samples: one pass of the wave covers the quad), and lane e
+    // accumulates edge e's moments in the CPU definition's sample order and fits its line.  (One edge after the other,
+    // with every lane repeating the ordered sums, the stage's one-frame latency was four dependent rounds of image
+    // gathers and line fits: 71 us for a noisy 1080p frame.)
     if (P.refine_edges) {
-      for (int edge = 0; edge < 4; edge++) {
-        const int a = edge, b = (edge + 1) & 3;
-        const double pax = (double)q.p[a][0], pay = (double)q.p[a][1], pbx = (double)q.p[b][0], pby = (double)q.p[b][1];
-        double nx = pby - pay;
-        double ny = -pbx + pax;
-        const double mag = __dsqrt_rn(nx * nx + ny * ny);
-        nx /= mag; ny /= mag;
-        if (q.reversed_border) { nx = -nx; ny = -ny; }
-        int nsamples = (int)(mag / 8);
-        if (nsamples < 16) nsamples = 16;
-        double Mx = 0, My = 0, Mxx = 0, Mxy = 0, Myy = 0, N = 0;
-        const double range = P.decimate + 1;
-        const int steps = (int)(2 * range * 4) + 1;
-        for (int s0 = 0; s0 < nsamples; s0 += DW_MAXS) {
-          const int s = s0 + lane;
-          int ok = 0;
-          double bestx = 0, besty = 0;
-          if (s < nsamples) {
-            const double alpha = (1.0 + s) / (nsamples + 1);
-            const double x0 = alpha * pax + (1 - alpha) * pbx;
-            const double y0 = alpha * pay + (1 - alpha) * pby;
-            double Mn = 0, Mcount = 0;  // exact sums: integer weights times multiples of 0.25
-            for (int k = 0; k < steps; k++) {
-              const double n = -range + 0.25 * k;
+      // per-edge geometry, computed by every lane for the edge its sample belongs to (and by lane e for edge e)
+      int ns[4], base[5];
+      base[0] = 0;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int b = (e + 1) & 3;
+        const double ex = (double)q.p[b][1] - (double)q.p[e][1], ey = -(double)q.p[b][0] + (double)q.p[e][0];
+        const double mag = __dsqrt_rn(ex * ex + ey * ey);
+        int n = (int)(mag / 8);
+        if (n < 16) n = 16;
+        ns[e] = n;
+        base[e + 1] = base[e] + n;
+      }
+      const int total = base[4];
+      const double range = P.decimate + 1;
+      const int steps = (int)(2 * range * 4) + 1;
+      double Mx = 0, My = 0, Mxx = 0, Mxy = 0, Myy = 0, N = 0;   // lane e < 4: moments of edge e
+      for (int c0 = 0; c0 < total; c0 += DW_MAXS) {
+        const int idx = c0 + lane;
+        int ok = 0;
+        double bestx = 0, besty = 0;
+        if (idx < total) {
+          const int edge = (idx >= base[1]) + (idx >= base[2]) + (idx >= base[3]);
+          const int sidx = idx - (edge == 0 ? base[0] : edge == 1 ? base[1] : edge == 2 ? base[2] : base[3]);
+          const int nsamples = edge == 0 ? ns[0] : edge == 1 ? ns[1] : edge == 2 ? ns[2] : ns[3];
+          const int b = (edge + 1) & 3;
+          const double pax = (double)s_p0[edge][0], pay = (double)s_p0[edge][1], pbx = (double)s_p0[b][0], pby = (double)s_p0[b][1];
+          double nx = pby - pay;
+          double ny = -pbx + pax;
+          const double mag = __dsqrt_rn(nx * nx + ny * ny);
+          nx /= mag; ny /= mag;
+          if (q.reversed_border) { nx = -nx; ny = -ny; }
+          const double alpha = (1.0 + sidx) / (nsamples + 1);
+          const double x0 = alpha * pax + (1 - alpha) * pbx;
+          const double y0 = alpha * pay + (1 - alpha) * pby;
+          double Mn = 0, Mcount = 0;  // exact sums: integer weights times multiples of 0.25
+          // the image gathers of DW_KB steps are issued together (their addresses do not depend on each other); a step
+          // outside the image reads pixel 0 and is not counted
+          for (int k0 = 0; k0 < steps; k0 += DW_KB) {
+            int g1[DW_KB], g2[DW_KB];
+            bool in[DW_KB];
+#pragma unroll
+            for (int u = 0; u < DW_KB; u++) {
+              const double n = -range + 0.25 * (k0 + u);
               const int x1 = (int)(x0 + (n + 1.0) * nx);
               const int y1 = (int)(y0 + (n + 1.0) * ny);
-              if (x1 < 0 || x1 >= w || y1 < 0 || y1 >= h) continue;
               const int x2 = (int)(x0 + (n - 1.0) * nx);
               const int y2 = (int)(y0 + (n - 1.0) * ny);
-              if (x2 < 0 || x2 >= w || y2 < 0 || y2 >= h) continue;
-              const int g1 = im[(size_t)y1 * pitch + x1];
-              const int g2 = im[(size_t)y2 * pitch + x2];
-              if (g1 < g2) continue;
-              const double weight = (double)((g2 - g1) * (g2 - g1));
+              in[u] = (k0 + u < steps) && !(x1 < 0 || x1 >= w || y1 < 0 || y1 >= h) && !(x2 < 0 || x2 >= w || y2 < 0 || y2 >= h);
+              g1[u] = im[in[u] ? (size_t)y1 * pitch + x1 : (size_t)0];
+              g2[u] = im[in[u] ? (size_t)y2 * pitch + x2 : (size_t)0];
+            }
+#pragma unroll
+            for (int u = 0; u < DW_KB; u++) {
+              if (!in[u] || g1[u] < g2[u]) continue;
+              const double n = -range + 0.25 * (k0 + u);
+              const double weight = (double)((g2[u] - g1[u]) * (g2[u] - g1[u]));
               Mn += weight * n;
               Mcount += weight;
             }
-            if (Mcount != 0) {
-              const double n0 = Mn / Mcount;
-              bestx = x0 + n0 * nx;
-              besty = y0 + n0 * ny;
-              ok = 1;
-            }
           }
-          s_bx[lane] = bestx; s_by[lane] = besty; s_bok[lane] = ok;
-          __syncthreads();
-          const int cnt = min(DW_MAXS, nsamples - s0);
-          for (int j = 0; j < cnt; j++) {  // the CPU definition's order; uniform LDS broadcast reads
+          if (Mcount != 0) {
+            const double n0 = Mn / Mcount;
+            bestx = x0 + n0 * nx;
+            besty = y0 + n0 * ny;
+            ok = 1;
+          }
+        }
+        s_bx[lane] = bestx; s_by[lane] = besty; s_bok[lane] = ok;
+        __syncthreads();
+        if (lane < 4) {   // this chunk's samples of edge `lane`, in sample order
+          const int lo = (lane == 0 ? base[0] : lane == 1 ? base[1] : lane == 2 ? base[2] : base[3]);
+          const int hi = (lane == 0 ? base[1] : lane == 1 ? base[2] : lane == 2 ? base[3] : base[4]);
+          const int j0 = max(lo, c0) - c0, j1 = min(hi, c0 + DW_MAXS) - c0;
+          for (int j = j0; j < j1; j++) {
             if (!s_bok[j]) continue;
             const double bx = s_bx[j], by = s_by[j];
             Mx += bx; My += by; Mxx += bx * bx; Mxy += bx * by; Myy += by * by; N++;
           }
-          __syncthreads();
         }
+        __syncthreads();
+      }
+      if (lane < 4) {
         const double Ex = Mx / N, Ey = My / N;
         const double Cxx = Mxx / N - Ex * Ex, Cxy = Mxy / N - Ex * Ey, Cyy = Myy / N - Ey * Ey;
         const double disc = (Cxx - Cyy) * (Cxx - Cyy) + 4 * Cxy * Cxy;
         const double eig = 0.5 * (Cxx + Cyy + (double)at_sqrtf_rn((float)disc));
         const double nx1 = Cxx - eig, ny1 = Cxy, M1 = nx1 * nx1 + ny1 * ny1;
         const double nx2 = Cxy, ny2 = Cyy - eig, M2 = nx2 * nx2 + ny2 * ny2;
-        double M;
+        double nx, ny, M;
         if (M1 > M2) { nx = nx1; ny = ny1; M = M1; } else { nx = nx2; ny = ny2; M = M2; }
         const double length = (double)at_sqrtf_rn((float)M);
         if (fabs(length) < 1e-12) { nx = 0; ny = 0; } else { nx = nx / length; ny = ny / length; }
-        if (lane == 0) { s_lines[edge * 4 + 0] = Ex; s_lines[edge * 4 + 1] = Ey; s_lines[edge * 4 + 2] = nx; s_lines[edge * 4 + 3] = ny; }
+        s_lines[lane * 4 + 0] = Ex; s_lines[lane * 4 + 1] = Ey; s_lines[lane * 4 + 2] = nx; s_lines[lane * 4 + 3] = ny;
       }
       __syncthreads();
       if (lane < 4) {

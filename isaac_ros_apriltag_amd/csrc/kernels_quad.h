@@ -616,6 +616,10 @@ __device__ const PairTable g_pair_table = make_pair_table();
 // Dynamic LDS layout: [0, 8*sort_cap) slope keys (later: raw/smoothed errors, then maxima candidates) |
 // FQ_TABLE_DOUBLES doubles for the group prefixes of the early-exit test (none in the one-wave class).  Clusters with size in (size_lo, size_hi] are processed by this
 // launch; those above sort_cap (only possible in the last class) sort in global scratch.
+#ifdef AMDAT_FQ_TIMELINE   // tools-only: wall-clock interval of every cluster a workgroup processes (tools/fit_timeline_one.py)
+__device__ unsigned long long g_fq_tl[1 << 16][2];
+__device__ unsigned int g_fq_tl_n;
+#endif
 template <int NT, bool SPLIT>
 #ifndef FQ_EPT
 #define FQ_EPT(NT) ((NT) >= 256 ? 2 : 1)   // elements per lane in the moment sweep
@@ -717,6 +721,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
   // returns per microsecond (MI355X_MICROARCH.md, "dequeue"), which a one-cluster pop of the small classes
   // (0.7 M clusters per 256-frame submission) would hit.
   uint32_t next_item = 0, chunk_left = 0;   // uniform
+#ifdef AMDAT_FQ_TIMELINE
+  unsigned long long tl_t0_ = 0; unsigned int tl_sz_ = 0;
+#endif
   for (;;) {
     __syncthreads();   // the previous cluster's LDS use (and s_item) is finished in every wave
     if (chunk_left == 0) {
@@ -727,6 +734,13 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     }
     const uint32_t item = next_item++;
     chunk_left--;
+#ifdef AMDAT_FQ_TIMELINE
+    if (tid == 0) {
+      const unsigned long long now_ = wall_clock64();
+      if (tl_sz_) { const unsigned int k_ = atomicAdd(&g_fq_tl_n, 1u); if (k_ < (1u << 16)) { g_fq_tl[k_][0] = tl_t0_; g_fq_tl[k_][1] = ((now_ - tl_t0_) << 32) | ((unsigned long long)NT << 20) | (unsigned long long)tl_sz_; } }
+      tl_t0_ = now_; tl_sz_ = 0;
+    }
+#endif
     if (item >= nwork) break;
     const uint32_t wi = (uint32_t)__builtin_amdgcn_readfirstlane((int)work[item]);
     const int frame = (int)(wi >> 16);
@@ -736,6 +750,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     const __attribute__((address_space(1))) uint8_t* const ggray = (const __attribute__((address_space(1))) uint8_t*)gray;   // global, not generic
     const ClusterRec cl = clusters_all[(size_t)frame * P.ccap + (wi & 0xFFFFu)];
     const int sz = (int)cl.count;
+#ifdef AMDAT_FQ_TIMELINE
+    tl_sz_ = (unsigned int)sz;
+#endif
     if (sz < 24 || sz > slot_cap) continue;   // (the work list only holds clusters of this class)
     FQ_TICK(0)
     const uint32_t* pts = pts_all + (size_t)frame * P.pcap + cl.start;

@@ -15,7 +15,7 @@ for r in rows:
     if "k_scatter" in n:
         cur = {"t0": r[2], "fits": [], "decode": None}
         groups.append(cur)
-    elif cur is not None and "k_fit_quads" in n:
+    elif cur is not None and ("k_fit_" in n or "k_quad_finish" in n):
         cur["fits"].append(r)
     elif cur is not None and "k_decode_wave" in n and cur["decode"] is None:
         cur["decode"] = r
