@@ -708,7 +708,21 @@ static void launch_threshold(amdAprilTagsDetector_st* D, const DetParams& P, uin
 
 // Issues the whole stage sequence for batch slots [0, n) on stream s.  mark() is called between stages
 // (event timing when profiling).
-static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s, const std::function<void()>& mark) {
+// first launch of a submission: frame descriptors from the pinned host block to device memory, work-list control words
+// and frame counters to zero (one block per frame)
+__global__ __launch_bounds__(64) void k_prologue(const uint32_t* __restrict__ host_frames, uint32_t* __restrict__ frames,
+                                                 uint32_t* __restrict__ workctl, uint32_t* __restrict__ counters, int fd_words, int fc_words) {
+  const int frame = (int)blockIdx.x, t = (int)threadIdx.x;
+  for (int i = t; i < fd_words; i += 64) frames[frame * fd_words + i] = host_frames[frame * fd_words + i];
+  for (int i = t; i < fc_words; i += 64) counters[frame * fc_words + i] = 0u;
+  if (frame == 0 && t < 32) workctl[t] = 0u;
+}
+
+// Small submissions let k_reconcile write results and counters into the pinned host buffers itself (see there); large
+// ones keep the two copy commands (megabytes over PCIe are the copy engines' job).
+static inline bool direct_results(uint32_t n) { return n <= 8; }
+
+static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s, const std::function<void()>& mark) {
   DetParams P = D->P;
   P.frame0 = 0;
   launch_threshold(D, P, n, s);
@@ -900,7 +914,11 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
     hipLaunchKernelGGL(k_decode_wave, dim3(gq, n), dim3(64), 0, s, D->d_frames, D->d_quads, D->d_dets, D->d_counters, P);
   }
   mark();
-  hipLaunchKernelGGL(k_reconcile, dim3(n), dim3(64), 0, s, D->d_frames, D->d_dets, D->d_out, D->d_counters, D->d_order, P);
+  {
+    const bool direct = direct_results(n);
+    hipLaunchKernelGGL(k_reconcile, dim3(n), dim3(64), 0, s, D->d_frames, D->d_dets, D->d_out, D->d_counters, D->d_order,
+                       direct ? D->h_out : nullptr, ostride, D->h_counters, P);
+  }
   mark();
   return AMDAT_SUCCESS;
 }
@@ -910,17 +928,23 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, hipStream_t s,
 static int enqueue_submission(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s, const std::function<void()>& mark) {
   const DetParams& P = D->P;
   mark();
-  HIP_TRY(hipMemcpyAsync(D->d_frames, D->h_frames, n * sizeof(FrameDesc), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(D->d_workctl, 0, 32 * 4 + n * sizeof(FrameCounters), s));   // control words + the counters behind them
+  // descriptor upload + clears in one small kernel (it reads the pinned descriptor block over the bus itself): a copy
+  // command and a fill command ahead of the first kernel cost a one-frame call about 15 us, this launch 4
+  static_assert(sizeof(FrameDesc) % 4 == 0 && sizeof(FrameDesc) <= 256 && sizeof(FrameCounters) % 4 == 0 && sizeof(FrameCounters) <= 256, "k_prologue: one word per thread");
+  hipLaunchKernelGGL(k_prologue, dim3(n), dim3(64), 0, s, reinterpret_cast<const uint32_t*>(D->h_frames),
+                     reinterpret_cast<uint32_t*>(D->d_frames), D->d_workctl, reinterpret_cast<uint32_t*>(D->d_counters),
+                     (int)(sizeof(FrameDesc) / 4), (int)(sizeof(FrameCounters) / 4));
   if (D->fq_counters) HIP_TRY(hipMemsetAsync(D->d_fqprof, 0, (64 + 8) * 8, s));
   mark();
   {
-    const int rc = issue_pipeline(D, n, s, mark);
+    const int rc = issue_pipeline(D, n, ostride, s, mark);
     if (rc) return rc;
   }
-  HIP_TRY(hipMemcpyAsync(D->h_counters, D->d_counters, n * sizeof(FrameCounters), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpy2DAsync(D->h_out, (size_t)ostride * sizeof(DetRec), D->d_out, (size_t)P.dcap * sizeof(DetRec),
-                           (size_t)ostride * sizeof(DetRec), n, hipMemcpyDeviceToHost, s));
+  if (!direct_results(n)) {
+    HIP_TRY(hipMemcpyAsync(D->h_counters, D->d_counters, n * sizeof(FrameCounters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpy2DAsync(D->h_out, (size_t)ostride * sizeof(DetRec), D->d_out, (size_t)P.dcap * sizeof(DetRec),
+                             (size_t)ostride * sizeof(DetRec), n, hipMemcpyDeviceToHost, s));
+  }
   mark();
   return AMDAT_SUCCESS;
 }

@@ -151,7 +151,11 @@ __device__ void pose_from_homography_dev(const double* H, double fx_in, double f
 // one 64-thread block per frame; lane 0 orders and reconciles (tens of records), all lanes copy
 __global__ __launch_bounds__(64) void k_reconcile(const FrameDesc* __restrict__ frames, const DetRec* __restrict__ dets_all,
                                                   DetRec* __restrict__ out_all, FrameCounters* __restrict__ counters,
-                                                  uint16_t* __restrict__ order_all, DetParams P) {
+                                                  uint16_t* __restrict__ order_all, DetRec* __restrict__ host_out,
+                                                  uint32_t host_stride, FrameCounters* __restrict__ host_counters, DetParams P) {
+  // host_out != nullptr (small submissions): the kept records and the frame's counters go straight to the pinned host
+  // buffers the API call reads -- `host_stride` records per frame -- instead of to device buffers that two copy commands
+  // would move afterwards (about 10 us of a one-frame call)
   const int frame = (int)blockIdx.x + P.frame0;
   uint32_t nd = counters[frame].ndets;
   if (nd > P.dcap) nd = P.dcap;
@@ -194,6 +198,8 @@ __global__ __launch_bounds__(64) void k_reconcile(const FrameDesc* __restrict__ 
   for (uint32_t i = threadIdx.x; i < nk; i += 64) {
     DetRec d = dets[order[i]];
     pose_from_homography_dev(d.H, fd.fx, fd.fy, fd.cx, fd.cy, fd.skew, P.tag_size, d.R, d.t);
-    out[i] = d;
+    if (!host_out) out[i] = d;
+    else if (i < host_stride) host_out[(size_t)frame * host_stride + i] = d;
   }
+  if (host_out && threadIdx.x == 0) host_counters[frame] = counters[frame];   // (this block wrote the last field, nout, itself)
 }
