@@ -528,16 +528,6 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
     // to 768, 256 up to 2048, 512 up to 8192 -- measured slower on one-frame submissions, 0.36 against 0.28 ms for the
     // stage: the larger workgroups' barriers cost more than the shorter per-lane runs save)
     D->prefilter_class = 2;
-#ifdef AMDAT_LAT_B01   // experiment: class boundaries of a handle that only ever sees small submissions
-    if ((uint64_t)B * (uint64_t)P.W * (uint64_t)P.H < (16ull << 20)) {
-      c[0].hi = c[1].lo = AMDAT_LAT_B01;
-      c[1].hi = c[2].lo = AMDAT_LAT_B12;
-#ifdef AMDAT_LAT_B23
-      c[2].hi = c[3].lo = AMDAT_LAT_B23;
-      c[3].hi = c[4].lo = AMDAT_LAT_B34;
-#endif
-    }
-#endif
     c[4] = {FQ_NT_BIG, 16384, 8192, 0x7FFFFFFF, minu(cus, 16u * (unsigned)B), P.max_cluster_points, 1};
     if (P.max_cluster_points > 16384 && P.max_cluster_points <= 18432) c[4].sort_cap = (P.max_cluster_points + 63) & ~63;
     if (c[4].slot_cap < 8193) c[4].slot_cap = 8193;
@@ -857,24 +847,11 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
       // (the longest chain) first.
       // A small submission leaves most of the chip empty either way: its classes below the prefilter start at once on the
       // side streams, beside the prefilter.
-#ifdef AMDAT_SMALL_SERIAL
-      if (small) {
-        launch_prefilter(s);
-        for (int c = pf_first; c < FQ_NCLS; c++) launch_class(c, s);
-        for (int c = pf_first - 1; c >= 0; c--) launch_class(c, s);
-        hipLaunchKernelGGL(k_quad_finish, dim3(16, n), dim3(256), 0, s, D->d_cands, D->d_quads, D->d_counters, P);
-        goto fit_done;
-      }
-#endif
       if (!small) launch_prefilter(s);
       HIP_TRY(hipEventRecord(D->ev_fork, s));
       for (int a = 0; a < 3; a++) HIP_TRY(hipStreamWaitEvent(aux[a], D->ev_fork, 0));
       if (small) launch_prefilter(s);
       for (int c = pf_first; c < FQ_NCLS; c++) launch_class(c, s);   // (nearly all survivors are in the first of them)
-#ifdef AMDAT_SMALL_PLAN   // experiment: stream of each class below the prefilter, one nibble per class (0 = s, 1..3 = side streams)
-      if (small) { for (int c = pf_first - 1; c >= 0; c--) { const int w = (AMDAT_SMALL_PLAN >> (4 * c)) & 15; launch_class(c, w ? aux[w - 1] : s); } }
-      else
-#endif
       for (int c = pf_first - 1, a = 0; c >= 0; c--, a++) launch_class(c, aux[a % 3]);   // the longest chains first
     } else {
     if (large_first) {
@@ -902,9 +879,6 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
     }
     // corners + area / angle checks of the candidates, one thread each
     hipLaunchKernelGGL(k_quad_finish, dim3(16, n), dim3(256), 0, s, D->d_cands, D->d_quads, D->d_counters, P);
-#ifdef AMDAT_SMALL_SERIAL
-  fit_done:;
-#endif
   }
   mark();
   {

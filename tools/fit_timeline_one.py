@@ -7,9 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 from isaac_ros_apriltag_amd import capi, synth
 capi.LIB_PATH = os.path.join(ROOT, "isaac_ros_apriltag_amd", "libapriltag_amd_%s.so" % os.environ.get("AMDAT_LIB", "tl"))
 from isaac_ros_apriltag_amd.detector import AprilTagDetector
-img, K, _ = synth.scene_c2(seed=1234)
-t = torch.from_numpy(img).cuda()
-det = AprilTagDetector(1920, 1080, intrinsics=(K[0, 0], K[1, 1], K[0, 2], K[1, 2]), max_batch=1)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+K = synth.scene_c2(seed=1234)[1]
+t = torch.from_numpy(np.stack([synth.scene_c2(seed=1234 + i)[0] for i in range(B)])).cuda()
+det = AprilTagDetector(1920, 1080, intrinsics=(K[0, 0], K[1, 1], K[0, 2], K[1, 2]), max_batch=B)
 prep = det.prepare(t)
 L = capi.lib()
 L.amdAprilTagsDebugTimeline.argtypes = [C.c_void_p, C.c_uint]
@@ -30,6 +31,8 @@ for c in sorted(set(nt)):
     print("NT=%4d: %5d clusters, first start %.1f us, last start %.1f us, last end %.1f us, mean dur %.1f us, max dur %.1f us (sz %d)" %
           (c, m.sum(), (t0[m].min() - base) * tick, (t0[m].max() - base) * tick, ((t0 + dur)[m].max() - base) * tick, dur[m].mean() * tick,
            dur[m].max() * tick, sz[m][dur[m].argmax()]))
+    ends = np.sort((t0 + dur)[m] - base) * tick
+    print("      ends: 50%% %.1f  90%% %.1f  99%% %.1f  100%% %.1f us; busy wave-us %.0f" % (ends[len(ends) // 2], ends[int(len(ends) * .9)], ends[int(len(ends) * .99)], ends[-1], dur[m].sum() * tick))
     order = np.argsort(-(t0 + dur)[m])[:5]
     for k in order:
         print("      sz %5d start %.1f dur %.1f end %.1f" % (sz[m][k], (t0[m][k] - base) * tick, dur[m][k] * tick, ((t0 + dur)[m][k] - base) * tick))

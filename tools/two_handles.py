@@ -3,7 +3,9 @@ host threads, the second started half a step later, against one handle with B fr
 import os, sys, time, threading
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-from isaac_ros_apriltag_amd import synth
+from isaac_ros_apriltag_amd import capi, synth
+if os.environ.get("AMDAT_LIB"):
+    capi.LIB_PATH = os.path.join(ROOT, "isaac_ros_apriltag_amd", "libapriltag_amd_%s.so" % os.environ["AMDAT_LIB"])
 from isaac_ros_apriltag_amd.detector import AprilTagDetector
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 nh = int(sys.argv[2]) if len(sys.argv) > 2 else 2
@@ -23,7 +25,7 @@ for d, p in zip(dets, preps):
     d.run_prepared(p)
 steps = 12
 def worker(i):
-    time.sleep(i * 0.009)
+    time.sleep(i * float(os.environ.get('STAGGER_MS', '9')) * 1e-3)
     for _ in range(steps): dets[i].run_prepared(preps[i])
 ths = [threading.Thread(target=worker, args=(i,)) for i in range(nh)]
 t0 = time.perf_counter()
