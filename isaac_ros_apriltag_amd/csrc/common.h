@@ -163,13 +163,15 @@ __device__ __forceinline__ void at_frame_block(uint32_t lin, uint32_t bpf, uint3
 }
 
 // wave-level inclusive scan (wave64)
+// (on the DPP network -- row_shr 1/2/4/8 inside the rows of 16 lanes, then the row broadcasts 15 and 31; lanes without a
+// source add 0 -- not with __shfl_up: that is six ds_bpermute_b32 through the LDS crossbar per scan)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-  int lane = lane_id();
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    uint32_t n = __shfl_up(v, off, 64);
-    if (lane >= off) v += n;
-  }
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);
   return v;
 }
 

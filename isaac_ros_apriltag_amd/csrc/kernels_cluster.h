@@ -91,7 +91,10 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
 #define PT_TICK(slot)
   (void)prof;
 #endif
-  __shared__ uint8_t sv[PT_LH * PT_LW];
+  // tile + halo, one word per pixel: representative of the pixel's component if it is large enough, bit 31 = the pixel is
+  // white; AT_NO_LABEL = no component that counts (value 127, or too small).  Two labelled pixels have different values
+  // exactly when bit 31 differs, so the emission tests read this one array (a separate byte array of the values cost a
+  // second LDS read per test, and its four-pixels-per-bank byte reads were most of the kernel's LDS bank conflicts).
   __shared__ uint32_t slab[PT_LH * PT_LW];
   __shared__ uint32_t sscan[4];
   __shared__ uint32_t sbase;
@@ -138,8 +141,8 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
 #pragma unroll
     for (int e = 0; e < NE; e++) {
       const int i = tid + e * 256;
-      const uint32_t lab = (r[e] >> 31) ? (r[e] & AT_LABEL_MASK) : AT_NO_LABEL;
-      if (i < PT_LH * PT_LW) { sv[i] = (uint8_t)v[e]; slab[i] = lab; }
+      const uint32_t lab = (r[e] >> 31) ? ((r[e] & AT_LABEL_MASK) | (v[e] == 255u ? 0x80000000u : 0u)) : AT_NO_LABEL;
+      if (i < PT_LH * PT_LW) slab[i] = lab;
     }
   }
   tkey[tid] = AT_EMPTY_KEY;
@@ -168,17 +171,18 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     const int gy = Y0 + ly;
     if (gx < 1 || gx > W - 2 || gy < 1 || gy > H - 2) continue;
     const int c = ly * PT_LW + lx + 1;
-    if (slab[c] == AT_NO_LABEL) continue;
-    const int v0 = sv[c];
+    const uint32_t s0 = slab[c];
+    if (s0 == AT_NO_LABEL) continue;
     // upstream's connected_last: the left neighbour (a valid source itself) emitted its (1,1) point,
     // which is this pixel's (-1,1) half-pixel location
-    const bool left_emits = gx - 1 >= 1 && slab[c - 1] != AT_NO_LABEL && slab[c + PT_LW] != AT_NO_LABEL &&
-                            (int)sv[c - 1] + (int)sv[c + PT_LW] == 255;
+    const uint32_t s_l = slab[c - 1], s_d = slab[c + PT_LW];
+    const bool left_emits = gx - 1 >= 1 && s_l != AT_NO_LABEL && s_d != AT_NO_LABEL && ((s_l ^ s_d) >> 31);
 #pragma unroll
     for (int d = 0; d < 4; d++) {
       if (d == 2 && left_emits) continue;
       const int n = c + DY[d] * PT_LW + DX[d];
-      if (slab[n] == AT_NO_LABEL || v0 + (int)sv[n] != 255) continue;
+      const uint32_t s_n = (d == 1) ? s_d : slab[n];
+      if (s_n == AT_NO_LABEL || !((s0 ^ s_n) >> 31)) continue;
       emask |= 1u << (k * 4 + d);
       cnt++;
     }
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     const int ly = (int)(rec & 1023u) >> 6, plx = (int)(rec & 63u), d = (int)((rec >> 10) & 3u);
     const int c = ly * PT_LW + plx + 1;
     const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
-    const uint32_t r0 = slab[c], r1 = slab[c + ddy * PT_LW + ddx];
+    const uint32_t r0 = slab[c] & AT_LABEL_MASK, r1 = slab[c + ddy * PT_LW + ddx] & AT_LABEL_MASK;
     const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
     const int e = ltab_insert(tkey, key);
     uint32_t ee = 255u, rk = 0u;
@@ -257,13 +261,14 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     const int c = ly * PT_LW + plx + 1;
     const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
     const int n = c + ddy * PT_LW + ddx;
-    const int v0 = sv[c], v1 = sv[n];
+    const uint32_t s0 = slab[c], s1 = slab[n];
+    const int v0 = (s0 >> 31) ? 255 : 0, v1 = (s1 >> 31) ? 255 : 0;
     uint32_t slot, rk = 0;
     if (e != 255u) {
       slot = tslot[e];
       if (slot != AT_INVALID_SLOT) rk = tbase[e] + (rec >> 20);
     } else {  // not counted in the block table: this point goes straight to the frame table
-      const uint32_t r0 = slab[c], r1 = slab[n];
+      const uint32_t r0 = s0 & AT_LABEL_MASK, r1 = s1 & AT_LABEL_MASK;
       const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
       slot = hash_insert(hkeys, P.hcap, P.hshift, key);
       if (slot == AT_INVALID_SLOT) atomicOr(&counters[frame].flags, 0x2u);
