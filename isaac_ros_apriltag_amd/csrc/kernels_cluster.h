@@ -74,6 +74,13 @@ __device__ __forceinline__ int ltab_find(const unsigned long long* tkey, uint64_
   return -1;
 }
 
+// Where the kernel's time goes (256 sigma-2 1080p frames, 3.97 ms; builds that stop after a phase, and builds with one
+// operation taken out): tile load 0.85 ms, emission tests + scan 0.43, list 0.37, pass 2 1.0 (of which the returning
+// same-address LDS add 0.5, the table insert 0.23), frame table 0.8 (two or three dependent L2 round trips per block, with
+// the block's other waves at the barrier), emit + staging stores 0.6.  Grouping a wave's lanes by key with ballots so that
+// one lane per group adds (2 / 4 / 6 leader rounds) measured 4.00 / 4.09 / 4.05 ms: the rounds cost what the serialised
+// atomic does.  (The cycle shares of the profiling build put 60 % on the last two phases: its per-phase global atomics are
+// waited for there.)
 // Boundary points of one 64x16 tile.  Points are counted per component pair in a per-block LDS table
 // first, so that the per-frame hash table sees ONE insert and ONE atomicAdd per (block, pair); the
 // value the add returns is the block's base rank inside the cluster, so every staged point carries its
@@ -191,8 +198,8 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   const uint32_t off = block_excl_scan256(cnt, sscan, &total);  // contains __syncthreads
   PT_TICK(1)
   if (total == 0) return;
-#if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 2   // (pass 1's results are written out so that they stay live)
-  if (P.max_nmaxima == 10) { rank_all[(size_t)frame * P.pcap + (blk_ % 64u) * 256 + tid] = emask ^ off; return; }
+#if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 2   // (pass 1's results are written out so that they stay live; into the staging buffer -- the rank array is not allocated when the staging record is packed)
+  if (P.max_nmaxima == 10) { reinterpret_cast<uint32_t*>(stage_all + (size_t)frame * P.pcap)[(blk_ % 64u) * 256 + tid] = emask ^ off; return; }
 #endif
   unsigned long long* hkeys = hkeys_all + (size_t)frame * P.hcap;
   uint32_t* hcnt = hcnt_all + (size_t)frame * P.hcap;
@@ -209,6 +216,9 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   }
   __syncthreads();
   PT_TICK(2)
+#if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 4   // (after the list is built)
+  if (P.max_nmaxima == 10) { reinterpret_cast<uint32_t*>(stage_all + (size_t)frame * P.pcap)[(blk_ % 64u) * 256 + tid] = emask ^ off ^ elist[tid]; return; }
+#endif
   // pass 2, DENSE over the list (entry q belongs to thread q mod 256): pair key -> block table entry e (one insert), and
   // the emission's rank inside its (block, pair) group from the value the counting atomic returns -- on a full wave of
   // real emissions the returning LDS atomic costs what a leader loop over the wave's distinct entries does, and the
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   __syncthreads();
   PT_TICK(3)
 #if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 3
-  if (P.max_nmaxima == 10) { rank_all[(size_t)frame * P.pcap + (blk_ % 64u) * 256 + tid] = emask ^ off ^ elist[tid] ^ sbase; return; }
+  if (P.max_nmaxima == 10) { reinterpret_cast<uint32_t*>(stage_all + (size_t)frame * P.pcap)[(blk_ % 64u) * 256 + tid] = emask ^ off ^ elist[tid] ^ sbase; return; }
 #endif
   {
     // one global insert + one global add per distinct pair of this block; the add's return value is the base rank of
