@@ -186,15 +186,15 @@ def stage_rooflines(stage_ms, nframes, counts, decimate):
     Per frame of N working pixels, P raw boundary points, Pk points in kept clusters:
       threshold  read N, write N                                                          2 N
       cc_local   read N (threshold image), write 4 N (labels)                             5 N
-      points     read N + 4 N, write 8 B per raw point (slot | rank, point)               5 N + 8 P
-      scatter    read 8 P, write 4 Pk                                                     8 P + 4 Pk
+      points     read N + 4 N, write 4 B per raw point (one staging word)                 5 N + 4 P
+      scatter    read 4 P, write 4 Pk                                                     4 P + 4 Pk
       fit_quads  read 4 B per point + the four gray bytes of its gradient                 8 Pk
     Representative / size gathers (points), the offset gather (scatter) and the quad fit's cumulative-moment scratch
     (48 B per point written and read back) are NOT algorithmic: they show up in traffic_ratio."""
     w, h = 1 + (W - 1) // decimate, 1 + (H - 1) // decimate
     N = float(w * h)
     P, Pk = counts["npoints_raw"], counts["npoints_kept"]
-    alg = {"threshold": 2 * N, "cc_local": 5 * N, "points": 5 * N + 8 * P, "scatter": 8 * P + 4 * Pk, "fit_quads": 8 * Pk}
+    alg = {"threshold": 2 * N, "cc_local": 5 * N, "points": 5 * N + 4 * P, "scatter": 4 * P + 4 * Pk, "fit_quads": 8 * Pk}
     pmc, pmc_src = None, None
     path = os.path.join(ROOT, "profiles", "r03_pipeline_pmc.json")
     if decimate == 1 and os.path.exists(path):

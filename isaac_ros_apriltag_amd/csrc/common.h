@@ -33,7 +33,7 @@ struct FrameCounters {
   uint32_t nout;          // detections after reconcile
   uint32_t nroots;        // tile-local component roots (CC root list)
   uint32_t ncand;         // quad candidates (four fitted lines) awaiting k_quad_finish
-  uint32_t pad0;
+  uint32_t nlong;         // long staging records (k_points -> k_scatter)
 };
 
 struct ClusterRec {
@@ -107,8 +107,7 @@ struct DetParams {
   uint32_t pcap, hcap, hshift, ccap, qcap, dcap;
   uint32_t rcap;     // tile-local roots per frame (CC root list)
   uint32_t cand_cap; // quad candidates per frame (k_fit_quads -> k_quad_finish); grows on demand up to ccap
-  int pack_stage;    // staging record = {slot | rank << 16, point} (8 bytes) instead of {slot, point} + rank (12): needs
-                     // hcap <= 65536 and kept clusters below 65534 points
+  uint32_t lcap;     // long staging records per frame (emissions without a block-table entry, kernels_cluster.h): pcap / 8
   FamilyDev fam[AT_MAX_FAMILIES];
 };
 

@@ -152,8 +152,10 @@ struct amdAprilTagsDetector_st {
   unsigned long long* d_hkeys = nullptr;
   uint32_t* d_hcnt = nullptr;
   uint32_t* d_hoff = nullptr;
-  uint2* d_stage = nullptr;
-  uint32_t* d_rank = nullptr;
+  uint32_t* d_stage = nullptr;       // one word per staged boundary point (kernels_cluster.h, pass 3 of k_points)
+  uint2* d_bhdr = nullptr;           // per block (tile) of k_points: {first staging word, words}
+  uint2* d_btab = nullptr;           // per block: its component-pair table, {pair-table slot, base rank inside the cluster} per entry
+  uint4* d_long = nullptr;           // {slot, rank, packed point}: emissions without a block-table entry
   uint32_t* d_pts = nullptr;
   ClusterRec* d_clusters = nullptr;
   uint32_t* d_work = nullptr;        // work lists of the quad fit (all classes, FqWorkLayout)
@@ -326,7 +328,7 @@ const char* amdAprilTagsStageName(uint32_t stage) { return stage < AMDAT_NUM_STA
 static void free_all(amdAprilTagsDetector_st* D) {
   for (auto& g : D->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
   hipFree(D->d_gray); hipFree(D->d_thr); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_roots); hipFree(D->d_hkeys);
-  hipFree(D->d_hcnt); hipFree(D->d_hoff); hipFree(D->d_stage); hipFree(D->d_rank); hipFree(D->d_pts); hipFree(D->d_clusters);
+  hipFree(D->d_hcnt); hipFree(D->d_hoff); hipFree(D->d_stage); hipFree(D->d_bhdr); hipFree(D->d_btab); hipFree(D->d_long); hipFree(D->d_pts); hipFree(D->d_clusters);
   hipFree(D->d_work); hipFree(D->d_work2); hipFree(D->d_workctl); hipFree(D->d_keys_scr); hipFree(D->d_quads);
   for (auto& c : D->cls) { hipFree(c.d_lf); hipFree(c.d_errs); }
   hipFree(D->d_fqprof);
@@ -355,12 +357,11 @@ static int clear_hash_tables(amdAprilTagsDetector_st* D) {
   return AMDAT_SUCCESS;
 }
 
-// The component-pair table of P.hcap slots per frame; also decides the staging format (DetParams::pack_stage).
+// The component-pair table of P.hcap slots per frame.
 static int alloc_hash_buffers(amdAprilTagsDetector_st* D) {
   DetParams& P = D->P;
   const size_t B = D->cfg.max_batch;
   { uint32_t lg = 0; while ((1u << lg) < P.hcap) lg++; P.hshift = 64 - lg; }
-  P.pack_stage = (P.hcap <= 65536u && P.max_cluster_points < 65534) ? 1 : 0;
   void** bufs[3] = {(void**)&D->d_hkeys, (void**)&D->d_hcnt, (void**)&D->d_hoff};
   const size_t bytes[3] = {B * (size_t)P.hcap * 8, B * (size_t)P.hcap * 4, B * (size_t)P.hcap * 4};
   for (int i = 0; i < 3; i++)
@@ -373,7 +374,7 @@ static int alloc_hash_buffers(amdAprilTagsDetector_st* D) {
   return clear_hash_tables(D);
 }
 
-// Buffers whose size follows the point capacity P.pcap: staging records, ranks, points and the quad fit's work lists (their
+// Buffers whose size follows the point capacity P.pcap: staging words, long staging records, points and the quad fit's work lists (their
 // capacities are bounded by points / smallest cluster of the class).  Called at creation and again when the capacity grows.
 static int alloc_point_buffers(amdAprilTagsDetector_st* D) {
   DetParams& P = D->P;
@@ -390,8 +391,9 @@ static int alloc_point_buffers(amdAprilTagsDetector_st* D) {
     D->work_layout.cap[k] = (uint32_t)cap;
     off += cap;
   }
-  void** bufs[5] = {(void**)&D->d_stage, (void**)&D->d_rank, (void**)&D->d_pts, (void**)&D->d_work, (void**)&D->d_work2};
-  const size_t bytes[5] = {B * (size_t)P.pcap * 8, P.pack_stage ? 0 : B * (size_t)P.pcap * 4, B * (size_t)P.pcap * 4, (size_t)off * 4,
+  P.lcap = P.pcap / 8 > 4096u ? P.pcap / 8 : 4096u;
+  void** bufs[5] = {(void**)&D->d_stage, (void**)&D->d_long, (void**)&D->d_pts, (void**)&D->d_work, (void**)&D->d_work2};
+  const size_t bytes[5] = {B * (size_t)P.pcap * 4, B * (size_t)P.lcap * 16, B * (size_t)P.pcap * 4, (size_t)off * 4,
                            ((size_t)off - D->work_layout.off[D->prefilter_class]) * 4};
   for (int i = 0; i < 5; i++) {
     if (*bufs[i]) { hipFree(*bufs[i]); *bufs[i] = nullptr; D->device_bytes -= D->point_buffer_bytes[i]; D->point_buffer_bytes[i] = 0; }
@@ -548,6 +550,11 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   P.rcap = (uint32_t)(((W + CC_T - 1) / CC_T) * ((H + CC_T - 1) / CC_T)) * (4u * CC_T - 4u);
   alloc((void**)&D->d_roots, B * (size_t)P.rcap * 4);
   if (ok) ok = alloc_hash_buffers(D) == AMDAT_SUCCESS;   // (before the point buffers: it decides the staging format)
+  {   // per block (64 x 16 tile) of k_points: header and component-pair table for k_scatter
+    const size_t tiles = (size_t)((W + PT_TW - 1) / PT_TW) * (size_t)((H + PT_TH - 1) / PT_TH);
+    alloc((void**)&D->d_bhdr, B * tiles * sizeof(uint2));
+    alloc((void**)&D->d_btab, B * tiles * PT_TB * sizeof(uint2));
+  }
   alloc((void**)&D->d_clusters, B * (size_t)P.ccap * sizeof(ClusterRec));
   if (ok) { const int rc = alloc_point_buffers(D); if (rc == AMDAT_BATCH_TOO_LARGE) { free_all(D); delete D; return rc; } ok = rc == AMDAT_SUCCESS; }
   for (int k = 0; k < FQ_NCLS; k++) {
@@ -739,7 +746,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
   {
     const uint32_t gxt = (uint32_t)((P.W + PT_TW - 1) / PT_TW), gyt = (uint32_t)((P.H + PT_TH - 1) / PT_TH);
     hipLaunchKernelGGL(k_points, dim3(gxt * gyt * n), dim3(256), 0, s, D->d_thr, D->d_label, D->d_csize, D->d_hkeys, D->d_hcnt,
-                       D->d_stage, D->d_rank, D->d_counters, (D->fq_counters ? D->d_ptprof : nullptr), gxt, gyt, n, P);
+                       D->d_stage, D->d_bhdr, D->d_btab, D->d_long, D->d_counters, (D->fq_counters ? D->d_ptprof : nullptr), gxt, gyt, n, P);
   }
   mark();
   hipLaunchKernelGGL(k_cluster_select, dim3((P.hcap + 1023) / 1024, 1, n), dim3(256), 0, s, D->d_hkeys, D->d_hcnt, D->d_hoff,
@@ -752,9 +759,9 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
   }
   mark();
   {
-    unsigned gx = (P.pcap + 255) / 256;
-    if (gx > 2048) gx = 2048;
-    hipLaunchKernelGGL(k_scatter, dim3(gx, 1, n), dim3(256), 0, s, D->d_stage, D->d_rank, D->d_hoff, D->d_pts, D->d_counters, P);
+    const uint32_t gxt = (uint32_t)((P.W + PT_TW - 1) / PT_TW), gyt = (uint32_t)((P.H + PT_TH - 1) / PT_TH);
+    hipLaunchKernelGGL(k_scatter, dim3(gxt * gyt, 1, n), dim3(256), 0, s, D->d_stage, D->d_bhdr, D->d_btab, D->d_long, D->d_hoff, D->d_pts,
+                       D->d_counters, gxt, gyt, P);
   }
   mark();
   {

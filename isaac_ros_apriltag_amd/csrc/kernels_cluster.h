@@ -87,8 +87,9 @@ __device__ __forceinline__ int ltab_find(const unsigned long long* tkey, uint64_
 // final position (hoff[slot] + rank) and the scatter pass needs no atomics at all.
 __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_all, const uint32_t* __restrict__ label_all,
                                                 const uint32_t* __restrict__ csize_all, unsigned long long* __restrict__ hkeys_all,
-                                                uint32_t* __restrict__ hcnt_all, uint2* __restrict__ stage_all,
-                                                uint32_t* __restrict__ rank_all, FrameCounters* __restrict__ counters,
+                                                uint32_t* __restrict__ hcnt_all, uint32_t* __restrict__ stage_all,
+                                                uint2* __restrict__ bhdr_all, uint2* __restrict__ btab_all, uint4* __restrict__ long_all,
+                                                FrameCounters* __restrict__ counters,
                                                 unsigned long long* __restrict__ prof, uint32_t gx_tiles, uint32_t gy_tiles, uint32_t nframes,
                                                 DetParams P) {
 #ifdef AMDAT_FQ_PROFILE   // tools-only: shader cycles per phase, prof[0..5] (tile load, emission tests + scan, list, block table, frame table, stores)
@@ -197,9 +198,13 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   uint32_t total;
   const uint32_t off = block_excl_scan256(cnt, sscan, &total);  // contains __syncthreads
   PT_TICK(1)
-  if (total == 0) return;
+  const uint32_t bpf = gx_tiles * gy_tiles;   // blocks (tiles) per frame
+  if (total == 0) {
+    if (tid == 0) bhdr_all[(size_t)frame * bpf + blk_] = make_uint2(0u, 0u);
+    return;
+  }
 #if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 2   // (pass 1's results are written out so that they stay live; into the staging buffer -- the rank array is not allocated when the staging record is packed)
-  if (P.max_nmaxima == 10) { reinterpret_cast<uint32_t*>(stage_all + (size_t)frame * P.pcap)[(blk_ % 64u) * 256 + tid] = emask ^ off; return; }
+  if (P.max_nmaxima == 10) { stage_all[(size_t)frame * P.pcap + (blk_ % 64u) * 256 + tid] = emask ^ off; return; }
 #endif
   unsigned long long* hkeys = hkeys_all + (size_t)frame * P.hcap;
   uint32_t* hcnt = hcnt_all + (size_t)frame * P.hcap;
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   __syncthreads();
   PT_TICK(2)
 #if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 4   // (after the list is built)
-  if (P.max_nmaxima == 10) { reinterpret_cast<uint32_t*>(stage_all + (size_t)frame * P.pcap)[(blk_ % 64u) * 256 + tid] = emask ^ off ^ elist[tid]; return; }
+  if (P.max_nmaxima == 10) { stage_all[(size_t)frame * P.pcap + (blk_ % 64u) * 256 + tid] = emask ^ off ^ elist[tid]; return; }
 #endif
   // pass 2, DENSE over the list (entry q belongs to thread q mod 256): pair key -> block table entry e (one insert), and
   // the emission's rank inside its (block, pair) group from the value the counting atomic returns -- on a full wave of
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   __syncthreads();
   PT_TICK(3)
 #if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 3
-  if (P.max_nmaxima == 10) { reinterpret_cast<uint32_t*>(stage_all + (size_t)frame * P.pcap)[(blk_ % 64u) * 256 + tid] = emask ^ off ^ elist[tid] ^ sbase; return; }
+  if (P.max_nmaxima == 10) { stage_all[(size_t)frame * P.pcap + (blk_ % 64u) * 256 + tid] = emask ^ off ^ elist[tid] ^ sbase; return; }
 #endif
   {
     // one global insert + one global add per distinct pair of this block; the add's return value is the base rank of
@@ -253,6 +258,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
       else atomicOr(&counters[frame].flags, 0x2u);
       tslot[tid] = slot;
       tbase[tid] = base;
+      btab_all[((size_t)frame * bpf + blk_) * PT_TB + tid] = make_uint2(slot, base);   // (only used entries are ever written or read)
     }
   }
   __syncthreads();
@@ -261,10 +267,15 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   if (base + total > P.pcap) {
     if (tid == 0) atomicOr(&counters[frame].flags, 0x1u);
   }
-  // pass 3: emit {slot, point} and the rank inside the cluster, dense over the list again: the staging stores of a wave
-  // are 64 consecutive records.
-  uint2* stage = stage_all + (size_t)frame * P.pcap;
-  uint32_t* rank = rank_all + (size_t)frame * P.pcap;
+  // pass 3: the staging records, dense over the list again (the stores of a wave are 64 consecutive words).  A record is
+  // ONE word -- block-table entry (8 bits) | rank inside the (block, pair) group (11) | pixel of the tile (10) | direction (2)
+  // | sign of the value step (1) -- because everything else k_scatter needs is per block: the tile origin follows from the
+  // block index, the pair-table slot and the block's base rank inside the cluster from the table entry (btab), the range
+  // of the block's records from its header (bhdr).  (8-byte records {slot | rank, packed point} were 40 % more bytes
+  // through the staging buffer and back.)  The few emissions without a table entry -- block table full, or beyond the
+  // list -- take their slot and rank from the frame table one by one and go to a side list of long records.
+  uint32_t* stage = stage_all + (size_t)frame * P.pcap;
+  if (tid == 0) bhdr_all[(size_t)frame * bpf + blk_] = make_uint2(base, base + total > P.pcap ? (base < P.pcap ? P.pcap - base : 0u) : total);
   auto emit = [&](uint32_t rec, uint32_t pos) {
     const int ly = (int)(rec & 1023u) >> 6, plx = (int)(rec & 63u), d = (int)((rec >> 10) & 3u);
     const uint32_t e = (rec >> 12) & 255u;
@@ -272,32 +283,25 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
     const int n = c + ddy * PT_LW + ddx;
     const uint32_t s0 = slab[c], s1 = slab[n];
-    const int v0 = (s0 >> 31) ? 255 : 0, v1 = (s1 >> 31) ? 255 : 0;
-    uint32_t slot, rk = 0;
+    uint32_t w = 0xFFFFFFFFu;   // entry 255 = "not here": k_scatter skips the word
     if (e != 255u) {
-      slot = tslot[e];
-      if (slot != AT_INVALID_SLOT) rk = tbase[e] + (rec >> 20);
-    } else {  // not counted in the block table: this point goes straight to the frame table
+      // value step v1 - v0 = +-255: bit 31 set when it is negative (v0 white)
+      w = e | ((rec >> 20) << 8) | ((rec & 1023u) << 19) | ((uint32_t)d << 29) | (s0 & 0x80000000u);
+    } else {  // not counted in the block table: this point goes straight to the frame table and to the long records
       const uint32_t r0 = s0 & AT_LABEL_MASK, r1 = s1 & AT_LABEL_MASK;
       const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
-      slot = hash_insert(hkeys, P.hcap, P.hshift, key);
+      const uint32_t slot = hash_insert(hkeys, P.hcap, P.hshift, key);
       if (slot == AT_INVALID_SLOT) atomicOr(&counters[frame].flags, 0x2u);
-      else rk = atomicAdd(&hcnt[slot], 1u);
-    }
-    if (pos < P.pcap) {
-      // written once, read once by k_scatter two kernels later, 3.5 GB per 256-frame step: non-temporal stores keep it out
-      // of the caches' way
-      const uint32_t pk = pack_point(2 * (X0 + plx) + ddx, 2 * (Y0 + ly) + ddy, ddx * (v1 - v0), ddy * (v1 - v0));
-      if (P.pack_stage) {
-        // slot (< 2^16) and rank in one word; a rank that does not fit belongs to a cluster too large to be kept, and
-        // 0xFFFFFFFF stays free for "no slot"
-        const uint32_t w0 = (slot == AT_INVALID_SLOT) ? 0xFFFFFFFFu : (slot | ((rk < 0xFFFEu ? rk : 0xFFFEu) << 16));
-        __builtin_nontemporal_store((unsigned long long)w0 | ((unsigned long long)pk << 32), reinterpret_cast<unsigned long long*>(stage + pos));
-      } else {
-        __builtin_nontemporal_store((unsigned long long)slot | ((unsigned long long)pk << 32), reinterpret_cast<unsigned long long*>(stage + pos));
-        __builtin_nontemporal_store(rk, rank + pos);
+      else {
+        const uint32_t rk = atomicAdd(&hcnt[slot], 1u);
+        const uint32_t li = atomicAdd(&counters[frame].nlong, 1u);
+        const int v0 = (s0 >> 31) ? 255 : 0, v1 = (s1 >> 31) ? 255 : 0;
+        if (li < P.lcap) long_all[(size_t)frame * P.lcap + li] = make_uint4(slot, rk, pack_point(2 * (X0 + plx) + ddx, 2 * (Y0 + ly) + ddy, ddx * (v1 - v0), ddy * (v1 - v0)), 0u);
+        else atomicOr(&counters[frame].flags, 0x1u);   // (the point buffers grow together)
       }
     }
+    // written once, read once by k_scatter two kernels later: non-temporal stores keep it out of the caches' way
+    if (pos < P.pcap) __builtin_nontemporal_store(w, stage + pos);
   };
   for (uint32_t q = tid; q < nlist; q += 256) emit(elist[q], base + q);
   if (off + cnt > PT_ELIST) {   // this thread's emissions beyond the list
@@ -417,21 +421,51 @@ __global__ __launch_bounds__(256) void k_worklist(const ClusterRec* __restrict__
   }
 }
 
-// one thread per staged point: final position = cluster range start + rank, no atomics
-__global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ stage_all, const uint32_t* __restrict__ rank_all,
+// One block per block of k_points (same tile): final position of a staged point = cluster range start (hoff of its pair's
+// slot) + the block's base rank inside the cluster + the point's rank inside the block's group; no atomics.  The packed
+// point is rebuilt from the tile origin, the pixel and the direction.  The blocks also share out the frame's long records.
+__global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ stage_all, const uint2* __restrict__ bhdr_all,
+                                                 const uint2* __restrict__ btab_all, const uint4* __restrict__ long_all,
                                                  const uint32_t* __restrict__ hoff_all, uint32_t* __restrict__ pts_all,
-                                                 const FrameCounters* __restrict__ counters, DetParams P) {
+                                                 const FrameCounters* __restrict__ counters, uint32_t gx_tiles, uint32_t gy_tiles,
+                                                 DetParams P) {
   const int frame = (int)blockIdx.z + P.frame0;
-  uint32_t n = counters[frame].npoints_raw;
-  if (n > P.pcap) n = P.pcap;
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const uint2 rec = stage_all[(size_t)frame * P.pcap + i];
-    if (rec.x == AT_INVALID_SLOT) continue;
-    uint32_t slot = rec.x, rk;
-    if (P.pack_stage) { slot = rec.x & 0xFFFFu; rk = rec.x >> 16; }
-    else rk = rank_all[(size_t)frame * P.pcap + i];
-    const uint32_t off = hoff_all[(size_t)frame * P.hcap + slot];
-    if (off == AT_INVALID_SLOT) continue;
-    pts_all[(size_t)frame * P.pcap + off + rk] = rec.y;
+  const uint32_t bpf = gx_tiles * gy_tiles, blk = blockIdx.x;
+  const uint32_t* hoff = hoff_all + (size_t)frame * P.hcap;
+  uint32_t* pts = pts_all + (size_t)frame * P.pcap;
+  const uint2 hdr = bhdr_all[(size_t)frame * bpf + blk];
+  const uint2* btab = btab_all + ((size_t)frame * bpf + blk) * PT_TB;
+  const uint32_t* stage = stage_all + (size_t)frame * P.pcap + hdr.x;
+  const int X0 = (int)(blk % gx_tiles) * PT_TW, Y0 = (int)(blk / gx_tiles) * PT_TH;
+  // Three dependent loads per record (staging word -> table entry -> range start).  A tile has a few records per thread:
+  // they are taken four at a time, level by level, so that the latencies of a thread's records overlap instead of adding up.
+  for (uint32_t i0 = threadIdx.x; i0 < hdr.y; i0 += 4 * 256) {
+    uint32_t w[4], off[4];
+    uint2 tb[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t i = i0 + (uint32_t)u * 256u;
+      w[u] = i < hdr.y ? __builtin_nontemporal_load(stage + i) : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) tb[u] = (w[u] & 255u) != 255u ? btab[w[u] & 255u] : make_uint2(AT_INVALID_SLOT, 0u);
+#pragma unroll
+    for (int u = 0; u < 4; u++) off[u] = tb[u].x != AT_INVALID_SLOT ? hoff[tb[u].x] : AT_INVALID_SLOT;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (off[u] == AT_INVALID_SLOT) continue;
+      const uint32_t pix = (w[u] >> 19) & 1023u;
+      const int ly = (int)(pix >> 6), plx = (int)(pix & 63u), d = (int)((w[u] >> 29) & 3u);
+      const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
+      const int step = (w[u] >> 31) ? -255 : 255;
+      pts[off[u] + tb[u].y + ((w[u] >> 8) & 2047u)] = pack_point(2 * (X0 + plx) + ddx, 2 * (Y0 + ly) + ddy, ddx * step, ddy * step);
+    }
+  }
+  uint32_t nl = counters[frame].nlong;
+  if (nl > P.lcap) nl = P.lcap;
+  for (uint32_t i = blk * 256 + threadIdx.x; i < nl; i += bpf * 256) {
+    const uint4 r = long_all[(size_t)frame * P.lcap + i];
+    const uint32_t off = hoff[r.x];
+    if (off != AT_INVALID_SLOT) pts[off + r.y] = r.z;
   }
 }
