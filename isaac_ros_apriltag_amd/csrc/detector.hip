@@ -749,13 +749,10 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
                        D->d_stage, D->d_bhdr, D->d_btab, D->d_long, D->d_counters, (D->fq_counters ? D->d_ptprof : nullptr), gxt, gyt, n, P);
   }
   mark();
-  hipLaunchKernelGGL(k_cluster_select, dim3((P.hcap + 1023) / 1024, 1, n), dim3(256), 0, s, D->d_hkeys, D->d_hcnt, D->d_hoff,
-                     D->d_clusters, D->d_counters, P);
   {
-    unsigned gw = (P.ccap + 255) / 256;
-    if (gw > 16) gw = 16;
-    hipLaunchKernelGGL(k_worklist, dim3(gw, 1, n), dim3(256), 0, s, D->d_clusters, D->d_counters, D->d_work, D->d_workctl,
-                       D->work_layout, P);
+    const int nchunks = n >= 16 ? SEL_CHUNKS : 1;   // (see the kernel)
+    hipLaunchKernelGGL(k_cluster_select, dim3((P.hcap + 1024 * nchunks - 1) / (1024 * nchunks), 1, n), dim3(256), 0, s, D->d_hkeys,
+                       D->d_hcnt, D->d_hoff, D->d_clusters, D->d_counters, D->d_work, D->d_workctl, D->work_layout, nchunks, P);
   }
   mark();
   {

@@ -318,108 +318,111 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
 #undef PT_TICK
 }
 
-// one thread per hash slot; 1024-thread blocks so that the two allocation counters see one atomic each
-// per block
-__global__ __launch_bounds__(256) void k_cluster_select(unsigned long long* __restrict__ hkeys_all,
-                                                        uint32_t* __restrict__ hcnt_all, uint32_t* __restrict__ hoff_all,
-                                                        ClusterRec* __restrict__ clusters_all,
-                                                        FrameCounters* __restrict__ counters, DetParams P) {
-  // 1024 table slots per block, four consecutive ones per thread (16-byte loads and stores; hcap is a power of two >= 256)
-  __shared__ uint32_t wsum[4], wcnt[4];
-  __shared__ uint32_t s_pbase, s_cbase;
-  const int frame = (int)blockIdx.z + P.frame0;
-  const uint32_t slot0 = blockIdx.x * 1024 + threadIdx.x * 4;
-  const bool in_range = slot0 < P.hcap;
-  const size_t hi = (size_t)frame * P.hcap + (in_range ? slot0 : 0);
-  // a slot holds a key exactly when its count is non-zero (every insert is followed by an add of at least one point),
-  // so the 8-byte keys of the ~95 % empty slots are never read
-  uint4 c4 = make_uint4(0, 0, 0, 0);
-  if (in_range) c4 = *reinterpret_cast<const uint4*>(hcnt_all + hi);
-  const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
-  if (c4.x | c4.y | c4.z | c4.w) *reinterpret_cast<uint4*>(hcnt_all + hi) = make_uint4(0, 0, 0, 0);
-  // a frame whose point staging overflowed has pair counts that exceed what was staged: it yields no
-  // clusters at all (the overflow bit is reported), never an out-of-range range
-  const bool frame_ok = (counters[frame].flags & 0x1u) == 0;
-  unsigned long long key[4];
-  bool keep[4];
-  uint32_t tsum = 0, tcnt = 0;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    key[j] = c[j] ? hkeys_all[hi + j] : AT_EMPTY_KEY;
-    if (c[j]) hkeys_all[hi + j] = AT_EMPTY_KEY;   // this kernel is the table's last reader: it leaves it empty for the next submission
-    keep[j] = frame_ok && key[j] != AT_EMPTY_KEY && (int)c[j] >= P.min_cluster_points && (int)c[j] <= P.max_cluster_points;
-    if (keep[j]) { tsum += c[j]; tcnt++; }
-  }
-  const uint32_t inc = wave_incl_scan(tsum), cinc = wave_incl_scan(tcnt);
-  const int lane = lane_id(), wv = threadIdx.x >> 6;
-  if (lane == 63) { wsum[wv] = inc; wcnt[wv] = cinc; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t ps = 0, cs = 0;
-    for (int w = 0; w < 4; w++) { const uint32_t a = wsum[w], b = wcnt[w]; wsum[w] = ps; wcnt[w] = cs; ps += a; cs += b; }
-    s_pbase = ps ? atomicAdd(&counters[frame].npoints_kept, ps) : 0;
-    s_cbase = cs ? atomicAdd(&counters[frame].nclusters, cs) : 0;
-  }
-  __syncthreads();
-  uint32_t off[4] = {AT_INVALID_SLOT, AT_INVALID_SLOT, AT_INVALID_SLOT, AT_INVALID_SLOT};
-  uint32_t po = s_pbase + wsum[wv] + inc - tsum, ci = s_cbase + wcnt[wv] + cinc - tcnt;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    if (!keep[j]) continue;
-    if (ci < P.ccap) {
-      off[j] = po;
-      ClusterRec rec;
-      rec.key = key[j]; rec.start = po; rec.count = c[j];
-      clusters_all[(size_t)frame * P.ccap + ci] = rec;
-    } else {
-      atomicOr(&counters[frame].flags, 0x4u);
-    }
-    po += c[j];
-    ci++;
-  }
-  if (in_range) *reinterpret_cast<uint4*>(hoff_all + hi) = make_uint4(off[0], off[1], off[2], off[3]);
-}
-
 // Work lists of the quad fit: the kept clusters of all frames of the submission, bucketed by size class
-// (class c holds lo[c] < count <= hi[c]).  An item is (frame << 16) | cluster index.  Appends are aggregated per
-// block in LDS, so every class counter sees one global atomic per block.
+// (class c holds lo[c] < count <= hi[c]).  An item is (frame << 16) | cluster index.  k_cluster_select appends them as it
+// creates the cluster records; appends are aggregated per block in LDS, so every class counter sees one global atomic per
+// block.  (A separate k_worklist pass over the records cost a launch and a round trip through them.)
 #define FQ_NCLS 5
 struct FqWorkLayout {
   int lo[FQ_NCLS], hi[FQ_NCLS];
   uint32_t off[FQ_NCLS], cap[FQ_NCLS];   // item range of class c inside the work array
 };
-__global__ __launch_bounds__(256) void k_worklist(const ClusterRec* __restrict__ clusters_all, FrameCounters* __restrict__ counters,
-                                                  uint32_t* __restrict__ work, uint32_t* __restrict__ work_n, FqWorkLayout L,
-                                                  DetParams P) {
-  __shared__ uint32_t s_cnt[FQ_NCLS], s_base[FQ_NCLS];
+
+// One thread per four pair-table slots, SEL_CHUNKS chunks of 1024 slots per block (`nchunks` of them used: a large submission
+// takes all four, so that the shared class counters of the work lists see a quarter of the blocks' atomics -- every
+// block of every frame adds to the same five words; a small one takes one chunk per block and keeps the frame's chunks
+// side by side).
+#define SEL_CHUNKS 4
+__global__ __launch_bounds__(256) void k_cluster_select(unsigned long long* __restrict__ hkeys_all,
+                                                        uint32_t* __restrict__ hcnt_all, uint32_t* __restrict__ hoff_all,
+                                                        ClusterRec* __restrict__ clusters_all,
+                                                        FrameCounters* __restrict__ counters, uint32_t* __restrict__ work,
+                                                        uint32_t* __restrict__ work_n, FqWorkLayout L, int nchunks, DetParams P) {
+  // 1024 table slots per chunk, four consecutive ones per thread (16-byte loads and stores; hcap is a power of two >= 256)
+  __shared__ uint32_t wsum[4], wcnt[4];
+  __shared__ uint32_t s_pbase, s_cbase;
+  __shared__ uint32_t s_wcnt[FQ_NCLS], s_wbase[FQ_NCLS];
+  if (threadIdx.x < FQ_NCLS) s_wcnt[threadIdx.x] = 0;   // (visible after the first scan's barrier below)
   const int frame = (int)blockIdx.z + P.frame0;
-  uint32_t ncl = counters[frame].nclusters;
-  if (ncl > P.ccap) ncl = P.ccap;
-  const int tid = threadIdx.x;
-  for (uint32_t base = blockIdx.x * 256; base < ncl; base += gridDim.x * 256) {
-    if (tid < FQ_NCLS) s_cnt[tid] = 0;
-    __syncthreads();
-    const uint32_t ci = base + tid;
-    int c = -1;
-    uint32_t rank = 0;
-    if (ci < ncl) {
-      const int count = (int)clusters_all[(size_t)frame * P.ccap + ci].count;
+  // a frame whose point staging overflowed has pair counts that exceed what was staged: it yields no
+  // clusters at all (the overflow bit is reported), never an out-of-range range
+  const bool frame_ok = (counters[frame].flags & 0x1u) == 0;
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  // work item of a kept cluster: size class, rank among the block's items of the class, cluster index
+  int wcls[SEL_CHUNKS][4];
+  uint32_t wrank[SEL_CHUNKS][4], wci[SEL_CHUNKS][4];
 #pragma unroll
-      for (int k = 0; k < FQ_NCLS; k++)
-        if (count > L.lo[k] && count <= L.hi[k]) c = k;
-      if (c >= 0) rank = atomicAdd(&s_cnt[c], 1u);
+  for (int ch = 0; ch < SEL_CHUNKS; ch++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) { wcls[ch][j] = -1; wrank[ch][j] = 0; wci[ch][j] = 0; }
+    if (ch >= nchunks) continue;   // (uniform)
+    if (ch) __syncthreads();       // the previous chunk's scan scratch has been read
+    const uint32_t slot0 = ((uint32_t)blockIdx.x * (uint32_t)nchunks + (uint32_t)ch) * 1024u + threadIdx.x * 4;
+    const bool in_range = slot0 < P.hcap;
+    const size_t hi = (size_t)frame * P.hcap + (in_range ? slot0 : 0);
+    // a slot holds a key exactly when its count is non-zero (every insert is followed by an add of at least one point),
+    // so the 8-byte keys of the ~95 % empty slots are never read
+    uint4 c4 = make_uint4(0, 0, 0, 0);
+    if (in_range) c4 = *reinterpret_cast<const uint4*>(hcnt_all + hi);
+    const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+    if (c4.x | c4.y | c4.z | c4.w) *reinterpret_cast<uint4*>(hcnt_all + hi) = make_uint4(0, 0, 0, 0);
+    unsigned long long key[4];
+    bool keep[4];
+    uint32_t tsum = 0, tcnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      key[j] = c[j] ? hkeys_all[hi + j] : AT_EMPTY_KEY;
+      if (c[j]) hkeys_all[hi + j] = AT_EMPTY_KEY;   // this kernel is the table's last reader: it leaves it empty for the next submission
+      keep[j] = frame_ok && key[j] != AT_EMPTY_KEY && (int)c[j] >= P.min_cluster_points && (int)c[j] <= P.max_cluster_points;
+      if (keep[j]) { tsum += c[j]; tcnt++; }
+    }
+    const uint32_t inc = wave_incl_scan(tsum), cinc = wave_incl_scan(tcnt);
+    if (lane == 63) { wsum[wv] = inc; wcnt[wv] = cinc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t ps = 0, cs = 0;
+      for (int w = 0; w < 4; w++) { const uint32_t a = wsum[w], b = wcnt[w]; wsum[w] = ps; wcnt[w] = cs; ps += a; cs += b; }
+      s_pbase = ps ? atomicAdd(&counters[frame].npoints_kept, ps) : 0;
+      s_cbase = cs ? atomicAdd(&counters[frame].nclusters, cs) : 0;
     }
     __syncthreads();
-    if (tid < FQ_NCLS) s_base[tid] = s_cnt[tid] ? atomicAdd(&work_n[tid], s_cnt[tid]) : 0u;
-    __syncthreads();
-    if (c >= 0) {
-      const uint32_t pos = s_base[c] + rank;
-      if (pos < L.cap[c]) work[L.off[c] + pos] = ((uint32_t)frame << 16) | ci;
+    uint32_t off[4] = {AT_INVALID_SLOT, AT_INVALID_SLOT, AT_INVALID_SLOT, AT_INVALID_SLOT};
+    uint32_t po = s_pbase + wsum[wv] + inc - tsum, ci = s_cbase + wcnt[wv] + cinc - tcnt;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (!keep[j]) continue;
+      if (ci < P.ccap) {
+        off[j] = po;
+        ClusterRec rec;
+        rec.key = key[j]; rec.start = po; rec.count = c[j];
+        clusters_all[(size_t)frame * P.ccap + ci] = rec;
+#pragma unroll
+        for (int k = 0; k < FQ_NCLS; k++)
+          if ((int)c[j] > L.lo[k] && (int)c[j] <= L.hi[k]) wcls[ch][j] = k;
+        if (wcls[ch][j] >= 0) { wrank[ch][j] = atomicAdd(&s_wcnt[wcls[ch][j]], 1u); wci[ch][j] = ci; }
+      } else {
+        atomicOr(&counters[frame].flags, 0x4u);
+      }
+      po += c[j];
+      ci++;
+    }
+    if (in_range) *reinterpret_cast<uint4*>(hoff_all + hi) = make_uint4(off[0], off[1], off[2], off[3]);
+  }
+  __syncthreads();
+  if (threadIdx.x < FQ_NCLS) s_wbase[threadIdx.x] = s_wcnt[threadIdx.x] ? atomicAdd(&work_n[threadIdx.x], s_wcnt[threadIdx.x]) : 0u;
+  __syncthreads();
+#pragma unroll
+  for (int ch = 0; ch < SEL_CHUNKS; ch++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (wcls[ch][j] < 0) continue;
+      const uint32_t pos = s_wbase[wcls[ch][j]] + wrank[ch][j];
+      if (pos < L.cap[wcls[ch][j]]) work[L.off[wcls[ch][j]] + pos] = ((uint32_t)frame << 16) | wci[ch][j];
       else atomicOr(&counters[frame].flags, 0x4u);
     }
-    __syncthreads();
   }
 }
+
 
 // One block per block of k_points (same tile): final position of a staged point = cluster range start (hoff of its pair's
 // slot) + the block's base rank inside the cluster + the point's rank inside the block's group; no atomics.  The packed

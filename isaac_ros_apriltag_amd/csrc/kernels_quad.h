@@ -2,7 +2,7 @@
 // src/apriltag_node.cpp:491-493).  One workgroup per cluster, five launch classes by cluster size
 // (one wave for <= 768 points ... 1024 threads above 8192) so that small clusters do not pay for idle
 // waves and the slope sort always runs in LDS (6 KB ... 145 KB of keys).  Every class is one launch of
-// PERSISTENT workgroups: k_worklist has bucketed the clusters of all frames of the submission into one
+// PERSISTENT workgroups: k_cluster_select has bucketed the clusters of all frames of the submission into one
 // compact work list per class, and a workgroup pops the next cluster with one atomic until its list is
 // empty -- no workgroup walks clusters of another class, and the cumulative-moment array of a cluster lives
 // in a scratch slot owned by the workgroup (reused cluster after cluster, so it stays cache-resident) instead
@@ -1618,21 +1618,13 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
     const int q_reversed = dot < 0;
     if (!P.reversed_border && q_reversed) reject = true;
     if (!P.normal_border && !q_reversed) reject = true;
-#if defined(AMDAT_PF_EXP) && AMDAT_PF_EXP == 1
-    if (false) {
-#else
     if (!reject && P.split_moments) {   // (the sector sums assume the fast path's coordinate range; larger images skip the test)
-#endif
       const float cx = (float)cxd, cy = (float)cyd;
       double a[7];
       int cur = -1;
       auto flush = [&]() {
-#if defined(AMDAT_PF_EXP) && AMDAT_PF_EXP == 2
-        if (a[0] == 1.2345) sB[0] = a[1] + a[2] + a[3] + a[4] + a[5] + a[6];
-#else
 #pragma unroll
         for (int j = 0; j < 7; j++) __hip_atomic_fetch_add(&sB[(cur + 1) * 7 + j], a[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
       };
       for (int base = 0; base < sz; base += FQ_PF_CHUNK) {
         if (base) __syncthreads();   // the previous round's points have been consumed
@@ -1655,14 +1647,12 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
           const uint32_t px = p >> 18, py = (p >> 4) & 0x3FFFu;
           const int ix = (int)((px + 1) >> 1), iy = (int)((py + 1) >> 1);
           GG[e] = 0;
-#if !(defined(AMDAT_PF_EXP) && AMDAT_PF_EXP == 3)
           if ((base + tid * 8 + e < sz) & ((unsigned)(ix - 1) < (unsigned)(W - 2)) & ((unsigned)(iy - 1) < (unsigned)(H - 2))) {
             const uint32_t o = (uint32_t)iy * (uint32_t)gpitch + (uint32_t)ix;
             const int g_r = ggray[o + 1], g_l = ggray[o - 1], g_d = ggray[o + (uint32_t)gpitch], g_u = ggray[o - (uint32_t)gpitch];
             const int grad_x = g_r - g_l, grad_y = g_d - g_u;
             GG[e] = (uint32_t)(grad_x * grad_x + grad_y * grad_y);
           }
-#endif
         }
 #pragma unroll
         for (int e = 0; e < 8; e++) {
