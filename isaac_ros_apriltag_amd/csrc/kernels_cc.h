@@ -35,11 +35,15 @@
 // and an address shift each -- no compare, no exec-mask bookkeeping; the divergent loop's scalar instructions were as many as
 // the kernel's vector instructions), the loop only finishes the rare longer chains.
 #ifndef CC_FIND_HOPS
-#define CC_FIND_HOPS 3
+#define CC_FIND_HOPS 2
 #endif
+#ifndef CC_FLATTEN_HOPS
+#define CC_FLATTEN_HOPS 4
+#endif
+template <int HOPS = CC_FIND_HOPS>
 __device__ __forceinline__ uint32_t lds_find(const uint32_t* L, uint32_t i) {
 #pragma unroll
-  for (int h = 0; h < CC_FIND_HOPS; h++) i = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (int h = 0; h < HOPS; h++) i = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   uint32_t p;
   while ((p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != i) i = p;
   return i;
@@ -121,11 +125,24 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   const int gx = X0 + lane;
   const bool src_ok = gx >= 1 && gx <= W - 2;  // this column may be a link source
 
+  // The lane's column of the wave's 16 rows stays in registers from here on, and so does the row above the strip; left and
+  // right neighbours come over the DPP network (wave_shr:1 / wave_shl:1), not from the byte array again -- the three passes
+  // below used to re-read it eight times per pixel.
+  uint32_t vv[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) vv[k] = st[(wv * 16 + k) * CC_T + lane];
+  const uint32_t vtop = wv > 0 ? (uint32_t)st[(wv * 16 - 1) * CC_T + lane] : 127u;
+#define CC_LEFT(x) ((uint32_t)__builtin_amdgcn_update_dpp(127, (int)(x), 0x138, 0xF, 0xF, false))    /* lane i <- lane i - 1 (lane 0: 127) */
+#define CC_RIGHT(x) ((uint32_t)__builtin_amdgcn_update_dpp(127, (int)(x), 0x130, 0xF, 0xF, false))   /* lane i <- lane i + 1 (lane 63: 127) */
   // ---- 1. run labelling per row (wave ballot, no atomics) -------------------------------------
+  uint32_t linkmask = 0;   // bit k: the pixel continues the run of its left neighbour
+#pragma unroll
   for (int k = 0; k < 16; k++) {
     const int r = wv * 16 + k;
-    const uint32_t v = st[r * CC_T + lane];
-    const bool link = lane > 0 && v != 127 && src_ok && st[r * CC_T + lane - 1] == v;
+    const uint32_t v = vv[k];
+    const uint32_t vleft = CC_LEFT(v);   // (in every lane: a DPP read from an inactive lane returns the fill value)
+    const bool link = lane > 0 && v != 127 && src_ok && vleft == v;
+    if (link) linkmask |= 1u << k;
     const unsigned long long L = __ballot(link);
     const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
     const unsigned long long m = ~L & below;  // run starts at or below this lane (lane 0 always set)
@@ -146,6 +163,7 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   {
     uint16_t* ureq = s_ureq + wv * CC_UREQ;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
     for (int k0 = 0; k0 < 16; k0 += CC_UROWS) {
       uint32_t nreq = 0;   // uniform
 #pragma unroll
@@ -153,19 +171,17 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
         const int r = wv * 16 + k0 + kk;
         bool up = false, upl = false, upr = false;
         const uint32_t me = (uint32_t)(r * CC_T + lane);
-        if (r > 0) {
-          const uint32_t v = st[r * CC_T + lane];
-          if (v != 127 && src_ok) {
-            const uint32_t vu = st[(r - 1) * CC_T + lane];
-            const uint32_t vl = lane > 0 ? st[r * CC_T + lane - 1] : 127;
-            const uint32_t vul = lane > 0 ? st[(r - 1) * CC_T + lane - 1] : 127;
+        {
+          const int k = k0 + kk;   // (compile-time after unrolling: the register rows are indexed statically)
+          const uint32_t v = vv[k], vu = k > 0 ? vv[k - 1] : vtop;
+          // (the DPP moves run in every lane, outside the conditions)
+          const uint32_t vl = CC_LEFT(v), vul = CC_LEFT(vu), vur = CC_RIGHT(vu), vr = CC_RIGHT(v);
+          if (r > 0 && v != 127 && src_ok) {
             const bool left_src = gx - 1 >= 1;  // (x-1) is itself a valid link source
             up = vu == v && !(lane > 0 && left_src && vl == v && vul == v);
             if (v == 255) {
               upl = lane > 0 && vul == 255 && vu != 255 && !(left_src && vl == 255);
               if (lane < 63) {
-                const uint32_t vur = st[(r - 1) * CC_T + lane + 1];
-                const uint32_t vr = st[r * CC_T + lane + 1];
                 const bool right_src = gx + 1 <= W - 2;
                 upr = vur == 255 && !(right_src && (vu == 255 || vr == 255));
               }
@@ -198,15 +214,16 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   for (int k = 0; k < 16; k++) {
     const int r = wv * 16 + k;
     const uint32_t l = sl[r * CC_T + lane];
-    root[k] = (l == AT_NO_LABEL) ? AT_NO_LABEL : lds_find(sl, (uint32_t)(r * CC_T + lane));
+    root[k] = (l == AT_NO_LABEL) ? AT_NO_LABEL : lds_find<CC_FLATTEN_HOPS>(sl, (uint32_t)(r * CC_T + lane));
   }
   __syncthreads();
   for (int k = 0; k < 16; k++) sl[(wv * 16 + k) * CC_T + lane] = 0;
   __syncthreads();
+#pragma unroll
   for (int k = 0; k < 16; k++) {
     const int r = wv * 16 + k;
-    const uint32_t v = st[r * CC_T + lane];
-    const bool link = lane > 0 && v != 127 && src_ok && st[r * CC_T + lane - 1] == v;
+    const uint32_t v = vv[k];
+    const bool link = (linkmask >> k) & 1u;
     const unsigned long long S = ~__ballot(link);  // run starts
     if (!link && v != 127) {
       const unsigned long long higher = (lane == 63) ? 0ull : (S & ~((2ull << lane) - 1ull));
