@@ -589,6 +589,78 @@ __device__ __forceinline__ void bitonic_sort_block2(KeyPtr A, int n, int lpow) {
   }
 }
 
+// ---- the same network for a cluster that fits the REGISTERS of one wave (64 K keys, K = 1, 2, 4) ---------------------------
+// The LDS passes above give every thread a group of eight keys, so a 128-key sort keeps 16 lanes of the wave busy and costs
+// as many instructions as a 512-key sort: the sort was a fixed ~780 wave-instructions per cluster of the one-wave class,
+// whose clusters mostly have 65 ... 256 points.  Here lane l holds keys l K ... l K + K - 1 for the whole sort: steps of
+// stride < K exchange registers, the others fetch the partner lane's key over the LDS crossbar (ds_bpermute, no memory)
+// and keep the minimum or the maximum by the lane's side of the exchange.  Same network, same +infinity pads, same result.
+__device__ __forceinline__ unsigned long long fq_fetch64(unsigned long long v, int byte_addr) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(uint32_t)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long fq_minmax64(unsigned long long mine, unsigned long long other, bool keep_min) {
+  const double a = __longlong_as_double((long long)mine), b = __longlong_as_double((long long)other);
+  double mn, mx;
+  asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(a), "v"(b));
+  asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(a), "v"(b));
+  return (unsigned long long)__double_as_longlong(keep_min ? mn : mx);
+}
+template <int K>
+__device__ __forceinline__ void fq_wave_sort(unsigned long long* A) {   // A: skewed LDS key array holding 64 K keys (pads included)
+  constexpr int LK = K == 1 ? 0 : K == 2 ? 1 : K == 4 ? 2 : 3;
+  const int lane = lane_id();
+  unsigned long long v[K];
+#pragma unroll
+  for (int j = 0; j < K; j++) v[j] = A[FQ_KP(lane * K + j)];
+  auto ce = [](unsigned long long& lo, unsigned long long& hi) {
+    const double a = __longlong_as_double((long long)lo), b = __longlong_as_double((long long)hi);
+    double mn, mx;
+    asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(a), "v"(b));
+    lo = (unsigned long long)__double_as_longlong(mn);
+    hi = (unsigned long long)__double_as_longlong(mx);
+  };
+#pragma unroll
+  for (int lk = 1; lk <= LK + 6; lk++) {
+    // flip inside blocks of 2^lk: index i meets i ^ (2^lk - 1)
+    if ((1 << lk) <= K) {
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        const int j2 = j ^ ((1 << lk) - 1);
+        if (j < j2) ce(v[j], v[j2]);
+      }
+    } else {
+      const int lx = (1 << (lk - LK)) - 1;                      // partner lane = lane ^ lx, partner register = K - 1 - j
+      const bool keep_min = (lane & (1 << (lk - LK - 1))) == 0;  // the lower of the two lanes
+      const int addr = (lane ^ lx) << 2;
+      unsigned long long o[K];
+#pragma unroll
+      for (int j = 0; j < K; j++) o[j] = fq_fetch64(v[K - 1 - j], addr);
+#pragma unroll
+      for (int j = 0; j < K; j++) v[j] = fq_minmax64(v[j], o[j], keep_min);
+    }
+    // half-cleaners of stride 2^(lk-2) ... 1
+#pragma unroll
+    for (int S = (1 << lk) >> 2; S >= 1; S >>= 1) {
+      if (S < K) {
+#pragma unroll
+        for (int j = 0; j < K; j++)
+          if ((j & S) == 0) ce(v[j], v[j + S]);
+      } else {
+        const int lx = S / K;
+        const bool keep_min = (lane & lx) == 0;
+        const int addr = (lane ^ lx) << 2;
+#pragma unroll
+        for (int j = 0; j < K; j++) v[j] = fq_minmax64(v[j], fq_fetch64(v[j], addr), keep_min);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < K; j++) A[FQ_KP(lane * K + j)] = v[j];
+}
+
 // lexicographic list of the 4-subsets of {0..9}: entry t = {m0,m1,m2,m3} packed 4 bits each, built at
 // compile time (computing it in the kernel prologue cost ~2600 instructions per workgroup)
 struct ComboTable { uint16_t v[210]; };
@@ -834,7 +906,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       if (in_lds) skeys[FQ_KP(i)] = key; else gkeys[i] = key;
       }
     }
-    int lpow = 0;
+    int lpow = NT == 64 ? 6 : 0;   // (the one-wave class sorts at least 64 keys: one per lane of the register sort)
     while ((1 << lpow) < sz) lpow++;
     // when the LDS array holds the next power of two, the tail is filled with +infinity keys and the network runs
     // without per-element bounds tests
@@ -905,7 +977,14 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       if (!feas_pre) { FQ_COUNT(1, sz) continue; }
     }
 #endif
-    if (padded) bitonic_sort_block2<NT, true, true>(skeys, sz, lpow);
+    // (a wave's own LDS accesses are ordered: the one-wave class needs no barrier around the register sort)
+#ifndef FQ_REGSORT_MAX_LPOW
+#define FQ_REGSORT_MAX_LPOW 8
+#endif
+    if (NT == 64 && padded && lpow <= FQ_REGSORT_MAX_LPOW) {
+      if (lpow <= 6) fq_wave_sort<1>(skeys); else if (lpow == 7) fq_wave_sort<2>(skeys); else fq_wave_sort<4>(skeys);
+    }
+    else if (padded) bitonic_sort_block2<NT, true, true>(skeys, sz, lpow);
     else if (in_lds) bitonic_sort_block2<NT, false, true>(skeys, sz, lpow);
     else bitonic_sort_block2<NT, false, false>(gkeys, sz, lpow);
     FQ_TICK(2)

@@ -5,7 +5,7 @@ VS=$1; N=${2:-6}
 for i in $(seq $N); do
   for v in $VS; do
     L=$v; [ "$v" = "default" ] && L=""
-    AMDAT_LIB=$L timeout 120 python tools/pipeline_once.py 256 4 16 2>&1 | grep "stages" | python -c "
+    AMDAT_LIB=$L timeout 120 python tools/pipeline_once.py 256 3 64 2>&1 | grep "stages" | python -c "
 import sys, ast
 l = sys.stdin.read()
 d = ast.literal_eval(l[l.index('{'):])
