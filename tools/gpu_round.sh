@@ -28,7 +28,7 @@ if [ "$2" != "noprof" ]; then
   cat $OUT/fit_timeline.txt | tee -a $OUT/summary.txt
   find $OUT/trace -name "*.db" -delete
   echo "== PMC passes (B=32)" | tee -a $OUT/summary.txt
-  bash tools/pmc_round.sh $TAG/pmc "k_fit k_quad k_cc_ k_points k_scatter k_cluster_select k_worklist k_decode k_threshold" > /dev/null 2>&1
+  bash tools/pmc_round.sh $TAG/pmc "k_fit k_quad k_cc_ k_points k_scatter k_cluster_select k_decode k_reconcile k_prologue k_threshold" > /dev/null 2>&1
   cat $OUT/pmc/pmc_summary.md | cut -c1-260 | tee -a $OUT/summary.txt
   echo "== threshold PMC (160 frames per launch)" | tee -a $OUT/summary.txt
   bash tools/thr_pmc.sh $TAG/thrpmc 2>&1 | tee -a $OUT/summary.txt

@@ -2,7 +2,7 @@
 Usage: python tools/pmc_summary.py <dir-or-db> [substring ...]"""
 import collections, glob, os, sqlite3, sys
 path = sys.argv[1]
-pats = sys.argv[2:] or ["k_fit_quads", "k_cc_", "k_points", "k_scatter", "k_cluster_select", "k_worklist", "k_decode", "k_threshold"]
+pats = sys.argv[2:] or ["k_fit_quads", "k_cc_", "k_points", "k_scatter", "k_cluster_select", "k_decode", "k_threshold"]
 dbs = [path] if path.endswith(".db") else sorted(glob.glob(os.path.join(path, "**", "*.db"), recursive=True))
 acc = collections.defaultdict(list)
 dur = collections.defaultdict(list)
