@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
                                                 FrameCounters* __restrict__ counters,
                                                 unsigned long long* __restrict__ prof, uint32_t gx_tiles, uint32_t gy_tiles, uint32_t nframes,
                                                 DetParams P) {
-#ifdef AMDAT_FQ_PROFILE   // tools-only: shader cycles per phase, prof[0..5] (tile load, emission tests + scan, list, block table, frame table, stores)
+#ifdef AMDAT_FQ_PROFILE   // tools-only: shader cycles per phase, prof[0..5] (tile load, emission tests + scan, list, block table, stores, frame table)
 #define PT_TICK(slot) if (prof && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&prof[slot], now_ - t_prev_); t_prev_ = now_; }
   unsigned long long t_prev_ = prof ? __builtin_readcyclecounter() : 0ull;
 #else
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   __shared__ uint32_t sscan[4];
   __shared__ uint32_t sbase;
   __shared__ unsigned long long tkey[PT_TB];
-  __shared__ uint32_t tcnt[PT_TB], tslot[PT_TB], tbase[PT_TB];
+  __shared__ uint32_t tcnt[PT_TB];
   __shared__ uint32_t elist[PT_ELIST];
 #ifndef PT_ILEAVE
 #define PT_ILEAVE 256
@@ -247,22 +247,6 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
 #if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 3
   if (P.max_nmaxima == 10) { stage_all[(size_t)frame * P.pcap + (blk_ % 64u) * 256 + tid] = emask ^ off ^ elist[tid] ^ sbase; return; }
 #endif
-  {
-    // one global insert + one global add per distinct pair of this block; the add's return value is the base rank of
-    // the block's points inside the cluster
-    const unsigned long long key = tkey[tid];
-    if (key != AT_EMPTY_KEY) {
-      const uint32_t slot = hash_insert(hkeys, P.hcap, P.hshift, key);
-      uint32_t base = 0;
-      if (slot != AT_INVALID_SLOT) base = atomicAdd(&hcnt[slot], tcnt[tid]);
-      else atomicOr(&counters[frame].flags, 0x2u);
-      tslot[tid] = slot;
-      tbase[tid] = base;
-      btab_all[((size_t)frame * bpf + blk_) * PT_TB + tid] = make_uint2(slot, base);   // (only used entries are ever written or read)
-    }
-  }
-  __syncthreads();
-  PT_TICK(4)
   const uint32_t base = sbase;
   if (base + total > P.pcap) {
     if (tid == 0) atomicOr(&counters[frame].flags, 0x1u);
@@ -312,6 +296,22 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
       if (q >= PT_ELIST)
         emit((uint32_t)(((tid >> 6) + 4 * (sidx >> 2)) * 64 + lx) | ((uint32_t)(sidx & 3) << 10) | (255u << 12), base + q);
       q++;
+    }
+  }
+  PT_TICK(4)
+  {
+    // LAST, with nothing waiting for it: one global insert + one global add per distinct pair of this block; the add's
+    // return value is the base rank of the block's points inside the cluster.  Slot and base go straight to the block's
+    // table for k_scatter -- the staging words above do not depend on them, so the two or three dependent L2 round trips
+    // of this phase no longer stand between the block's other waves and their stores (it used to sit before pass 3,
+    // behind a barrier: 0.8 ms of the kernel).
+    const unsigned long long key = tkey[tid];
+    if (key != AT_EMPTY_KEY) {
+      const uint32_t slot = hash_insert(hkeys, P.hcap, P.hshift, key);
+      uint32_t kbase = 0;
+      if (slot != AT_INVALID_SLOT) kbase = atomicAdd(&hcnt[slot], tcnt[tid]);
+      else atomicOr(&counters[frame].flags, 0x2u);
+      btab_all[((size_t)frame * bpf + blk_) * PT_TB + tid] = make_uint2(slot, kbase);   // (only used entries are ever written or read)
     }
   }
   PT_TICK(5)
