@@ -92,10 +92,13 @@ __device__ __forceinline__ void glb_union(uint32_t* L, uint32_t a, uint32_t b) {
 __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ thr_all, uint32_t* __restrict__ label_all,
                                                   uint32_t* __restrict__ csize_all, uint32_t* __restrict__ roots_all,
                                                   FrameCounters* __restrict__ counters, DetParams P) {
-  __shared__ __attribute__((aligned(16))) uint8_t st[CC_T * CC_T];
+  // (the threshold tile is only read into registers right after the load; the link-request lists of the union pass take
+  // over its space -- a barrier lies between -- which brings the block from 26.6 to 22.6 KB of LDS: 7 blocks per CU, not 6)
+  __shared__ __attribute__((aligned(16))) uint8_t s_tile_or_requests[(CC_T * CC_T > 4 * CC_UREQ * 2) ? CC_T * CC_T : 4 * CC_UREQ * 2];
+  uint8_t* const st = s_tile_or_requests;
+  uint16_t* const s_ureq = reinterpret_cast<uint16_t*>(s_tile_or_requests);
   __shared__ uint32_t sl[CC_T * CC_T];
   __shared__ uint32_t s_nroots, s_rbase;
-  __shared__ uint16_t s_ureq[4 * CC_UREQ];
   const int frame = (int)blockIdx.z + P.frame0;
   const int X0 = blockIdx.x * CC_T, Y0 = blockIdx.y * CC_T;
   const int W = P.W, H = P.H;
