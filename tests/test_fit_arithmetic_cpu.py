@@ -1,4 +1,4 @@
-"""Host-side checks of two pieces of index / floating-point algebra the quad-fit kernel relies on
+"""Host-side checks of the index and floating-point algebra the kernels rely on (sqrt of the line-fit weights, skewed key array, frame-interleaved block order, one-word staging record, register sort network)
 (isaac_ros_apriltag_amd/csrc/kernels_quad.h, common.h); the device versions are exercised by tests/test_gpu_parity.py."""
 import os
 import subprocess
@@ -65,3 +65,111 @@ def test_skew_spreads_every_lane_stride_over_the_banks():
         for k in range(E):
             banks = {_kp(E * t + k) % 32 for t in range(32)}
             assert len(banks) >= 23, (E, k, len(banks))
+
+
+# ---- host models of this round's index algebra (device versions: tests/test_gpu_parity.py, tools/fuzz_gpu.py) -------------
+def _frame_block(lin, bpf, n, G):
+    """at_frame_block (csrc/common.h): block -> (frame, block of the frame), the frames of a group of G taking turns."""
+    if G <= 1:
+        return lin // bpf, lin % bpf
+    ngroups = (n + G - 1) // G
+    group = min(lin // (bpf * G), ngroups - 1)
+    rem = lin - group * bpf * G
+    gsize = n - group * G if group == ngroups - 1 else G
+    blk = rem // gsize
+    return group * G + (rem - blk * gsize), blk
+
+
+@pytest.mark.parametrize("bpf,n,G", [(1, 1, 256), (7, 1, 256), (5, 3, 2), (510, 8, 256), (13, 20, 16), (3, 33, 16), (2040, 5, 4),
+                                     (9, 256, 256), (4, 17, 1), (6, 300, 256)])
+def test_frame_interleaved_block_order_is_a_bijection(bpf, n, G):
+    """Every (frame, block) pair is produced exactly once by the 1-D grid of bpf * n blocks, whatever the group size -- also
+    when the last group is short -- and inside a full group consecutive blocks belong to different frames."""
+    seen = set()
+    for lin in range(bpf * n):
+        f, b = _frame_block(lin, bpf, n, G)
+        assert 0 <= f < n and 0 <= b < bpf
+        seen.add((f, b))
+    assert len(seen) == bpf * n
+    if G > 1 and n >= 2:
+        g = min(G, n)
+        assert len({_frame_block(lin, bpf, n, G)[0] for lin in range(g)}) == g   # the first g blocks: g different frames
+
+
+def _pack_point(x, y, gx, gy):
+    return (x << 18) | (y << 4) | ((gx // 255 + 1) << 2) | (gy // 255 + 1)
+
+
+def test_staging_word_round_trip():
+    """k_points stages ONE word per boundary point -- table entry (8 bits) | rank in the block's group (11) | pixel of the
+    64 x 16 tile (10) | direction (2) | sign of the value step (1) -- and k_scatter rebuilds the packed point from the tile
+    origin: the rebuilt point equals the one the old 8-byte record carried, for every field combination that can occur."""
+    import random
+    rng = random.Random(3)
+    for _ in range(20000):
+        e, rk, pix, d, neg = rng.randrange(255), rng.randrange(2048), rng.randrange(1024), rng.randrange(4), rng.randrange(2)
+        X0, Y0 = 64 * rng.randrange(60), 16 * rng.randrange(135)
+        w = e | (rk << 8) | (pix << 19) | (d << 29) | (neg << 31)
+        assert w != 0xFFFFFFFF and (w & 255) != 255
+        # k_scatter's decode
+        e2, rk2, pix2, d2 = w & 255, (w >> 8) & 2047, (w >> 19) & 1023, (w >> 29) & 3
+        assert (e2, rk2, pix2, d2, w >> 31) == (e, rk, pix, d, neg)
+        ly, plx = pix2 >> 6, pix2 & 63
+        ddx = -1 if d2 == 2 else (0 if d2 == 1 else 1)
+        ddy = 0 if d2 == 0 else 1
+        step = -255 if (w >> 31) else 255
+        rebuilt = _pack_point(2 * (X0 + plx) + ddx, 2 * (Y0 + ly) + ddy, ddx * step, ddy * step)
+        # k_points' emit with the pixel values: v0 white <=> step negative
+        v0, v1 = (255, 0) if neg else (0, 255)
+        direct = _pack_point(2 * (X0 + plx) + ddx, 2 * (Y0 + ly) + ddy, ddx * (v1 - v0), ddy * (v1 - v0))
+        assert rebuilt == direct
+
+
+@pytest.mark.parametrize("K", [1, 2, 4])
+def test_register_sort_network_sorts(K):
+    """fq_wave_sort<K> (kernels_quad.h): lane l holds keys l K .. l K + K - 1; flips meet index i with i ^ (2^lk - 1) -- across
+    lanes that is lane ^ (2^lk / K - 1), register K - 1 - j -- half-cleaners meet i with i ^ S; the lower lane of an exchange
+    keeps the minimum.  The model runs the same steps on random keys (with +infinity pads) and must leave them sorted."""
+    import random
+    rng = random.Random(K)
+    LK = {1: 0, 2: 1, 4: 2}[K]
+    for trial in range(40):
+        n = 64 * K
+        real = rng.randrange(1, n + 1)
+        keys = [rng.randrange(1 << 20) for _ in range(real)] + [float("inf")] * (n - real)
+        v = [[keys[l * K + j] for j in range(K)] for l in range(64)]
+        for lk in range(1, LK + 7):
+            if (1 << lk) <= K:
+                for l in range(64):
+                    for j in range(K):
+                        j2 = j ^ ((1 << lk) - 1)
+                        if j < j2:
+                            a, b = v[l][j], v[l][j2]
+                            v[l][j], v[l][j2] = min(a, b), max(a, b)
+            else:
+                lx = (1 << (lk - LK)) - 1
+                old = [row[:] for row in v]
+                for l in range(64):
+                    keep_min = (l & (1 << (lk - LK - 1))) == 0
+                    for j in range(K):
+                        o = old[l ^ lx][K - 1 - j]
+                        v[l][j] = min(old[l][j], o) if keep_min else max(old[l][j], o)
+            S = (1 << lk) >> 2
+            while S >= 1:
+                if S < K:
+                    for l in range(64):
+                        for j in range(K):
+                            if (j & S) == 0:
+                                a, b = v[l][j], v[l][j + S]
+                                v[l][j], v[l][j + S] = min(a, b), max(a, b)
+                else:
+                    lx = S // K
+                    old = [row[:] for row in v]
+                    for l in range(64):
+                        keep_min = (l & lx) == 0
+                        for j in range(K):
+                            o = old[l ^ lx][j]
+                            v[l][j] = min(old[l][j], o) if keep_min else max(old[l][j], o)
+                S >>= 1
+        flat = [v[l][j] for l in range(64) for j in range(K)]
+        assert flat == sorted(keys)
