@@ -92,9 +92,35 @@ def build_host(force=False):
     return HOST_BIN
 
 
+LIB_STRESS = os.path.join(_HERE, "libapriltag_amd_stress.so")
+
+
+def build_stress(force=False):
+    """Stress build for the GPU suite (tests/test_gpu_parity.py::test_long_staging_records...): a 64 x 16 tile's emission list
+    is cut to 768 entries, so that on ordinary frames a good share of the boundary points takes the long-record path that the
+    product build only enters above two emissions per pixel of a tile.  Never loaded by the product path."""
+    if force or _newer(LIB_STRESS, [os.path.join(_CSRC, "detector.hip")] + _sources(".h")):
+        build_amd_variant("stress", ["PT_ELIST=768", "AMDAT_LCAP_DIV=1"])
+    return LIB_STRESS
+
+
 def build_all(force=False):
+    import threading
     build_synth(force)
+    err = []
+
+    def _stress():
+        try:
+            build_stress(force)
+        except (subprocess.CalledProcessError, OSError) as e:   # only its test needs it
+            err.append(e)
+    t = threading.Thread(target=_stress)
+    t.start()                      # (next to the product library: two hipcc runs of the same translation unit)
     build_amd(force)
+    t.join()
+    if err:
+        import sys
+        sys.stderr.write("isaac_ros_apriltag_amd.build: stress variant not built (%s); only its test needs it\n" % (err[0],))
     build_node(force)
     try:   # the multi-GPU example links RCCL; a machine without it still gets the product libraries
         build_host(force)

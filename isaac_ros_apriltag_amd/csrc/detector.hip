@@ -391,7 +391,13 @@ static int alloc_point_buffers(amdAprilTagsDetector_st* D) {
     D->work_layout.cap[k] = (uint32_t)cap;
     off += cap;
   }
-  P.lcap = P.pcap / 8 > 4096u ? P.pcap / 8 : 4096u;
+  // Long staging records (kernels_cluster.h) only occur where a 64 x 16 tile has more than 2048 emissions -- above two per pixel --
+  // or more than 255 component pairs; an eighth of the point capacity is room for them (an overflow reports like a point
+  // overflow and grows with the point buffers).  Tools builds that shrink the tile's list take the whole capacity.
+#ifndef AMDAT_LCAP_DIV
+#define AMDAT_LCAP_DIV 8
+#endif
+  P.lcap = P.pcap / AMDAT_LCAP_DIV > 4096u ? P.pcap / AMDAT_LCAP_DIV : 4096u;
   void** bufs[5] = {(void**)&D->d_stage, (void**)&D->d_long, (void**)&D->d_pts, (void**)&D->d_work, (void**)&D->d_work2};
   const size_t bytes[5] = {B * (size_t)P.pcap * 4, B * (size_t)P.lcap * 16, B * (size_t)P.pcap * 4, (size_t)off * 4,
                            ((size_t)off - D->work_layout.off[D->prefilter_class]) * 4};

@@ -41,7 +41,10 @@ __device__ __forceinline__ uint32_t hash_insert(unsigned long long* hkeys, uint3
 }
 
 #define PT_TB 256  // entries of the per-block component-pair table
-#define PT_ELIST 2048   // emissions of one tile kept in the LDS list of pass 2 (the tile has 1024 pixels)
+#ifndef PT_ELIST
+#define PT_ELIST 2048   // emissions of one tile kept in the LDS list of pass 2 (the tile has 1024 pixels; tools builds shrink it
+                        // to drive the long-record path of the emissions beyond the list)
+#endif
 
 // per-block table in LDS: returns entry index or -1 when full
 // (slot = top byte of a 32-bit multiplicative hash of the two labels: two quarter-rate multiplies instead of the four

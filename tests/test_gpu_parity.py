@@ -855,3 +855,26 @@ def test_pair_table_grows_with_the_content(built):
     fixed.detect_batch_ex(t, max_dets=64)
     assert fixed.frame_flags(1)[0] & 2
     fixed.close()
+
+
+@pytest.mark.gpu
+def test_long_staging_records_with_a_short_tile_list(built):
+    """k_points stages one word per boundary point through its tile's pair table; the emissions that have no table entry --
+    beyond the tile's 2048-entry list (more than two per pixel), or a 256th component pair -- take their slot and rank from
+    the frame table one by one and travel as long records (kernels_cluster.h).  Ordinary content never gets there, so the
+    suite runs the stage-by-stage checks and a slice of the fuzzer against libapriltag_amd_stress.so, the same sources with
+    the list cut to 768 entries: on the noisy 1080p frames every other tile overflows it.  (Own processes: the library is
+    chosen when isaac_ros_apriltag_amd.capi is first used.)"""
+    import subprocess
+    import sys
+    from isaac_ros_apriltag_amd import build as bld
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(bld.LIB_STRESS):
+        bld.build_stress()
+    env = dict(os.environ, AMDAT_LIB="stress")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_check.py")], capture_output=True, text=True, timeout=900,
+                         cwd=root, env=env)
+    assert out.returncode == 0 and "ALL OK" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "--cases", "200", "--seed", "4242"],
+                         capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0 and "200 cases, 0 failed" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])

@@ -17,7 +17,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 import torch  # noqa: E402
 
-from isaac_ros_apriltag_amd import synth  # noqa: E402
+from isaac_ros_apriltag_amd import capi, synth  # noqa: E402
+if os.environ.get("AMDAT_LIB"):   # measurement / stress variant (isaac_ros_apriltag_amd.build.build_amd_variant)
+    capi.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "isaac_ros_apriltag_amd", "libapriltag_amd_%s.so" % os.environ["AMDAT_LIB"])
 from isaac_ros_apriltag_amd.detector import AprilTagDetector  # noqa: E402
 import parity_util as pu  # noqa: E402
 
