@@ -1308,6 +1308,12 @@ int amdAprilTagsDebugCopy(amdAprilTagsHandle handle, uint32_t frame, amdAprilTag
 
 #ifdef AMDAT_FQ_TIMELINE
 // tools-only: returns and clears the quad fit's per-cluster wall-clock log (start tick, duration << 32 | threads << 20 | points)
+extern "C" int amdAprilTagsDebugTimelinePhases(unsigned int* out, unsigned int n) {   // call BEFORE amdAprilTagsDebugTimeline (which clears the log)
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (n > (1u << 16)) n = 1u << 16;
+  if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fq_ph), (size_t)n * 32) != hipSuccess) return -1;
+  return (int)n;
+}
 extern "C" int amdAprilTagsDebugTimeline(unsigned long long* out, unsigned int cap) {
   unsigned int n = 0;
   if (hipDeviceSynchronize() != hipSuccess) return -1;

@@ -225,26 +225,9 @@ __device__ __forceinline__ double div_by(double n, double d, double r) {
   return __builtin_fma(e, r, q);
 }
 
-// Line fit over the cumulative moments lf[i*6 + {Mx,My,Mxx,Mxy,Myy,W}] of points i0..i1 (circular).
-__device__ __forceinline__ void fit_line_dev(const double* lf, int sz, int i0, int i1, double* lineparm, double* err,
-                                             double* mse) {
-  double Mx, My, Mxx, Mxy, Myy, W;
-  int N;
-  const double* b = lf + (size_t)i1 * 6;
-  if (i0 < i1) {
-    N = i1 - i0 + 1;
-    Mx = b[0]; My = b[1]; Mxx = b[2]; Mxy = b[3]; Myy = b[4]; W = b[5];
-    if (i0 > 0) {
-      const double* a = lf + (size_t)(i0 - 1) * 6;
-      Mx -= a[0]; My -= a[1]; Mxx -= a[2]; Mxy -= a[3]; Myy -= a[4]; W -= a[5];
-    }
-  } else {
-    const double* e = lf + (size_t)(sz - 1) * 6;
-    const double* a = lf + (size_t)(i0 - 1) * 6;
-    Mx = e[0] - a[0]; My = e[1] - a[1]; Mxx = e[2] - a[2]; Mxy = e[3] - a[3]; Myy = e[4] - a[4]; W = e[5] - a[5];
-    Mx += b[0]; My += b[1]; Mxx += b[2]; Mxy += b[3]; Myy += b[4]; W += b[5];
-    N = sz - i0 + i1 + 1;
-  }
+// Line parameters and errors from the moments of a run of points (the second half of every line fit).
+__device__ __forceinline__ void fit_line_moments(double Mx, double My, double Mxx, double Mxy, double Myy, double W, int N,
+                                                 double* lineparm, double* err, double* mse) {
   // Five IEEE divisions by the same W share one reciprocal refinement (shared_recip / div_by)
   const double rW = shared_recip(W);
   auto divW = [W, rW](double n) { return div_by(n, W, rW); };
@@ -268,6 +251,30 @@ __device__ __forceinline__ void fit_line_dev(const double* lf, int sz, int i0, i
   if (err) *err = N * eig_small;
   if (mse) *mse = eig_small;
 }
+
+// Line fit over the cumulative moments lf[i*6 + {Mx,My,Mxx,Mxy,Myy,W}] of points i0..i1 (circular).
+__device__ __forceinline__ void fit_line_dev(const double* lf, int sz, int i0, int i1, double* lineparm, double* err,
+                                             double* mse) {
+  double Mx, My, Mxx, Mxy, Myy, W;
+  int N;
+  const double* b = lf + (size_t)i1 * 6;
+  if (i0 < i1) {
+    N = i1 - i0 + 1;
+    Mx = b[0]; My = b[1]; Mxx = b[2]; Mxy = b[3]; Myy = b[4]; W = b[5];
+    if (i0 > 0) {
+      const double* a = lf + (size_t)(i0 - 1) * 6;
+      Mx -= a[0]; My -= a[1]; Mxx -= a[2]; Mxy -= a[3]; Myy -= a[4]; W -= a[5];
+    }
+  } else {
+    const double* e = lf + (size_t)(sz - 1) * 6;
+    const double* a = lf + (size_t)(i0 - 1) * 6;
+    Mx = e[0] - a[0]; My = e[1] - a[1]; Mxx = e[2] - a[2]; Mxy = e[3] - a[3]; Myy = e[4] - a[4]; W = e[5] - a[5];
+    Mx += b[0]; My += b[1]; Mxx += b[2]; Mxy += b[3]; Myy += b[4]; W += b[5];
+    N = sz - i0 + i1 + 1;
+  }
+  fit_line_moments(Mx, My, Mxx, Mxy, Myy, W, N, lineparm, err, mse);
+}
+
 
 // ---- sound early exit before the second walk of the moment sweep ----------------------------------------------------
 // A quad needs four corner indices i0 < i1 < i2 < i3 of the sorted, duplicate-free point sequence such that each of
@@ -690,6 +697,7 @@ __device__ const PairTable g_pair_table = make_pair_table();
 // launch; those above sort_cap (only possible in the last class) sort in global scratch.
 #ifdef AMDAT_FQ_TIMELINE   // tools-only: wall-clock interval of every cluster a workgroup processes (tools/fit_timeline_one.py)
 __device__ unsigned long long g_fq_tl[1 << 16][2];
+__device__ unsigned int g_fq_ph[1 << 16][8];   // wall-clock ticks (10 ns) per phase of the same cluster (the FQ_TICK slots)
 __device__ unsigned int g_fq_tl_n;
 #endif
 template <int NT, bool SPLIT>
@@ -699,8 +707,8 @@ template <int NT, bool SPLIT>
 #define FQ_SEL_REGS 8          // maxima candidates per lane held in registers during the top-10 selection
 #define FQ_SMOOTH_REGS_OF(NT) ((NT) >= 1024 ? 8 : 16)   // smoothed errors per thread kept in registers (clusters up to that many x threads)
 #define FQ_TABLE_DOUBLES ((FQ_XG + 1) * 7)   // prefixes over FQ_XG groups, up to seven sums each
-// bytes of the key array region: the skewed keys, and at least the twelve pair tables that take the region over later
-#define FQ_KEY_BYTES(sort_cap) ((size_t)FQ_KP(sort_cap) * 8 > (size_t)(12 * 45 * 8) ? (size_t)FQ_KP(sort_cap) * 8 : (size_t)(12 * 45 * 8))
+// bytes of the key array region: the skewed keys, and at least the twelve pair tables + the 21 staged prefix rows that take the region over later
+#define FQ_KEY_BYTES(sort_cap) ((size_t)FQ_KP(sort_cap) * 8 > (size_t)((12 * 45 + 21 * 6) * 8) ? (size_t)FQ_KP(sort_cap) * 8 : (size_t)((12 * 45 + 21 * 6) * 8))
 #define FQ_PIDX(a, b) ((((a) * (19 - (a))) >> 1) + (b) - (a) - 1)   // a < b < 10 -> 0..44
 #ifndef FQ_WPE_64
 #define FQ_WPE_64 4
@@ -776,6 +784,10 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
   // points of the clusters that reach the pre-sort test (0), that it rejects (1), that the test after the first walk
   // rejects (2): prof[40 + 4 * class + k] (the launch passes prof + 8 * class)
 #define FQ_COUNT(k, n) if (prof && tid == 0) atomicAdd(&prof[40 - 4 * ((NT == 64) ? 0 : (NT == 128) ? 1 : (NT == 256) ? 2 : (NT == 512) ? 3 : 4) + (k)], (unsigned long long)(n));
+#elif defined(AMDAT_FQ_TIMELINE)
+#define FQ_TICK(slot) if (tid == 0) { const unsigned long long now_ = wall_clock64(); tl_ph_[slot] += (unsigned int)(now_ - tl_prev_); tl_prev_ = now_; }
+#define FQ_COUNT(k, n)
+  (void)prof;
 #else
 #define FQ_TICK(slot)
 #define FQ_COUNT(k, n)
@@ -794,7 +806,8 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
   // (0.7 M clusters per 256-frame submission) would hit.
   uint32_t next_item = 0, chunk_left = 0;   // uniform
 #ifdef AMDAT_FQ_TIMELINE
-  unsigned long long tl_t0_ = 0; unsigned int tl_sz_ = 0;
+  unsigned long long tl_t0_ = 0, tl_prev_ = 0; unsigned int tl_sz_ = 0;
+  unsigned int tl_ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   for (;;) {
     __syncthreads();   // the previous cluster's LDS use (and s_item) is finished in every wave
@@ -809,8 +822,17 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
 #ifdef AMDAT_FQ_TIMELINE
     if (tid == 0) {
       const unsigned long long now_ = wall_clock64();
-      if (tl_sz_) { const unsigned int k_ = atomicAdd(&g_fq_tl_n, 1u); if (k_ < (1u << 16)) { g_fq_tl[k_][0] = tl_t0_; g_fq_tl[k_][1] = ((now_ - tl_t0_) << 32) | ((unsigned long long)NT << 20) | (unsigned long long)tl_sz_; } }
-      tl_t0_ = now_; tl_sz_ = 0;
+      if (tl_sz_) {
+        const unsigned int k_ = atomicAdd(&g_fq_tl_n, 1u);
+        if (k_ < (1u << 16)) {
+          g_fq_tl[k_][0] = tl_t0_; g_fq_tl[k_][1] = ((now_ - tl_t0_) << 32) | ((unsigned long long)NT << 20) | (unsigned long long)tl_sz_;
+#pragma unroll
+          for (int j_ = 0; j_ < 8; j_++) g_fq_ph[k_][j_] = tl_ph_[j_];
+        }
+      }
+      tl_t0_ = now_; tl_prev_ = now_; tl_sz_ = 0;
+#pragma unroll
+      for (int j_ = 0; j_ < 8; j_++) tl_ph_[j_] = 0;
     }
 #endif
     if (item >= nwork) break;
@@ -1505,16 +1527,46 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     FQ_STOP_AT(6)
 
     // ---- pairwise segment fits, then all corner quadruples ---------------------------------------
+    // The 90 fits read only 2 m + 1 rows of the cumulative moments -- at every selected maximum, just before it, and the
+    // last row -- so those rows are fetched ONCE (one lane per row, all loads in flight together) and parked in the key
+    // region behind the pair tables; the fits then take them from LDS.  (Every fit used to start with its own three global
+    // loads, round after round: the phase is ~15 us of the ~40 us every cluster of the one-wave class costs, mostly waiting.)
+    double* const s_rows = s_tab + 12 * 45;   // [2 m + 1][6]: rows 0 .. m-1 at the maxima, m .. 2m-1 before them, 2m the last row
+    for (int r = tid; r < 2 * m + 1; r += NT) {
+      const int src = r < m ? s_maxidx[r] : r < 2 * m ? s_maxidx[r - m] - 1 : szd - 1;
+      double row[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // (before point 0: nothing; the fit does not subtract it)
+      if (src >= 0) {
+        const double* g = lf + (size_t)src * 6;
+#pragma unroll
+        for (int j = 0; j < 6; j++) row[j] = g[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 6; j++) s_rows[r * 6 + j] = row[j];
+    }
+    __syncthreads();
     for (int task = tid; task < 90; task += NT) {
       const int t = task < 45 ? task : task - 45;
       const int pr = g_pair_table.v[t], a = pr >> 4, b = pr & 15;   // a < b
       if (b < m) {
         double e, ms, lp[4];
         if (task < 45) {
-          fit_line_dev(lf, szd, s_maxidx[a], s_maxidx[b], lp, &e, &ms);
+          // forward a -> b: fit_line_dev(lf, szd, i_a, i_b) with i_a < i_b -- row at b, minus the row before a unless a is point 0
+          const double* rb = s_rows + b * 6;
+          double Mx = rb[0], My = rb[1], Mxx = rb[2], Mxy = rb[3], Myy = rb[4], W = rb[5];
+          if (s_maxidx[a] > 0) {
+            const double* ra = s_rows + (m + a) * 6;
+            Mx -= ra[0]; My -= ra[1]; Mxx -= ra[2]; Mxy -= ra[3]; Myy -= ra[4]; W -= ra[5];
+          }
+          fit_line_moments(Mx, My, Mxx, Mxy, Myy, W, s_maxidx[b] - s_maxidx[a] + 1, lp, &e, &ms);
           s_ferr[t] = e; s_fmse[t] = ms; s_fex[t] = lp[0]; s_fey[t] = lp[1]; s_fnx[t] = lp[2]; s_fny[t] = lp[3];
         } else {
-          fit_line_dev(lf, szd, s_maxidx[b], s_maxidx[a], lp, &e, &ms);
+          // around the end, b -> a: fit_line_dev(lf, szd, i_b, i_a) with i_b > i_a -- (last row - row before b) + row at a
+          const double* re = s_rows + 2 * m * 6;
+          const double* rp = s_rows + (m + b) * 6;
+          const double* ra = s_rows + a * 6;
+          double Mx = re[0] - rp[0], My = re[1] - rp[1], Mxx = re[2] - rp[2], Mxy = re[3] - rp[3], Myy = re[4] - rp[4], W = re[5] - rp[5];
+          Mx += ra[0]; My += ra[1]; Mxx += ra[2]; Mxy += ra[3]; Myy += ra[4]; W += ra[5];
+          fit_line_moments(Mx, My, Mxx, Mxy, Myy, W, szd - s_maxidx[b] + s_maxidx[a] + 1, lp, &e, &ms);
           s_werr[t] = e; s_wmse[t] = ms; s_wex[t] = lp[0]; s_wey[t] = lp[1]; s_wnx[t] = lp[2]; s_wny[t] = lp[3];
         }
       }

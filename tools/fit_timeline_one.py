@@ -19,8 +19,12 @@ for _ in range(6):
     det.run_prepared(prep)
 L.amdAprilTagsDebugTimeline(buf.ctypes.data, 1 << 16)
 det.run_prepared(prep)
+ph = np.zeros((1 << 16, 8), dtype=np.uint32)
+L.amdAprilTagsDebugTimelinePhases.argtypes = [C.c_void_p, C.c_uint]
+L.amdAprilTagsDebugTimelinePhases(ph.ctypes.data, 1 << 16)
 n = L.amdAprilTagsDebugTimeline(buf.ctypes.data, 1 << 16)
 b = buf[:n]
+ph = ph[:n]
 t0 = b[:, 0].astype(np.int64); dur = (b[:, 1] >> np.uint64(32)).astype(np.int64); nt = ((b[:, 1] >> np.uint64(20)) & np.uint64(0xFFF)).astype(int)
 sz = (b[:, 1] & np.uint64(0xFFFFF)).astype(int)
 base = t0.min()
@@ -36,8 +40,13 @@ for c in sorted(set(nt)):
     order = np.argsort(-(t0 + dur)[m])[:5]
     for k in order:
         print("      sz %5d start %.1f dur %.1f end %.1f" % (sz[m][k], (t0[m][k] - base) * tick, dur[m][k] * tick, ((t0 + dur)[m][k] - base) * tick))
+    names = ["pop+load", "bbox+dot", "keys+sort", "presort", "sweep", "errors+maxima", "top-10", "pairs+corners"]
     for lo, hi in ((24, 64), (65, 128), (129, 256), (257, 512), (513, 768), (769, 2048), (2049, 4096), (4097, 1 << 20)):
         mm = m & (sz >= lo) & (sz <= hi)
         if mm.sum():
             print("      sizes %5d..%-6d n %5d mean dur %.1f us max %.1f" % (lo, hi, mm.sum(), dur[mm].mean() * tick, dur[mm].max() * tick))
+            full = mm & (ph[:, 7] > 0)   # clusters that went through every phase
+            if full.sum():
+                print("            (%d reached the corner search) mean us per phase: " % full.sum() +
+                      ", ".join("%s %.1f" % (names[j], ph[full, j].mean() * tick) for j in range(8) if j != 3))
 det.close()
