@@ -751,7 +751,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
   mark();
   {
     const uint32_t gxt = (uint32_t)((P.W + PT_TW - 1) / PT_TW), gyt = (uint32_t)((P.H + PT_TH - 1) / PT_TH);
-    hipLaunchKernelGGL(k_points, dim3(gxt * gyt * n), dim3(256), 0, s, D->d_thr, D->d_label, D->d_csize, D->d_hkeys, D->d_hcnt,
+    hipLaunchKernelGGL(k_points, dim3(gxt * gyt * n), dim3(256), 0, s, D->d_thr, D->d_label, D->d_hkeys, D->d_hcnt,
                        D->d_stage, D->d_bhdr, D->d_btab, D->d_long, D->d_counters, (D->fq_counters ? D->d_ptprof : nullptr), gxt, gyt, n, P);
   }
   mark();

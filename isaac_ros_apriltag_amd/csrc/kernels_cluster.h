@@ -89,7 +89,7 @@ __device__ __forceinline__ int ltab_find(const unsigned long long* tkey, uint64_
 // value the add returns is the block's base rank inside the cluster, so every staged point carries its
 // final position (hoff[slot] + rank) and the scatter pass needs no atomics at all.
 __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_all, const uint32_t* __restrict__ label_all,
-                                                const uint32_t* __restrict__ csize_all, unsigned long long* __restrict__ hkeys_all,
+                                                unsigned long long* __restrict__ hkeys_all,
                                                 uint32_t* __restrict__ hcnt_all, uint32_t* __restrict__ stage_all,
                                                 uint2* __restrict__ bhdr_all, uint2* __restrict__ btab_all, uint4* __restrict__ long_all,
                                                 FrameCounters* __restrict__ counters,
@@ -123,7 +123,6 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   const size_t npx = (size_t)W * H;
   const uint8_t* thr = thr_all + (size_t)frame * H * P.WS;
   const uint32_t* label = label_all + (size_t)frame * npx;
-  const uint32_t* csize = csize_all + (size_t)frame * npx;
   const int X0 = bx_ * PT_TW, Y0 = by_ * PT_TH;
   const int tid = threadIdx.x;
 
