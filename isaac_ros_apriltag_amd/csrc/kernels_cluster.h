@@ -80,9 +80,10 @@ __device__ __forceinline__ int ltab_find(const unsigned long long* tkey, uint64_
 // Where the kernel's time goes (256 sigma-2 1080p frames, 3.97 ms; builds that stop after a phase, and builds with one
 // operation taken out): tile load 0.85 ms, emission tests + scan 0.43, list 0.37, pass 2 1.0 (of which the returning
 // same-address LDS add 0.5, the table insert 0.23), frame table 0.8 (two or three dependent L2 round trips per block, with
-// the block's other waves at the barrier), emit + staging stores 0.6.  Grouping a wave's lanes by key with ballots so that
-// one lane per group adds (2 / 4 / 6 leader rounds) measured 4.00 / 4.09 / 4.05 ms: the rounds cost what the serialised
-// atomic does.  (The cycle shares of the profiling build put 60 % on the last two phases: its per-phase global atomics are
+// the block's other waves at the barrier), emit + staging stores 0.6.  Grouping a wave's lanes by 64-bit KEY with ballots, BEFORE
+// the insert, so that one lane per group inserts and adds (2 / 4 / 6 leader rounds) measured 4.00 / 4.09 / 4.05 ms: the rounds
+// cost what the serialised atomic does.  ONE round on the table ENTRY after the insert (pass 2 below) is cheap enough:
+// 3.62 -> 3.49 ms.  (The cycle shares of the profiling build put 60 % on the last two phases: its per-phase global atomics are
 // waited for there.)
 // Boundary points of one 64x16 tile.  Points are counted per component pair in a per-block LDS table
 // first, so that the per-frame hash table sees ONE insert and ONE atomicAdd per (block, pair); the
@@ -241,6 +242,23 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
     const int e = ltab_insert(tkey, key);
     uint32_t ee = 255u, rk = 0u;
+#ifndef PT_NO_LEADER_ADD
+    // Most emissions of a wave's trip belong to ONE pair (the background's two big components meet in almost every tile):
+    // 64 lanes adding 1 to the same counter serialise in the LDS pipeline (the kernel's "bank conflicts" are these
+    // same-address atomics).  The lanes that share the first active lane's entry take their ranks from ONE add of their
+    // number; the others add for themselves.
+    const int e_first = __builtin_amdgcn_readfirstlane(e);
+    const bool with_first = e == e_first && e >= 0 && e < 255;
+    const unsigned long long gm = __ballot(with_first);
+    if (with_first) {
+      const int leader = (int)__ffsll((long long)gm) - 1;
+      uint32_t gbase = 0;
+      if ((int)(tid & 63) == leader) gbase = atomicAdd(&tcnt[e], (uint32_t)__popcll(gm));
+      gbase = (uint32_t)__builtin_amdgcn_readlane((int)gbase, leader);
+      ee = (uint32_t)e;
+      rk = gbase + (uint32_t)__popcll(gm & ((1ull << (tid & 63)) - 1ull));
+    } else
+#endif
     if (e >= 0 && e < 255) { ee = (uint32_t)e; rk = atomicAdd(&tcnt[e], 1u); }
     elist[q] = rec | (ee << 12) | (rk << 20);
   }
