@@ -162,7 +162,7 @@ def threshold_roofline(frames_dev, decimate, reps=20):
     # (tools/thr_only.py; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), committed under
     # profiles/; bench.py cannot collect PMC counters itself.
     traffic, traffic_src = None, None
-    for name in ("r03_threshold_pmc.json", "r02_threshold_pmc.json", "r01_threshold_pmc.json"):
+    for name in ("r04_threshold_pmc.json", "r03_threshold_pmc.json", "r02_threshold_pmc.json", "r01_threshold_pmc.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if decimate == 1 and os.path.exists(pmc):
             rec = json.load(open(pmc))
@@ -176,7 +176,7 @@ def threshold_roofline(frames_dev, decimate, reps=20):
 
 
 STAGE_KERNELS = {"threshold": ("k_threshold",), "cc_local": ("k_cc_local",), "points": ("k_points",), "scatter": ("k_scatter",),
-                 "fit_quads": ("k_fit_prefilter", "k_fit_quads", "k_quad_finish")}
+                 "fit_quads": ("k_fit_prefilter", "k_fit_quads", "k_fit_small", "k_quad_finish")}
 
 
 def stage_rooflines(stage_ms, nframes, counts, decimate):
@@ -196,9 +196,11 @@ def stage_rooflines(stage_ms, nframes, counts, decimate):
     P, Pk = counts["npoints_raw"], counts["npoints_kept"]
     alg = {"threshold": 2 * N, "cc_local": 5 * N, "points": 5 * N + 4 * P, "scatter": 4 * P + 4 * Pk, "fit_quads": 8 * Pk}
     pmc, pmc_src = None, None
-    path = os.path.join(ROOT, "profiles", "r03_pipeline_pmc.json")
-    if decimate == 1 and os.path.exists(path):
-        pmc, pmc_src = json.load(open(path)), "profiles/r03_pipeline_pmc.json"
+    for name in ("r04_pipeline_pmc.json", "r03_pipeline_pmc.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if decimate == 1 and os.path.exists(path):
+            pmc, pmc_src = json.load(open(path)), "profiles/" + name
+            break
     out = {}
     for k, b in alg.items():
         ms = stage_ms.get(k)
@@ -293,13 +295,20 @@ def main():
         ts = time.perf_counter()
         det.run_prepared(prep)
         step_ms.append((time.perf_counter() - ts) * 1e3)
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0          # this rank's own K steps (no barrier inside): what a straggler shows up in
     barrier()
     dt = time.perf_counter() - t0
     out = det.unpack(prep)
+    rank_fps = [B * args.steps / dt_own]
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        mine_t = torch.tensor([B * args.steps / dt_own], dtype=torch.float64, device=coll_dev)
+        all_t = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(all_t, mine_t)
+        rank_fps = [float(t.item()) for t in all_t]
     flags = det.frame_flags(B)
     det.set_profiling(True)
     det.run_prepared(prep)
@@ -308,31 +317,51 @@ def main():
     det.set_profiling(False)
     mem = det.device_bytes()
 
-    # per-rank parity gate against the CPU restatement on a few of this rank's frames (every rank checks its own)
+    # Parity gate in the same run: EVERY rank compares ALL frames of its batch with the CPU restatement (ids exact; corners,
+    # rotation and translation bit-identical).  Rank 0 goes first and alone -- its pass over the frames is also the timed
+    # cpu_baseline leg, on all host cores -- while the other ranks wait at a barrier (about 20 s on the driver's box, far
+    # below the process group's timeout of 10 minutes (RCCL) / 30 minutes (gloo)); then the other ranks check their own
+    # frames side by side, each on its share of the cores.
     gate_ok = True
     byframe = None
     cpu_rec = None
+    gated = 0
     if not args.no_cpu_baseline:
         if rank == 0:
             cpu_rec, byframe = cpu_baseline(frames_np, intr, args.decimate, tag_size)
-        else:
+        if world > 1:
+            dist.barrier()
+        if rank != 0:
+            from concurrent.futures import ThreadPoolExecutor
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import parity_util as pu
             from oracle import pyoracle as po
-            byframe = {}
-            for i in (0, B // 2, B - 1):
+            po.lib()
+
+            def run(i):
                 fx, fy, cx, cy = intr[i]
                 K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
-                byframe[i] = po.detect(frames_np[i], params=pu.oracle_params(K, args.decimate, tag_size))[0]
+                return po.detect(frames_np[i], params=pu.oracle_params(K, args.decimate, tag_size))[0]
+            # distinct frames only (the batch cycles through them); threads: this rank's share of the host cores
+            distinct_idx = sorted({int(i) for s_ in range(spr) for i in (s_ * per_stream_batch + np.arange(min(per_stream_batch, per_stream_distinct)))})
+            nthr = max(1, (os.cpu_count() or 1) // max(1, world - 1))
+            with ThreadPoolExecutor(max_workers=nthr) as ex:
+                byframe = dict(zip(distinct_idx, ex.map(run, distinct_idx)))
         for i, odets in byframe.items():
             g = out[i]
             gate_ok &= len(g) == len(odets) and all(
                 a["id"] == b["id"] and np.array_equal(a["p"], b["p"]) and np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"])
                 for a, b in zip(g, odets))
+        gated = len(byframe)
+    gated_all = [gated]
     if world > 1:
         gt = torch.tensor([1.0 if gate_ok else 0.0], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(gt, op=dist.ReduceOp.MIN)
         gate_all = bool(gt.item() > 0.5)
+        gm = torch.tensor([float(gated)], dtype=torch.float64, device=coll_dev)
+        ga = [torch.zeros_like(gm) for _ in range(world)]
+        dist.all_gather(ga, gm)
+        gated_all = [int(t.item()) for t in ga]
     else:
         gate_all = gate_ok
 
@@ -354,7 +383,10 @@ def main():
                                    "%d distinct frames per GPU, device-resident" % (args.sigma, nstreams, spr, per_stream_distinct * spr),
                        "frames_per_step_per_gpu": B, "decimate": args.decimate, "streams": nstreams, "streams_per_gpu": spr,
                        "world_size_seen_by_%s" % ("rccl" if args.backend == "nccl" else args.backend): observed_world,
-                       "parallelism": "%d independent streams, %d per GPU, RCCL broadcast of intrinsics only" % (nstreams, spr)},
+                       "parallelism": "%d independent streams, %d per GPU, RCCL broadcast of intrinsics only" % (nstreams, spr),
+                       # every rank's own rate over its K steps (frames/s): a straggler GPU is visible here, `value` uses the max-over-ranks time
+                       "per_rank_fps": {"min": round(min(rank_fps), 1), "max": round(max(rank_fps), 1), "mean": round(float(np.mean(rank_fps)), 1),
+                                        "ranks": [round(v, 1) for v in rank_fps]}},
             "detections_per_frame": float(np.mean(ndet)), "frame_flags_nonzero": int(sum(1 for f in flags if f)),
             "step_ms_median": round(float(np.median(step_ms)), 3), "step_ms_min": round(float(np.min(step_ms)), 3),
             "fps_median_step": round(B / (float(np.median(step_ms)) * 1e-3), 1), "fps_best_step": round(B / (float(np.min(step_ms)) * 1e-3), 1),
@@ -373,8 +405,9 @@ def main():
                 rec["roofline"]["in_pipeline"] = {"frames_per_launch": B, "ms": thr["ms"], "achieved": thr["GB/s"], "frac": thr["frac_of_8TBs"]}
         if byframe is not None:
             # correctness gate in the same run: ids exact; corners, rotation and translation bit-identical to the CPU restatement
-            rec["parity_gate"] = "pass" if gate_all else "FAIL"
+            rec["parity_gate"] = "pass" if gate_all else "FAIL"      # AND over all ranks
             rec["parity_gate_frames_rank0"] = len(byframe)
+            rec["parity_gate_frames_per_rank"] = gated_all
         print(json.dumps(rec))
         sys.stdout.flush()
     if world > 1:

@@ -138,7 +138,15 @@ typedef struct {
   int32_t device;              /* HIP device ordinal, -1 = current */
   float skew;                  /* K[0][1] of the pinhole matrix; 0 on the cuAprilTags-shaped path, the VPI path of
                                 * the reference passes it with its 2x3 intrinsics (src/apriltag_node.cpp:215-225) */
+  uint32_t corner_convention;  /* amdAprilTagsID_t only (amdAprilTagsDetectionEx_t always carries AprilRobotics' own):
+                                * AMDAT_CORNERS_DEFAULT: corners[i] = p[3 - i], R as solved -- the reading of the reference's
+                                * golden frame this library was built to (test/isaac_ros_apriltag_pol_test.py:132-175);
+                                * AMDAT_CORNERS_ROTATED_180: the other reading of that frame -- corner index turned by two
+                                * (corners[i] = p[(5 - i) & 3]) and the tag frame turned about its normal, R * Rz(pi) -- kept
+                                * selectable until output of the closed library itself is available */
 } amdAprilTagsConfig_t;
+#define AMDAT_CORNERS_DEFAULT 0u
+#define AMDAT_CORNERS_ROTATED_180 1u
 
 void amdAprilTagsDefaultConfig(amdAprilTagsConfig_t* cfg, uint32_t width, uint32_t height);
 
@@ -213,7 +221,12 @@ int amdAprilTagsRegisterFamily(amdAprilTagsFamily slot, const char* name, uint32
 int amdAprilTagsRegisterFamilyEx(amdAprilTagsFamily slot, const char* name, uint32_t nbits, const int8_t* bit_x,
                                  const int8_t* bit_y, uint32_t width_at_border, uint32_t total_width, int reversed_border,
                                  const uint64_t* codes, uint32_t ncodes);
-/* Family metadata: returns 0 and fills the outputs if the family is known. */
+/* Registered names are at most 31 characters and code words carry no bits above the family's width (AMDAT_INVALID_ARGUMENT
+ * otherwise).  amdAprilTagsUnregisterFamily empties a registrable slot again (handles created earlier keep their copy of the
+ * table). */
+int amdAprilTagsUnregisterFamily(amdAprilTagsFamily slot);
+/* Family metadata: returns 0 and fills the outputs if the family is known.  The pointers stay valid until the slot is
+ * registered again or emptied. */
 int amdAprilTagsFamilyInfo(amdAprilTagsFamily family, const char** name, uint32_t* data_bits_per_side,
                            uint32_t* ncodes, const uint64_t** codes);
 /* Family lookup by the reference's parameter string (src/apriltag_node.cpp:47-58); -1 if unknown

@@ -44,7 +44,7 @@ def build_amd(force=False):
     srcs = _sources(".hip", ".h")
     if force or _newer(LIB_AMD, srcs):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               "-fno-fast-math", "-Wall", "-Wno-unused-value", "-Wno-unused-function",
+               "-fno-fast-math", "-Wall", "-Wno-unused-value", "-Wno-unused-function", "-Wno-pass-failed",
                os.path.join(_CSRC, "detector.hip"), "-o", LIB_AMD]
         subprocess.check_call(cmd)
     return LIB_AMD
@@ -55,7 +55,7 @@ def build_amd_variant(tag, defines):
     The product library carries none of this; the variant is written next to it as libapriltag_amd_<tag>.so."""
     out = os.path.join(_HERE, "libapriltag_amd_%s.so" % tag)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-fno-fast-math", "-Wno-unused-value", "-Wno-unused-function"] + ["-D" + d for d in defines] + \
+           "-fno-fast-math", "-Wno-unused-value", "-Wno-unused-function", "-Wno-pass-failed"] + ["-D" + d for d in defines] + \
           [os.path.join(_CSRC, "detector.hip"), "-o", out]
     subprocess.check_call(cmd)
     return out

@@ -50,14 +50,14 @@ class Config(C.Structure):
                 ("tag_size", C.c_float), ("max_batch", C.c_uint32), ("refine_edges", C.c_uint32),
                 ("max_hamming", C.c_uint32), ("decode_sharpening", C.c_float), ("max_points", C.c_uint32),
                 ("hash_slots", C.c_uint32), ("max_clusters", C.c_uint32), ("max_quads", C.c_uint32),
-                ("max_detections", C.c_uint32), ("device", C.c_int32), ("skew", C.c_float)]
+                ("max_detections", C.c_uint32), ("device", C.c_int32), ("skew", C.c_float), ("corner_convention", C.c_uint32)]
 
 
 # every symbol include/apriltag_amd.h declares
 EXPORTS = ["amdAprilTagsDefaultConfig", "amdCreateAprilTagsDetector", "amdCreateAprilTagsDetectorEx",
            "amdAprilTagsDestroy", "amdAprilTagsDetect", "amdAprilTagsDetectBatch", "amdAprilTagsDetectBatchEx",
            "amdAprilTagsGetFrameFlags", "amdAprilTagsConvertToMono8", "amdAprilTagsRegisterFamily",
-           "amdAprilTagsRegisterFamilyEx",
+           "amdAprilTagsRegisterFamilyEx", "amdAprilTagsUnregisterFamily",
            "amdAprilTagsFamilyInfo", "amdAprilTagsFamilyFromName", "amdAprilTagsStageName",
            "amdAprilTagsSetProfiling", "amdAprilTagsGetStageMs", "amdAprilTagsThresholdOnly",
            "amdAprilTagsDebugCopy", "amdAprilTagsDebugMath", "amdAprilTagsDeviceAlloc", "amdAprilTagsDeviceFree",
@@ -96,6 +96,7 @@ def lib():
                                                C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.c_uint32]
     L.amdAprilTagsFamilyInfo.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32),
                                          C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint64))]
+    L.amdAprilTagsUnregisterFamily.argtypes = [C.c_int]
     L.amdAprilTagsFamilyFromName.argtypes = [C.c_char_p]
     L.amdAprilTagsStageName.argtypes = [C.c_uint32]
     L.amdAprilTagsStageName.restype = C.c_char_p
@@ -159,6 +160,10 @@ def register_family_ex(slot, name, bit_x, bit_y, width_at_border, total_width, r
     cc = (C.c_uint64 * len(codes))(*[int(c) for c in codes])
     _check("amdAprilTagsRegisterFamilyEx", lib().amdAprilTagsRegisterFamilyEx(slot, name.encode(), n, bx, by, width_at_border, total_width,
                                                                              int(bool(reversed_border)), cc, len(codes)))
+
+
+def unregister_family(slot):
+    _check("amdAprilTagsUnregisterFamily", lib().amdAprilTagsUnregisterFamily(slot))
 
 
 def debug_math(op, a, b):

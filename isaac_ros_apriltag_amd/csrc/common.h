@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "tools_hooks.h"
+
 #define AT_NO_LABEL 0xFFFFFFFFu
 #define AT_LABEL_BIG 0x80000000u    // on a root's own label entry: the component has at least min_component_size pixels
 #define AT_LABEL_MASK 0x7FFFFFFFu
@@ -53,9 +55,10 @@ struct QuadRec {
 // q3->q0, handed from k_fit_quads to k_quad_finish.
 struct FitCand {
   double line[4][4];
+  double wm[2];               // wrap_is_moments: line[3] = {Mx, My, Mxx, Mxy} and wm = {Myy, W} of the segment q3->q0
   uint64_t key;
   int32_t reversed_border;
-  uint32_t pad;
+  uint32_t wrap_is_moments;
 };
 
 // Same layout as amdAprilTagsDetectionEx_t.

@@ -24,6 +24,7 @@
 #include "kernels_decode_wave.h"
 #include "kernels_frontend.h"
 #include "kernels_quad.h"
+#include "kernels_quad_small.h"
 #include "kernels_threshold.h"
 
 static_assert(sizeof(DetRec) == sizeof(amdAprilTagsDetectionEx_t), "DetRec must match the public record");
@@ -123,11 +124,16 @@ uint32_t next_pow2(uint32_t v) {
 
 // One size class of the quad fit: workgroup size, LDS key capacity, cluster sizes (lo, hi], persistent grid,
 // scratch slot size (points) and its slice of the work array.
+// Side streams of the quad fit.  Three, as in every earlier round: a captured submission with six parallel branches (five side
+// streams + the submission stream) crashed inside hipGraphLaunch (hip::Graph::UpdateStreams, ROCm 7.2) in about one of seven
+// 300-case fuzz runs; with four branches it never has.  Classes that launch share the streams round-robin.
+#define FQ_NAUX 3
 struct FqClass {
   int nt, sort_cap, lo, hi;
   unsigned grid;
   int slot_cap;
   int pop;                                // clusters taken from the work list per atomic
+  int small_k = 0;                        // > 0: k_fit_small<small_k> (keys and sweep state in registers, moments in LDS), no scratch
   double* d_lf = nullptr;                 // grid x slot_cap x 6 doubles
   double* d_errs = nullptr;               // grid x slot_cap x 2 doubles: error arrays of clusters that exceed what the
                                           // kernel keeps in LDS / registers (slot_cap > 16 x nt, or > sort_cap)
@@ -141,8 +147,8 @@ struct amdAprilTagsDetector_st {
   size_t device_bytes = 0;
   hipStream_t own_stream = nullptr;
   // the size classes of the quad fit fork to auxiliary streams and join before decode
-  hipStream_t aux_stream[3] = {};
-  hipEvent_t ev_fork = nullptr, ev_join[3] = {};
+  hipStream_t aux_stream[FQ_NAUX] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[FQ_NAUX] = {};
   // device buffers
   uint8_t* d_gray = nullptr;
   uint8_t* d_thr = nullptr;
@@ -175,10 +181,12 @@ struct amdAprilTagsDetector_st {
   unsigned long long* d_fqprof = nullptr;  // per-phase cycle counters of k_fit_quads (-DAMDAT_FQ_PROFILE builds only)
   FqClass cls[FQ_NCLS];
   FqWorkLayout work_layout;
-  int prefilter_class = 2;           // first size class whose clusters go through k_fit_prefilter (those above 2048 points)
+  FqWorkLayout work_layout_small;    // small submissions: the k_fit_small classes are empty, the one-wave class starts at 0 (issue_pipeline)
+  int prefilter_class = FQ_C0 + 2;           // first size class whose clusters go through k_fit_prefilter (those above 2048 points)
   bool grow_points = false;          // point capacity follows the content (no explicit max_points)
   bool grow_hash = false;            // the same for the component-pair table (no explicit hash_slots)
   bool pending_hash_grow = false;
+  bool unusable = false;             // a capacity change failed twice (grown and original size): buffers are gone, every later call reports it
   size_t cands_bytes = 0;
   uint32_t hcap_hard = 0;
   size_t hash_buffer_bytes[3] = {0, 0, 0};
@@ -256,14 +264,26 @@ void amdAprilTagsDefaultConfig(amdAprilTagsConfig_t* cfg, uint32_t width, uint32
   cfg->device = -1;
 }
 
+// a registered name must fit the slot's buffer whole (a truncated name could never be found again), and a code word must not
+// carry bits above the family's width (it could never match, and the Hamming search would count the stray bits)
+static bool family_args_ok(const char* name, uint32_t nbits, const uint64_t* codes, uint32_t ncodes) {
+  if (strlen(name) >= sizeof(FamilyHost::name_buf)) return false;
+  if (nbits < 64)
+    for (uint32_t i = 0; i < ncodes; i++)
+      if (codes[i] >> nbits) return false;
+  return true;
+}
+
 int amdAprilTagsRegisterFamily(amdAprilTagsFamily slot, const char* name, uint32_t d, const uint64_t* codes, uint32_t ncodes) {
   std::call_once(g_fam_once, init_families);
   if (!is_registrable_slot((int)slot)) return AMDAT_INVALID_ARGUMENT;
   if (!name || !codes || ncodes == 0 || d < 3 || d > 7) return AMDAT_INVALID_ARGUMENT;
+  if (!family_args_ok(name, d * d, codes, ncodes)) return AMDAT_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> lk(g_fam_mutex);
   FamilyHost& f = g_families[slot];
   f.owned.assign(codes, codes + ncodes);
   strncpy(f.name_buf, name, sizeof(f.name_buf) - 1);
+  f.name_buf[sizeof(f.name_buf) - 1] = 0;
   f.name = f.name_buf;
   family_set_classic(f, d);
   f.ncodes = ncodes;
@@ -277,6 +297,7 @@ int amdAprilTagsRegisterFamilyEx(amdAprilTagsFamily slot, const char* name, uint
   std::call_once(g_fam_once, init_families);
   if (!is_registrable_slot((int)slot)) return AMDAT_INVALID_ARGUMENT;
   if (!name || !bit_x || !bit_y || !codes || ncodes == 0 || nbits == 0 || nbits > 64) return AMDAT_INVALID_ARGUMENT;
+  if (!family_args_ok(name, nbits, codes, ncodes)) return AMDAT_INVALID_ARGUMENT;
   if (width_at_border < 3 || total_width < width_at_border || total_width > 12 || ((total_width - width_at_border) & 1u))
     return AMDAT_INVALID_ARGUMENT;
   FamilyHost f;
@@ -300,9 +321,21 @@ int amdAprilTagsRegisterFamilyEx(amdAprilTagsFamily slot, const char* name, uint
   return AMDAT_SUCCESS;
 }
 
+int amdAprilTagsUnregisterFamily(amdAprilTagsFamily slot) {
+  std::call_once(g_fam_once, init_families);
+  if (!is_registrable_slot((int)slot)) return AMDAT_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(g_fam_mutex);
+  FamilyHost& f = g_families[slot];
+  f.codes = nullptr; f.ncodes = 0; f.name = nullptr; f.name_buf[0] = 0;
+  f.owned.clear();
+  return AMDAT_SUCCESS;
+}
+
 int amdAprilTagsFamilyInfo(amdAprilTagsFamily family, const char** name, uint32_t* d, uint32_t* ncodes, const uint64_t** codes) {
   std::call_once(g_fam_once, init_families);
-  if ((int)family < 0 || family >= AMDAT_ENUM_SIZE || g_families[family].codes == nullptr) return AMDAT_UNSUPPORTED;
+  if ((int)family < 0 || family >= AMDAT_ENUM_SIZE) return AMDAT_UNSUPPORTED;
+  std::lock_guard<std::mutex> lk(g_fam_mutex);   // (the pointers handed out stay valid until the slot is registered again)
+  if (g_families[family].codes == nullptr) return AMDAT_UNSUPPORTED;
   if (name) *name = g_families[family].name;
   if (d) *d = g_families[family].d;
   if (ncodes) *ncodes = g_families[family].ncodes;
@@ -316,6 +349,7 @@ int amdAprilTagsFamilyFromName(const char* name) {
   // registered tables take precedence over a built-in of the same name
   static const int scan[AMDAT_ENUM_SIZE] = {AMDAT_CUSTOM0, AMDAT_CUSTOM1, AMDAT_CUSTOM2, AMDAT_CUSTOM3, AMDAT_CUSTOM4,
                                             AMDAT_TAG36H10, AMDAT_TAG36H11, AMDAT_TAG25H9, AMDAT_TAG16H5};
+  std::lock_guard<std::mutex> lk(g_fam_mutex);
   for (int k = 0; k < AMDAT_ENUM_SIZE; k++) {
     const int i = scan[k];
     if (g_families[i].codes && g_families[i].name && !strcmp(g_families[i].name, name)) return i;
@@ -384,13 +418,17 @@ static int alloc_point_buffers(amdAprilTagsDetector_st* D) {
     const FqClass& c = D->cls[k];
     D->work_layout.lo[k] = c.lo < 23 ? 23 : c.lo;
     D->work_layout.hi[k] = c.hi;
-    const uint32_t per_frame = P.pcap / (uint32_t)(D->work_layout.lo[k] + 1) + 1;
-    const uint64_t cap = (uint64_t)B * (per_frame < P.ccap ? per_frame : P.ccap);
+    // (the one-wave class of k_fit_quads also takes the k_fit_small classes' clusters on small submissions: sized from 24 points)
+    const uint32_t per_frame = P.pcap / (uint32_t)((k == FQ_C0 ? 23 : D->work_layout.lo[k]) + 1) + 1;
+    const uint64_t cap = c.hi <= c.lo ? 16 : (uint64_t)B * (per_frame < P.ccap ? per_frame : P.ccap);   // (an empty class keeps a token range)
     if (cap > 0x7FFFFFFFull || off + cap > 0xFFFFFFFFull) return AMDAT_BATCH_TOO_LARGE;   // offsets and cursors are 32-bit
     D->work_layout.off[k] = (uint32_t)off;
     D->work_layout.cap[k] = (uint32_t)cap;
     off += cap;
   }
+  D->work_layout_small = D->work_layout;
+  for (int k = 0; k < FQ_C0; k++) { D->work_layout_small.lo[k] = 23; D->work_layout_small.hi[k] = 0; }
+  D->work_layout_small.lo[FQ_C0] = 23;
   // Long staging records (kernels_cluster.h) only occur where a 64 x 16 tile has more than 2048 emissions -- above two per pixel --
   // or more than 255 component pairs; an eighth of the point capacity is room for them (an overflow reports like a point
   // overflow and grows with the point buffers).  Tools builds that shrink the tile's list take the whole capacity.
@@ -423,7 +461,11 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   if (cfg.tile_size != 4) return AMDAT_UNSUPPORTED;
   if (cfg.decimate > 4) return AMDAT_UNSUPPORTED;     // the threshold loader is instantiated for 1..4
   if (cfg.max_hamming > 3) return AMDAT_INVALID_ARGUMENT;  // AprilRobotics' own limit for the code search
+  if (cfg.corner_convention > AMDAT_CORNERS_ROTATED_180) return AMDAT_INVALID_ARGUMENT;
   if (cfg.num_families < 1 || cfg.num_families > AT_MAX_FAMILIES) return AMDAT_INVALID_ARGUMENT;
+  // the family tables are read (and copied to the device) under the registry's lock: a concurrent
+  // amdAprilTagsRegisterFamily[Ex] cannot swap a table out from under the copy
+  std::lock_guard<std::mutex> fam_lock(g_fam_mutex);
   for (uint32_t i = 0; i < cfg.num_families; i++) {
     if ((int)cfg.families[i] < 0 || cfg.families[i] >= AMDAT_ENUM_SIZE || !g_families[cfg.families[i]].codes)
       return AMDAT_UNSUPPORTED;
@@ -460,7 +502,7 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   P.refine_edges = cfg.refine_edges ? 1 : 0;
   P.max_hamming = (int)cfg.max_hamming;
   P.nfam = (int)cfg.num_families;
-  P.cos_critical_rad = 0x1.f838b8c811c17p-1;
+  P.cos_critical_rad = (double)(float)0x1.f838b8c811c17p-1;   // cos(10 deg) as upstream's FLOAT parameter field holds it
   P.max_line_fit_mse = 10.0;
   P.decode_sharpening = (double)cfg.decode_sharpening;
   P.tag_size = (double)cfg.tag_size;
@@ -528,17 +570,31 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
 #define FQ_POP1 2
 #define FQ_POP2 1
 #endif
-    c[0] = {64, FQ_B01, 0, FQ_B01, minu((unsigned)FQ_GRID_64 * cus, 4096u * (unsigned)B), FQ_B01, FQ_POP0};
-    c[1] = {128, FQ_B12, FQ_B01, FQ_B12, minu((unsigned)FQ_GRID_128 * cus, 1024u * (unsigned)B), FQ_B12, FQ_POP1};
-    c[2] = {256, 4096, FQ_B12, 4096, minu(4u * cus, 256u * (unsigned)B), 4096, FQ_POP2};
-    c[3] = {512, 8192, 4096, 8192, minu(2u * cus, 64u * (unsigned)B), 8192, 1};
+    // The two smallest classes run k_fit_small (kernels_quad_small.h): clusters up to 128 (and 256) points, whose keys and
+    // sweep state fit a wave's registers and whose cumulative moments fit LDS.  They exist on the two-double path only
+    // (working images up to 2048 x 2048); otherwise their ranges are empty and the one-wave class starts at 0.
+#ifndef FS_B0
+#define FS_B0 128
+#endif
+#ifndef FS_B1
+#define FS_B1 FS_B0   // (= FS_B0: no K = 4 class)
+#endif
+    const int sb0 = P.split_moments ? FS_B0 : 0, sb1 = P.split_moments ? FS_B1 : 0;
+    c[0] = {64, 0, 0, sb0, minu((unsigned)FS_GRID_K2 * cus, 4096u * (unsigned)B), sb0, FQ_POP0, 2};
+    c[1] = {64, 0, sb0, sb1, minu((unsigned)FS_GRID_K4 * cus, 4096u * (unsigned)B), sb1, FQ_POP0, 4};
+    FqClass* const q = c + FQ_C0;   // the classes of k_fit_quads
+    q[0] = {64, FQ_B01, sb1, FQ_B01, minu((unsigned)FQ_GRID_64 * cus, 4096u * (unsigned)B), FQ_B01, FQ_POP0};
+    q[1] = {128, FQ_B12, FQ_B01, FQ_B12, minu((unsigned)FQ_GRID_128 * cus, 1024u * (unsigned)B), FQ_B12, FQ_POP1};
+    q[2] = {256, 4096, FQ_B12, 4096, minu(4u * cus, 256u * (unsigned)B), 4096, FQ_POP2};
+    q[3] = {512, 8192, 4096, 8192, minu(2u * cus, 64u * (unsigned)B), 8192, 1};
     // (a "latency layout" for small-batch handles -- about three times the threads per cluster: 64 up to 256 points, 128 up
     // to 768, 256 up to 2048, 512 up to 8192 -- measured slower on one-frame submissions, 0.36 against 0.28 ms for the
     // stage: the larger workgroups' barriers cost more than the shorter per-lane runs save)
-    D->prefilter_class = 2;
-    c[4] = {FQ_NT_BIG, 16384, 8192, 0x7FFFFFFF, minu(cus, 16u * (unsigned)B), P.max_cluster_points, 1};
-    if (P.max_cluster_points > 16384 && P.max_cluster_points <= 18432) c[4].sort_cap = (P.max_cluster_points + 63) & ~63;
-    if (c[4].slot_cap < 8193) c[4].slot_cap = 8193;
+    D->prefilter_class = FQ_C0 + 2;
+    q[4] = {FQ_NT_BIG, 16384, 8192, 0x7FFFFFFF, minu(cus, 16u * (unsigned)B), P.max_cluster_points, 1};
+    static_assert(FQ_C0 + 5 == FQ_NCLS, "class table");
+    if (P.max_cluster_points > 16384 && P.max_cluster_points <= 18432) q[4].sort_cap = (P.max_cluster_points + 63) & ~63;
+    if (q[4].slot_cap < 8193) q[4].slot_cap = 8193;
   }
 
   bool ok = true;
@@ -565,7 +621,7 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   if (ok) { const int rc = alloc_point_buffers(D); if (rc == AMDAT_BATCH_TOO_LARGE) { free_all(D); delete D; return rc; } ok = rc == AMDAT_SUCCESS; }
   for (int k = 0; k < FQ_NCLS; k++) {
     FqClass& c = D->cls[k];
-    if (P.max_cluster_points <= c.lo) continue;
+    if (P.max_cluster_points <= c.lo || c.small_k || c.hi <= c.lo) continue;
     alloc((void**)&c.d_lf, (size_t)c.grid * c.slot_cap * 48);
     // smoothed errors stay in registers up to FQ_SMOOTH_REGS_OF(threads) points per thread; larger clusters need a second array
     if (c.slot_cap > FQ_SMOOTH_REGS_OF(c.nt) * c.nt || c.slot_cap > c.sort_cap) alloc((void**)&c.d_errs, (size_t)c.grid * c.slot_cap * 16);
@@ -725,6 +781,12 @@ __global__ __launch_bounds__(64) void k_prologue(const uint32_t* __restrict__ ho
 // ones keep the two copy commands (megabytes over PCIe are the copy engines' job).
 static inline bool direct_results(uint32_t n) { return n <= 8; }
 
+// A small submission (the node's one-frame calls, up to eight 1080p frames) is about latency, not throughput: every cluster
+// is a workgroup's only one, the stage ends with its longest chain, and a launch more costs more than k_fit_small's shorter
+// chain per small cluster saves (measured: 0.54 against 0.47 ms per one-frame call).  Such a submission buckets all clusters
+// up to the one-wave class's bound into that class (work_layout_small) and launches no k_fit_small.
+static inline bool small_submission(const DetParams& P, uint32_t n) { return (uint64_t)n * (uint64_t)P.W * (uint64_t)P.H < (16ull << 20); }
+
 static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s, const std::function<void()>& mark) {
   DetParams P = D->P;
   P.frame0 = 0;
@@ -758,7 +820,8 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
   {
     const int nchunks = n >= 16 ? SEL_CHUNKS : 1;   // (see the kernel)
     hipLaunchKernelGGL(k_cluster_select, dim3((P.hcap + 1024 * nchunks - 1) / (1024 * nchunks), 1, n), dim3(256), 0, s, D->d_hkeys,
-                       D->d_hcnt, D->d_hoff, D->d_clusters, D->d_counters, D->d_work, D->d_workctl, D->work_layout, nchunks, P);
+                       D->d_hcnt, D->d_hoff, D->d_clusters, D->d_counters, D->d_work, D->d_workctl,
+                       small_submission(P, n) ? D->work_layout_small : D->work_layout, nchunks, P);
   }
   mark();
   {
@@ -792,13 +855,11 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
     // A small submission (the node's one-frame calls) is over when its slowest chain is: there the 256-thread class starts
     // at once beside the small classes (its in-kernel test after the first walk still drops most of its clusters) and
     // only the two largest classes wait for the prefilter -- prefilter, then the survivors' sort, was the longest chain.
-    const bool small = (uint64_t)n * (uint64_t)P.W * (uint64_t)P.H < (16ull << 20);
+    const bool small = small_submission(P, n);
     const int pf_first = small ? D->prefilter_class + 1 : D->prefilter_class;
     auto launch_prefilter = [&](hipStream_t sp) {
       if (!prefilter) return;
-#ifdef AMDAT_FQ_SKIP
-      if ((AMDAT_FQ_SKIP >> 5) & 1) return;
-#endif
+      if (FQ_SKIP_PREFILTER()) return;   // (tools_hooks.h: always 0 in the product build)
       // small submissions: one cluster per CU-wide workgroup (latency); otherwise one per wave (throughput)
       const bool wide = small;
 #define PF_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work, D->d_workctl, work2, D->d_workctl + 16, D->work_layout,   \
@@ -814,22 +875,29 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
       }
 #undef PF_ARGS
     };
-    auto launch_class = [&](int c, hipStream_t sc) {
+    auto launch_class = [&](int c, hipStream_t sc) -> bool {   // false: the class has no clusters on this handle, nothing was launched
       const FqClass& cl = D->cls[c];
-      if (P.max_cluster_points <= cl.lo || !cl.d_lf) return;
-#ifdef AMDAT_FQ_SKIP   // tools-only: leave out size classes (bits 0..4) or the prefilter (bit 5) to time the others alone
-      if ((AMDAT_FQ_SKIP >> c) & 1) return;
-#endif
+      if (P.max_cluster_points <= cl.lo || cl.hi <= cl.lo || (!cl.small_k && !cl.d_lf)) return false;
+      if (small && cl.small_k) return false;   // (their clusters are in the one-wave class's list: work_layout_small)
+      if (FQ_SKIP_CLASS(c)) return false;   // (tools_hooks.h: always 0 in the product build)
       const dim3 grid(cl.grid);   // (a submission of n < max_batch frames still gets the handle's persistent grid)
       const size_t lds = lds_bytes(cl);
       const bool big = c == FQ_NCLS - 1;
       // a small submission spreads its clusters over the workgroups one by one (latency); large ones pop in chunks
       const int pop = cl.pop < (int)(n / 16u) ? cl.pop : ((int)(n / 16u) < 1 ? 1 : (int)(n / 16u));
       const bool filtered = prefilter && c >= pf_first;
+      if (cl.small_k) {
+#define FS_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work + D->work_layout.off[c], D->d_workctl + c,               \
+                D->work_layout.cap[c], D->d_workctl + 8 + c, D->d_cands, D->d_counters, pop, P
+        if (cl.small_k == 2) hipLaunchKernelGGL(k_fit_small<2>, grid, dim3(64), FS_LDS_BYTES(2), sc, FS_ARGS);
+        else hipLaunchKernelGGL(k_fit_small<4>, grid, dim3(64), FS_LDS_BYTES(4), sc, FS_ARGS);
+#undef FS_ARGS
+        return true;
+      }
 #define FQ_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, (filtered ? work2 : D->d_work) + D->work_layout.off[c],                 \
                 D->d_workctl + (filtered ? 16 : 0) + c,                                                                                \
                 D->work_layout.cap[c], D->d_workctl + 8 + c, cl.d_lf, (big ? D->d_keys_scr : nullptr), cl.d_errs,                        \
-                D->d_cands, D->d_counters, (D->fq_counters ? D->d_fqprof + 8 * c : nullptr), cl.sort_cap, cl.slot_cap, pop, P
+                D->d_cands, D->d_counters, (D->fq_counters ? D->d_fqprof + 8 * (c - FQ_C0) : nullptr), cl.sort_cap, cl.slot_cap, pop, P
 #define FQ_LAUNCH(NTV)                                                                                          \
   if (P.split_moments) hipLaunchKernelGGL((k_fit_quads<NTV, true>), grid, dim3(NTV), lds, sc, FQ_ARGS);          \
   else hipLaunchKernelGGL((k_fit_quads<NTV, false>), grid, dim3(NTV), lds, sc, FQ_ARGS);
@@ -840,6 +908,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
       else { FQ_LAUNCH(FQ_NT_BIG) }
 #undef FQ_LAUNCH
 #undef FQ_ARGS
+      return true;
     };
     hipStream_t* aux = D->aux_stream;
     // (throughput-sized: from about 32 1080p working images on; below that the two extra dependent launches cost more
@@ -859,31 +928,36 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
       // side streams, beside the prefilter.
       if (!small) launch_prefilter(s);
       HIP_TRY(hipEventRecord(D->ev_fork, s));
-      for (int a = 0; a < 3; a++) HIP_TRY(hipStreamWaitEvent(aux[a], D->ev_fork, 0));
+      for (int a = 0; a < FQ_NAUX; a++) HIP_TRY(hipStreamWaitEvent(aux[a], D->ev_fork, 0));
       if (small) launch_prefilter(s);
       for (int c = pf_first; c < FQ_NCLS; c++) launch_class(c, s);   // (nearly all survivors are in the first of them)
-      for (int c = pf_first - 1, a = 0; c >= 0; c--, a++) launch_class(c, aux[a % 3]);   // the longest chains first
+      // the longest chains first; classes that launch nothing take no stream
+      int a = 0;
+      for (int c = pf_first - 1; c >= 0; c--)
+        if (launch_class(c, aux[a % FQ_NAUX])) a++;
     } else {
     if (large_first) {
-      launch_class(3, s);
-      launch_class(4, s);
-      if (AMDAT_FQ_ORDER == 1) launch_class(2, s);
+      launch_class(FQ_C0 + 3, s);
+      launch_class(FQ_C0 + 4, s);
+      if (AMDAT_FQ_ORDER == 1) launch_class(FQ_C0 + 2, s);
       HIP_TRY(hipEventRecord(D->ev_fork, s));   // both large classes are done
     }
-    for (int a = 0; a < 3; a++) HIP_TRY(hipStreamWaitEvent(aux[a], D->ev_fork, 0));
+    for (int a = 0; a < FQ_NAUX; a++) HIP_TRY(hipStreamWaitEvent(aux[a], D->ev_fork, 0));
     // (which small class shares the chip with which was measured over seven assignments: 16.0 - 16.9 ms; best when
     // the 256-thread class is the one that ends up running last)
     if (large_first) {
-      for (int c = 0; c < (AMDAT_FQ_ORDER == 1 ? 2 : 3); c++) launch_class(c, aux[c]);
+      for (int c = 0, a2 = 0; c < FQ_C0 + (AMDAT_FQ_ORDER == 1 ? 2 : 3); c++) if (launch_class(c, aux[a2 % FQ_NAUX])) a2++;
     } else {   // the longest chains side by side: the largest clusters | 4096..8192 then the one-wave class | the other two
-      launch_class(4, s);
-      launch_class(3, aux[0]);
-      launch_class(2, aux[1]);
-      launch_class(1, aux[2]);
-      launch_class(0, aux[0]);
+      launch_class(FQ_C0 + 4, s);
+      launch_class(FQ_C0 + 3, aux[0]);
+      launch_class(FQ_C0 + 2, aux[1]);
+      launch_class(FQ_C0 + 1, aux[2]);
+      launch_class(FQ_C0 + 0, aux[0]);
+      launch_class(1, aux[1]);
+      launch_class(0, aux[2]);
     }
     }
-    for (int a = 0; a < 3; a++) {
+    for (int a = 0; a < FQ_NAUX; a++) {
       HIP_TRY(hipEventRecord(D->ev_join[a], aux[a]));
       HIP_TRY(hipStreamWaitEvent(s, D->ev_join[a], 0));
     }
@@ -1010,6 +1084,7 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
                      const amdAprilTagsCameraIntrinsics_t* intr, uint32_t ostride, hipStream_t s) {
   DeviceGuard guard(D->device);
   if (!guard.ok) return AMDAT_HIP_ERROR;
+  if (D->unusable) return AMDAT_OUT_OF_MEMORY;   // (never launch on the half-allocated buffers of a failed regrowth)
   fill_frames(D, n, images, intr);   // image pointers, pitches and intrinsics travel through the pinned descriptor block
   D->last_n = n;
   if (ostride > D->P.dcap) ostride = D->P.dcap;
@@ -1021,7 +1096,7 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
       D->P.hcap = D->P.hcap * 2 > D->hcap_hard ? D->hcap_hard : D->P.hcap * 2;
       if (alloc_hash_buffers(D) != AMDAT_SUCCESS || alloc_point_buffers(D) != AMDAT_SUCCESS) {
         D->P.hcap = before; D->grow_hash = false;
-        if (alloc_hash_buffers(D) != AMDAT_SUCCESS || alloc_point_buffers(D) != AMDAT_SUCCESS) return AMDAT_OUT_OF_MEMORY;
+        if (alloc_hash_buffers(D) != AMDAT_SUCCESS || alloc_point_buffers(D) != AMDAT_SUCCESS) { D->unusable = true; return AMDAT_OUT_OF_MEMORY; }
       } else {
         D->grown++;
       }
@@ -1081,7 +1156,7 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
     if (grc != AMDAT_SUCCESS) {   // not enough memory to grow: keep reporting the overflow with the old capacities
       D->P.pcap = pcap_before; D->P.hcap = hcap_before;
       D->grow_points = false; D->grow_hash = false;
-      if (alloc_hash_buffers(D) != AMDAT_SUCCESS || alloc_point_buffers(D) != AMDAT_SUCCESS) return AMDAT_OUT_OF_MEMORY;
+      if (alloc_hash_buffers(D) != AMDAT_SUCCESS || alloc_point_buffers(D) != AMDAT_SUCCESS) { D->unusable = true; return AMDAT_OUT_OF_MEMORY; }
       return AMDAT_SUCCESS;
     }
     D->grown++;
@@ -1107,14 +1182,17 @@ int amdAprilTagsDetectBatchEx(amdAprilTagsHandle handle, uint32_t n, const amdAp
   return AMDAT_SUCCESS;
 }
 
-static void to_public(const DetRec& d, uint16_t family_enum, amdAprilTagsID_t* o) {
+static void to_public(const DetRec& d, uint16_t family_enum, uint32_t corner_convention, amdAprilTagsID_t* o) {
   memset(o, 0, sizeof(*o));
   o->id = (uint16_t)d.id;
-  // library-native corner order = message order = AprilRobotics p[3-i]
-  for (int i = 0; i < 4; i++) { o->corners[i].x = (float)d.p[3 - i][0]; o->corners[i].y = (float)d.p[3 - i][1]; }
+  // library-native corner order = message order = AprilRobotics p[3-i]; AMDAT_CORNERS_ROTATED_180 starts two corners later
+  // and turns the tag frame about its normal: R * Rz(pi) = R with its first two columns negated
+  const int turn = corner_convention == AMDAT_CORNERS_ROTATED_180 ? 2 : 0;
+  const double sgn = turn ? -1.0 : 1.0;
+  for (int i = 0; i < 4; i++) { o->corners[i].x = (float)d.p[(3 - i + turn) & 3][0]; o->corners[i].y = (float)d.p[(3 - i + turn) & 3][1]; }
   o->hamming_error = (uint16_t)d.hamming;
   for (int r = 0; r < 3; r++)
-    for (int c = 0; c < 3; c++) o->orientation[c * 3 + r] = (float)d.R[r * 3 + c];  // column-major
+    for (int c = 0; c < 3; c++) o->orientation[c * 3 + r] = (float)(c < 2 ? sgn * d.R[r * 3 + c] : d.R[r * 3 + c]);  // column-major
   for (int i = 0; i < 3; i++) o->translation[i] = (float)d.t[i];
   o->family = family_enum;
   o->decision_margin = d.decision_margin;
@@ -1138,7 +1216,7 @@ int amdAprilTagsDetectBatch(amdAprilTagsHandle handle, uint32_t n, const amdApri
     num_tags[f] = k;
     for (uint32_t i = 0; i < k; i++) {
       const DetRec& d = handle->h_out[(size_t)f * ostride + i];
-      to_public(d, (uint16_t)handle->cfg.families[d.family], &tags_out[(size_t)f * max_tags + i]);
+      to_public(d, (uint16_t)handle->cfg.families[d.family], handle->cfg.corner_convention, &tags_out[(size_t)f * max_tags + i]);
     }
   }
   return AMDAT_SUCCESS;
@@ -1306,26 +1384,7 @@ int amdAprilTagsDebugCopy(amdAprilTagsHandle handle, uint32_t frame, amdAprilTag
   return AMDAT_SUCCESS;
 }
 
-#ifdef AMDAT_FQ_TIMELINE
-// tools-only: returns and clears the quad fit's per-cluster wall-clock log (start tick, duration << 32 | threads << 20 | points)
-extern "C" int amdAprilTagsDebugTimelinePhases(unsigned int* out, unsigned int n) {   // call BEFORE amdAprilTagsDebugTimeline (which clears the log)
-  if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (n > (1u << 16)) n = 1u << 16;
-  if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fq_ph), (size_t)n * 32) != hipSuccess) return -1;
-  return (int)n;
-}
-extern "C" int amdAprilTagsDebugTimeline(unsigned long long* out, unsigned int cap) {
-  unsigned int n = 0;
-  if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_fq_tl_n), 4) != hipSuccess) return -1;
-  if (n > (1u << 16)) n = 1u << 16;
-  if (n > cap) n = cap;
-  if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fq_tl), (size_t)n * 16) != hipSuccess) return -1;
-  const unsigned int zero = 0;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(g_fq_tl_n), &zero, 4) != hipSuccess) return -1;
-  return (int)n;
-}
-#endif
+#include "tools_timeline.h"   // debug entry points of the -DAMDAT_FQ_TIMELINE tools build; empty in the product build
 
 int amdAprilTagsDebugMath(int op, uint32_t n, const double* a, const double* b, double* out) {
   if (!a || !b || !out || n == 0) return AMDAT_INVALID_ARGUMENT;

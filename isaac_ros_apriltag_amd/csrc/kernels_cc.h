@@ -154,9 +154,7 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   }
   __syncthreads();
 
-#if defined(AMDAT_CC_STOP) && AMDAT_CC_STOP == 1   // tools-only: instruction counts per phase
-  if (P.max_nmaxima == 10) return;
-#endif
+  CC_STOP_AT(1)   // (tools_hooks.h: nothing in the product build)
   // ---- 2. unions with the row above (only the first pixel of every overlap) -------------------
   // A lane has at most three links to the row above (up, up-left, up-right) and most lanes have none, so the link
   // requests of four rows at a time are compacted into a wave-private list (ballot + popcount, no atomics) and the
@@ -209,9 +207,7 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   }
   __syncthreads();
 
-#if defined(AMDAT_CC_STOP) && AMDAT_CC_STOP == 2
-  if (P.max_nmaxima == 10) return;
-#endif
+  CC_STOP_AT(2)
   // ---- 3. flatten into registers, then count pixels per root (one LDS atomic per run) ----------
   uint32_t root[16];
   for (int k = 0; k < 16; k++) {
@@ -238,9 +234,7 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   }
   __syncthreads();
 
-#if defined(AMDAT_CC_STOP) && AMDAT_CC_STOP == 3
-  if (P.max_nmaxima == 10) return;
-#endif
+  CC_STOP_AT(3)
   // ---- 4. write global labels (index of the local root), local sizes at the roots, root list -------
   uint32_t* label = label_all + (size_t)frame * W * H;
   uint32_t* csize = csize_all + (size_t)frame * W * H;

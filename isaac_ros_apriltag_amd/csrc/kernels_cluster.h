@@ -96,13 +96,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
                                                 FrameCounters* __restrict__ counters,
                                                 unsigned long long* __restrict__ prof, uint32_t gx_tiles, uint32_t gy_tiles, uint32_t nframes,
                                                 DetParams P) {
-#ifdef AMDAT_FQ_PROFILE   // tools-only: shader cycles per phase, prof[0..5] (tile load, emission tests + scan, list, block table, stores, frame table)
-#define PT_TICK(slot) if (prof && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&prof[slot], now_ - t_prev_); t_prev_ = now_; }
-  unsigned long long t_prev_ = prof ? __builtin_readcyclecounter() : 0ull;
-#else
-#define PT_TICK(slot)
-  (void)prof;
-#endif
+  PT_HOOKS_DECL   // (tools_hooks.h: measurement hooks, nothing in the product build)
   // tile + halo, one word per pixel: representative of the pixel's component if it is large enough, bit 31 = the pixel is
   // white; AT_NO_LABEL = no component that counts (value 127, or too small).  Two labelled pixels have different values
   // exactly when bit 31 differs, so the emission tests read this one array (a separate byte array of the values cost a
@@ -160,9 +154,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   tcnt[tid] = 0;
   __syncthreads();
   PT_TICK(0)
-#if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 1   // tools-only: instruction counts per phase (tools/pt_phase_insts.sh)
-  if (P.max_nmaxima == 10) return;
-#endif
+  PT_STOP_AT(1, (void)0)
 
   const int lx = tid & 63;
   const int gx = X0 + lx;
@@ -206,9 +198,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     if (tid == 0) bhdr_all[(size_t)frame * bpf + blk_] = make_uint2(0u, 0u);
     return;
   }
-#if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 2   // (pass 1's results are written out so that they stay live; into the staging buffer -- the rank array is not allocated when the staging record is packed)
-  if (P.max_nmaxima == 10) { stage_all[(size_t)frame * P.pcap + (blk_ % 64u) * 256 + tid] = emask ^ off; return; }
-#endif
+  PT_STOP_AT(2, stage_all[(size_t)frame * P.pcap + (blk_ % 64u) * 256 + tid] = emask ^ off)
   unsigned long long* hkeys = hkeys_all + (size_t)frame * P.hcap;
   uint32_t* hcnt = hcnt_all + (size_t)frame * P.hcap;
   if (tid == 0) sbase = atomicAdd(&counters[frame].npoints_raw, total);
@@ -224,9 +214,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   }
   __syncthreads();
   PT_TICK(2)
-#if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 4   // (after the list is built)
-  if (P.max_nmaxima == 10) { stage_all[(size_t)frame * P.pcap + (blk_ % 64u) * 256 + tid] = emask ^ off ^ elist[tid]; return; }
-#endif
+  PT_STOP_AT(4, stage_all[(size_t)frame * P.pcap + (blk_ % 64u) * 256 + tid] = emask ^ off ^ elist[tid])
   // pass 2, DENSE over the list (entry q belongs to thread q mod 256): pair key -> block table entry e (one insert), and
   // the emission's rank inside its (block, pair) group from the value the counting atomic returns -- on a full wave of
   // real emissions the returning LDS atomic costs what a leader loop over the wave's distinct entries does, and the
@@ -264,9 +252,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   }
   __syncthreads();
   PT_TICK(3)
-#if defined(AMDAT_PT_STOP) && AMDAT_PT_STOP == 3
-  if (P.max_nmaxima == 10) { stage_all[(size_t)frame * P.pcap + (blk_ % 64u) * 256 + tid] = emask ^ off ^ elist[tid] ^ sbase; return; }
-#endif
+  PT_STOP_AT(3, stage_all[(size_t)frame * P.pcap + (blk_ % 64u) * 256 + tid] = emask ^ off ^ elist[tid] ^ sbase)
   const uint32_t base = sbase;
   if (base + total > P.pcap) {
     if (tid == 0) atomicOr(&counters[frame].flags, 0x1u);
@@ -342,7 +328,8 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
 // (class c holds lo[c] < count <= hi[c]).  An item is (frame << 16) | cluster index.  k_cluster_select appends them as it
 // creates the cluster records; appends are aggregated per block in LDS, so every class counter sees one global atomic per
 // block.  (A separate k_worklist pass over the records cost a launch and a round trip through them.)
-#define FQ_NCLS 5
+#define FQ_NCLS 7
+#define FQ_C0 2     // classes 0 .. FQ_C0 - 1: k_fit_small (K = 2, 4); FQ_C0 ..: k_fit_quads (64 ... 1024 threads)
 struct FqWorkLayout {
   int lo[FQ_NCLS], hi[FQ_NCLS];
   uint32_t off[FQ_NCLS], cap[FQ_NCLS];   // item range of class c inside the work array

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(64, DW_WPE) void k_decode_wave(const FrameDesc* __r
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         const int b = (e + 1) & 3;
-        const double ex = (double)q.p[b][1] - (double)q.p[e][1], ey = -(double)q.p[b][0] + (double)q.p[e][0];
+        // (upstream: double nx = quad->p[b][1] - quad->p[a][1] with float p[][]: FLOAT operations, then widened)
+        const double ex = (double)(q.p[b][1] - q.p[e][1]), ey = (double)(-q.p[b][0] + q.p[e][0]);
         const double mag = __dsqrt_rn(ex * ex + ey * ey);
         int n = (int)(mag / 8);
         if (n < 16) n = 16;
@@ -84,8 +85,8 @@ __global__ __launch_bounds__(64, DW_WPE) void k_decode_wave(const FrameDesc* __r
           const int nsamples = edge == 0 ? ns[0] : edge == 1 ? ns[1] : edge == 2 ? ns[2] : ns[3];
           const int b = (edge + 1) & 3;
           const double pax = (double)s_p0[edge][0], pay = (double)s_p0[edge][1], pbx = (double)s_p0[b][0], pby = (double)s_p0[b][1];
-          double nx = pby - pay;
-          double ny = -pbx + pax;
+          double nx = (double)(s_p0[b][1] - s_p0[edge][1]);    // float differences, as upstream
+          double ny = (double)(-s_p0[b][0] + s_p0[edge][0]);
           const double mag = __dsqrt_rn(nx * nx + ny * ny);
           nx /= mag; ny /= mag;
           if (q.reversed_border) { nx = -nx; ny = -ny; }
@@ -248,8 +249,9 @@ __global__ __launch_bounds__(64, DW_WPE) void k_decode_wave(const FrameDesc* __r
           case 6: p0 = 0.5f; p1 = (float)wb + 0.5f; p2 = 1; p3 = 0; is_white = 1; break;
           default: p0 = 0.5f; p1 = (float)wb - 0.5f; p2 = 1; p3 = 0; is_white = 0; break;
         }
-        const double tagx01 = ((double)p0 + i * (double)p2) / wb;
-        const double tagy01 = ((double)p1 + i * (double)p3) / wb;
+        // upstream: (pattern[0] + i*pattern[2]) / (family->width_at_border) on float pattern[]: float multiply, add and DIVIDE
+        const double tagx01 = (double)__fdiv_rn(p0 + (float)i * p2, (float)wb);
+        const double tagy01 = (double)__fdiv_rn(p1 + (float)i * p3, (float)wb);
         const double tagx = 2 * (tagx01 - 0.5), tagy = 2 * (tagy01 - 0.5);
         double px, py;
         homography_project_dev(H, tagx, tagy, &px, &py);
@@ -346,13 +348,20 @@ __global__ __launch_bounds__(64, DW_WPE) void k_decode_wave(const FrameDesc* __r
         } else {
           DetRec det;
           det.family = fi; det.id = id; det.hamming = hamming; det.decision_margin = margin;
-          const double c = (rotation == 0) ? 1.0 : (rotation == 2) ? -1.0 : 0.0;
-          const double s = (rotation == 1) ? 1.0 : (rotation == 3) ? -1.0 : 0.0;
+          // H' = H * Rz(rotation * 90 deg) as upstream forms it: libm's cos / sin of rotation * M_PI / 2 (their correctly
+          // rounded values as literals: cos(pi/2) is 6.1e-17, not 0) and the full product of matd_op("M*M"), acc = 0, k = 0, 1, 2
+          const double c = (rotation == 0) ? 1.0 : (rotation == 1) ? 6.123233995736766e-17 : (rotation == 2) ? -1.0 : -1.8369701987210297e-16;
+          const double sn = (rotation == 0) ? 0.0 : (rotation == 1) ? 1.0 : (rotation == 2) ? 1.2246467991473532e-16 : -1.0;
+          const double Rz[9] = {c, -sn, 0.0, sn, c, 0.0, 0.0, 0.0, 1.0};
 #pragma unroll
           for (int r = 0; r < 3; r++) {
-            det.H[r * 3 + 0] = H[r * 3 + 0] * c + H[r * 3 + 1] * s;
-            det.H[r * 3 + 1] = H[r * 3 + 0] * -s + H[r * 3 + 1] * c;
-            det.H[r * 3 + 2] = H[r * 3 + 2];
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) {
+              double acc = 0;
+#pragma unroll
+              for (int k = 0; k < 3; k++) acc += H[r * 3 + k] * Rz[k * 3 + cc];
+              det.H[r * 3 + cc] = acc;
+            }
           }
           homography_project_dev(det.H, 0, 0, &det.c[0], &det.c[1]);
 #pragma unroll

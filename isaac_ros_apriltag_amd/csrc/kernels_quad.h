@@ -23,6 +23,7 @@
 // The product build carries neither.
 #pragma once
 #include "common.h"
+#include "tools_hooks.h"
 
 
 // ---- wave reductions on the DPP network (row_shr 1/2/4/8 inside each row of 16 lanes, then the row
@@ -615,12 +616,9 @@ __device__ __forceinline__ unsigned long long fq_minmax64(unsigned long long min
   return (unsigned long long)__double_as_longlong(keep_min ? mn : mx);
 }
 template <int K>
-__device__ __forceinline__ void fq_wave_sort(unsigned long long* A) {   // A: skewed LDS key array holding 64 K keys (pads included)
+__device__ __forceinline__ void fq_wave_sort_regs(unsigned long long (&v)[K]) {   // lane l holds keys l K .. l K + K - 1 of 64 K (pads included)
   constexpr int LK = K == 1 ? 0 : K == 2 ? 1 : K == 4 ? 2 : 3;
   const int lane = lane_id();
-  unsigned long long v[K];
-#pragma unroll
-  for (int j = 0; j < K; j++) v[j] = A[FQ_KP(lane * K + j)];
   auto ce = [](unsigned long long& lo, unsigned long long& hi) {
     const double a = __longlong_as_double((long long)lo), b = __longlong_as_double((long long)hi);
     double mn, mx;
@@ -664,6 +662,14 @@ __device__ __forceinline__ void fq_wave_sort(unsigned long long* A) {   // A: sk
       }
     }
   }
+}
+template <int K>
+__device__ __forceinline__ void fq_wave_sort(unsigned long long* A) {   // A: skewed LDS key array holding 64 K keys (pads included)
+  const int lane = lane_id();
+  unsigned long long v[K];
+#pragma unroll
+  for (int j = 0; j < K; j++) v[j] = A[FQ_KP(lane * K + j)];
+  fq_wave_sort_regs<K>(v);
 #pragma unroll
   for (int j = 0; j < K; j++) A[FQ_KP(lane * K + j)] = v[j];
 }
@@ -691,15 +697,18 @@ constexpr PairTable make_pair_table() {
   return t;
 }
 __device__ const PairTable g_pair_table = make_pair_table();
+// the same pair from its triangular index in registers (a table load from global memory sat in every cluster's
+// critical path: one more round trip of latency before the segment fits could start)
+__device__ __forceinline__ int fq_pair_of(int t) {
+  const int a = (t >= 9) + (t >= 17) + (t >= 24) + (t >= 30) + (t >= 35) + (t >= 39) + (t >= 42) + (t >= 44);
+  const int b = t - ((a * (19 - a)) >> 1) + a + 1;
+  return (a << 4) | b;
+}
 
 // Dynamic LDS layout: [0, 8*sort_cap) slope keys (later: raw/smoothed errors, then maxima candidates) |
 // FQ_TABLE_DOUBLES doubles for the group prefixes of the early-exit test (none in the one-wave class).  Clusters with size in (size_lo, size_hi] are processed by this
 // launch; those above sort_cap (only possible in the last class) sort in global scratch.
-#ifdef AMDAT_FQ_TIMELINE   // tools-only: wall-clock interval of every cluster a workgroup processes (tools/fit_timeline_one.py)
-__device__ unsigned long long g_fq_tl[1 << 16][2];
-__device__ unsigned int g_fq_ph[1 << 16][8];   // wall-clock ticks (10 ns) per phase of the same cluster (the FQ_TICK slots)
-__device__ unsigned int g_fq_tl_n;
-#endif
+FQ_TIMELINE_GLOBALS   // (tools_hooks.h: nothing in the product build)
 template <int NT, bool SPLIT>
 #ifndef FQ_EPT
 #define FQ_EPT(NT) ((NT) >= 256 ? 2 : 1)   // elements per lane in the moment sweep
@@ -773,42 +782,12 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
 
   for (int t = tid; t < 210; t += NT) s_combo[t] = g_combo_table.v[t];
 
-#ifdef AMDAT_FQ_PROFILE
-#define FQ_TICK(slot)                                                                  \
-  if (prof && tid == 0) {                                                              \
-    const unsigned long long now_ = __builtin_readcyclecounter();                      \
-    atomicAdd(&prof[slot], now_ - t_prev_);                                            \
-    t_prev_ = now_;                                                                    \
-  }
-  unsigned long long t_prev_ = prof ? __builtin_readcyclecounter() : 0ull;
-  // points of the clusters that reach the pre-sort test (0), that it rejects (1), that the test after the first walk
-  // rejects (2): prof[40 + 4 * class + k] (the launch passes prof + 8 * class)
-#define FQ_COUNT(k, n) if (prof && tid == 0) atomicAdd(&prof[40 - 4 * ((NT == 64) ? 0 : (NT == 128) ? 1 : (NT == 256) ? 2 : (NT == 512) ? 3 : 4) + (k)], (unsigned long long)(n));
-#elif defined(AMDAT_FQ_TIMELINE)
-#define FQ_TICK(slot) if (tid == 0) { const unsigned long long now_ = wall_clock64(); tl_ph_[slot] += (unsigned int)(now_ - tl_prev_); tl_prev_ = now_; }
-#define FQ_COUNT(k, n)
-  (void)prof;
-#else
-#define FQ_TICK(slot)
-#define FQ_COUNT(k, n)
-  (void)prof;
-#endif
-  // tools-only builds (-DAMDAT_FQ_STOP=n) drop every cluster after phase n, to count the instructions of the phases
-  // before it (tools/fq_phase_insts.sh); the product build has no such exit
-#ifdef AMDAT_FQ_STOP
-#define FQ_STOP_AT(n) if (AMDAT_FQ_STOP == (n) && P.max_nmaxima == 10) continue;
-#else
-#define FQ_STOP_AT(n)
-#endif
+  FQ_HOOKS_DECL   // measurement hooks (FQ_TICK / FQ_COUNT / FQ_STOP_AT / FQ_TL_*): tools_hooks.h, nothing in the product build
 
   // Work is popped `pop` clusters at a time: one device-scope atomic on a single word saturates near 90
   // returns per microsecond (MI355X_MICROARCH.md, "dequeue"), which a one-cluster pop of the small classes
   // (0.7 M clusters per 256-frame submission) would hit.
   uint32_t next_item = 0, chunk_left = 0;   // uniform
-#ifdef AMDAT_FQ_TIMELINE
-  unsigned long long tl_t0_ = 0, tl_prev_ = 0; unsigned int tl_sz_ = 0;
-  unsigned int tl_ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
   for (;;) {
     __syncthreads();   // the previous cluster's LDS use (and s_item) is finished in every wave
     if (chunk_left == 0) {
@@ -819,22 +798,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     }
     const uint32_t item = next_item++;
     chunk_left--;
-#ifdef AMDAT_FQ_TIMELINE
-    if (tid == 0) {
-      const unsigned long long now_ = wall_clock64();
-      if (tl_sz_) {
-        const unsigned int k_ = atomicAdd(&g_fq_tl_n, 1u);
-        if (k_ < (1u << 16)) {
-          g_fq_tl[k_][0] = tl_t0_; g_fq_tl[k_][1] = ((now_ - tl_t0_) << 32) | ((unsigned long long)NT << 20) | (unsigned long long)tl_sz_;
-#pragma unroll
-          for (int j_ = 0; j_ < 8; j_++) g_fq_ph[k_][j_] = tl_ph_[j_];
-        }
-      }
-      tl_t0_ = now_; tl_prev_ = now_; tl_sz_ = 0;
-#pragma unroll
-      for (int j_ = 0; j_ < 8; j_++) tl_ph_[j_] = 0;
-    }
-#endif
+    FQ_TL_NEXT_CLUSTER()
     if (item >= nwork) break;
     const uint32_t wi = (uint32_t)__builtin_amdgcn_readfirstlane((int)work[item]);
     const int frame = (int)(wi >> 16);
@@ -844,9 +808,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     const __attribute__((address_space(1))) uint8_t* const ggray = (const __attribute__((address_space(1))) uint8_t*)gray;   // global, not generic
     const ClusterRec cl = clusters_all[(size_t)frame * P.ccap + (wi & 0xFFFFu)];
     const int sz = (int)cl.count;
-#ifdef AMDAT_FQ_TIMELINE
-    tl_sz_ = (unsigned int)sz;
-#endif
+    FQ_TL_SIZE(sz)
     if (sz < 24 || sz > slot_cap) continue;   // (the work list only holds clusters of this class)
     FQ_TICK(0)
     const uint32_t* pts = pts_all + (size_t)frame * P.pcap + cl.start;
@@ -1546,7 +1508,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     __syncthreads();
     for (int task = tid; task < 90; task += NT) {
       const int t = task < 45 ? task : task - 45;
-      const int pr = g_pair_table.v[t], a = pr >> 4, b = pr & 15;   // a < b
+      const int pr = fq_pair_of(t), a = pr >> 4, b = pr & 15;   // a < b
       if (b < m) {
         double e, ms, lp[4];
         if (task < 45) {
@@ -1622,7 +1584,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
           } else if (lane == 4) {
             cd->key = cl.key;
             cd->reversed_border = q_reversed;
-            cd->pad = 0;
+            cd->wrap_is_moments = 0;
           }
         } else if (lane == 0) {
           atomicOr(&counters[frame].flags, AT_FLAG_CANDS);   // (internal: the host grows the list and repeats, or reports 0x8)
@@ -1631,8 +1593,6 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     }
     FQ_TICK(7)
   }
-#undef FQ_TICK
-#undef FQ_COUNT
 }
 
 // ---- k_fit_prefilter: the cheap exits of the quad fit for the clusters of the large classes, ahead of k_fit_quads ---------
@@ -1666,13 +1626,7 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
   __shared__ int s_feasible;
   const int tid = threadIdx.x;
   const int W = P.W, H = P.H;
-#ifdef AMDAT_FQ_PROFILE   // tools-only: shader cycles per phase (prof[60..63]: box + dot, sector sums, scan + 32-sector test, 64-sector test)
-#define PF_TICK(slot) if (prof && tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&prof[slot], now_ - t_prev_); t_prev_ = now_; }
-  unsigned long long t_prev_ = prof ? __builtin_readcyclecounter() : 0ull;
-#else
-#define PF_TICK(slot)
-  (void)prof;
-#endif
+  PF_HOOKS_DECL   // (tools_hooks.h)
   // items of the classes first_class .. FQ_NCLS - 1, largest class first
   uint32_t cnt[FQ_NCLS], total = 0;
 #pragma unroll
@@ -1850,7 +1804,13 @@ __global__ __launch_bounds__(256) void k_quad_finish(const FitCand* __restrict__
   uint32_t ncand = counters[frame].ncand;
   if (ncand > P.cand_cap) ncand = P.cand_cap;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < ncand; i += gridDim.x * 256) {
-    const FitCand cd = cands_all[(size_t)frame * P.cand_cap + i];
+    FitCand cd = cands_all[(size_t)frame * P.cand_cap + i];
+    if (cd.wrap_is_moments) {
+      // k_fit_small hands over the six moments of the wrap-around segment instead of its line: the same fit, here
+      double lp[4];
+      fit_line_moments(cd.line[3][0], cd.line[3][1], cd.line[3][2], cd.line[3][3], cd.wm[0], cd.wm[1], 0, lp, nullptr, nullptr);
+      cd.line[3][0] = lp[0]; cd.line[3][1] = lp[1]; cd.line[3][2] = lp[2]; cd.line[3][3] = lp[3];
+    }
     float corner[4][2];
     bool ok = true;
 #pragma unroll
@@ -1872,9 +1832,10 @@ __global__ __launch_bounds__(256) void k_quad_finish(const FitCand* __restrict__
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int i1 = (k + 1) & 3, i2 = (k + 2) & 3;
-      const double ax = corner[k][0], ay = corner[k][1];
-      const double bx = corner[i1][0], by = corner[i1][1], cx2 = corner[i2][0], cy2 = corner[i2][1];
-      const double dx1 = bx - ax, dy1 = by - ay, dx2 = cx2 - bx, dy2 = cy2 - by;
+      // upstream: double dx1 = quad->p[i1][0] - quad->p[i0][0] and sq(quad->p[b][0] - quad->p[a][0]) with float p[][]:
+      // the corner differences are FLOAT operations, widened afterwards
+      const double dx1 = (double)(corner[i1][0] - corner[k][0]), dy1 = (double)(corner[i1][1] - corner[k][1]);
+      const double dx2 = (double)(corner[i2][0] - corner[i1][0]), dy2 = (double)(corner[i2][1] - corner[i1][1]);
       const double q1 = dx1 * dx1 + dy1 * dy1;
       len[k] = __dsqrt_rn(q1);
       const double cos_dtheta = (dx1 * dx2 + dy1 * dy2) / __dsqrt_rn(q1 * (dx2 * dx2 + dy2 * dy2));
@@ -1882,8 +1843,9 @@ __global__ __launch_bounds__(256) void k_quad_finish(const FitCand* __restrict__
     }
     double area = 0;
     {
-      const double ax = corner[0][0], ay = corner[0][1], px2 = corner[2][0], py2 = corner[2][1];
-      const double ed = __dsqrt_rn((ax - px2) * (ax - px2) + (ay - py2) * (ay - py2));
+      // diagonal: triangle (0,1,2) takes it as p[0] - p[2], triangle (2,3,0) as p[2] - p[0]; float differences negate exactly
+      const double ddx = (double)(corner[0][0] - corner[2][0]), ddy = (double)(corner[0][1] - corner[2][1]);
+      const double ed = __dsqrt_rn(ddx * ddx + ddy * ddy);
 #pragma unroll
       for (int t = 0; t < 2; t++) {   // triangle (0,1,2): sides len0, len1, diagonal; triangle (2,3,0): len2, len3, diagonal
         const double sa = len[2 * t], sb = len[2 * t + 1];

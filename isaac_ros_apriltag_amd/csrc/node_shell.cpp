@@ -351,8 +351,13 @@ struct AprilTagMultiCameraNode::Impl {
   struct Slot { bool pending = false; Header info_header; std::array<double, 9> k{}; };
   std::vector<Slot> slots;
 
+  float handle_skew = 0.0f;        // K[1] the handle was created with (VPI mode; the batch ABI carries fx, fy, cx, cy per frame, no skew)
+
   void Initialize(const CameraInfo& info) {
     if (opt.max_tags <= 0) throw std::runtime_error("'max_tags' must be positive");
+    // left over from an attempt that threw after the handle existed (e.g. the slot allocation failed)
+    if (detector) { api().destroy(detector); detector = nullptr; }
+    if (d_mono) { api().dev_free(d_mono); d_mono = nullptr; }
     amdAprilTagsConfig_t cfg;
     api().default_config(&cfg, info.width, info.height);
     cfg.tile_size = opt.tile_size;
@@ -363,7 +368,8 @@ struct AprilTagMultiCameraNode::Impl {
     cfg.intrinsics.fy = static_cast<float>(info.k[4]);
     cfg.intrinsics.cx = static_cast<float>(info.k[2]);
     cfg.intrinsics.cy = static_cast<float>(info.k[5]);
-    cfg.skew = cuapriltags_mode ? 0.0f : static_cast<float>(info.k[1]);   // (one skew per handle: the first stream's)
+    // one skew per handle -- the first stream's; a stream whose K[1] differs is refused frame by frame (CameraImageCallback)
+    cfg.skew = handle_skew = cuapriltags_mode ? 0.0f : static_cast<float>(info.k[1]);
     cfg.tag_size = static_cast<float>(opt.size);
     cfg.max_batch = S;
     const int error = api().create_ex(&detector, &cfg);
@@ -440,8 +446,17 @@ bool AprilTagMultiCameraNode::CameraImageCallback(uint32_t stream, const Image& 
   if (image.header.stamp.sec != camera_info.header.stamp.sec || image.header.stamp.nanosec != camera_info.header.stamp.nanosec)
     return false;  // ExactTime synchroniser would not fire
   if (!impl_->initialized) impl_->Initialize(camera_info);
-  if (!impl_->Stage(stream, image, camera_info)) return false;
+  if (!impl_->cuapriltags_mode && static_cast<float>(camera_info.k[1]) != impl_->handle_skew) {
+    // S independent nodes would each pass their own skew (src/apriltag_node.cpp:215-225); one batched handle has one
+    std::fprintf(stderr, "[apriltag_node] stream %u: camera skew K[1] = %g differs from the handle's %g: frame dropped\n", stream,
+                 camera_info.k[1], static_cast<double>(impl_->handle_skew));
+    return false;
+  }
   Impl::Slot& sl = impl_->slots[stream];
+  // the slot's device image is about to be overwritten: a frame staged earlier and not yet submitted is gone either way,
+  // and a failed staging must not leave it pending under its old header
+  sl.pending = false;
+  if (!impl_->Stage(stream, image, camera_info)) return false;
   sl.pending = true;
   sl.info_header = camera_info.header;
   sl.k = camera_info.k;

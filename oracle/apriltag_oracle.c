@@ -29,7 +29,9 @@ void ato_default_params(ato_params_t* p) {
   p->min_component_size = 25;
   p->min_cluster_points = 24;
   p->max_nmaxima = 10;
-  p->cos_critical_rad = 0x1.f838b8c811c17p-1; /* cos(10 deg) */
+  /* cos(10 deg) as upstream holds it: apriltag_quad_thresh_params.cos_critical_rad is a FLOAT field, so both angle
+   * tests compare against (double)(float)cos(10 * M_PI / 180) */
+  p->cos_critical_rad = (double)(float)0x1.f838b8c811c17p-1;
   p->max_line_fit_mse = 10.0;
   p->refine_edges = 1;
   p->decode_sharpening = 0.25;
@@ -458,7 +460,7 @@ static int quad_segment_maxima(const ato_params_t* prm, const lfp_t* lfps, int s
     double best_error = (double)HUGE_VALF;
     g_qsm_reason = 4;
     double err01, err12, err23, err30, mse01, mse12, mse23, mse30, p01[4], p12[4];
-    double max_dot = (prm->variant & ATO_VAR_FLOAT_COS) ? (double)(float)prm->cos_critical_rad : prm->cos_critical_rad;
+    double max_dot = prm->cos_critical_rad;
     for (int m0 = 0; m0 < nmaxima - 3; m0++) {
       int i0 = maxima[m0];
       for (int m1 = m0 + 1; m1 < nmaxima - 2; m1++) {
@@ -780,7 +782,8 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
     double area = 0, length[3], p;
     for (int i = 0; i < 3; i++) {
       int a = i, b = (i + 1) % 3;
-      double ddx = (double)quad->p[b][0] - (double)quad->p[a][0], ddy = (double)quad->p[b][1] - (double)quad->p[a][1];
+      /* upstream: sq(quad->p[b][0] - quad->p[a][0]) with float p[][] -- the difference is a FLOAT operation, widened for sq() */
+      double ddx = (double)(quad->p[b][0] - quad->p[a][0]), ddy = (double)(quad->p[b][1] - quad->p[a][1]);
       length[i] = sqrt(ddx * ddx + ddy * ddy);
     }
     p = (length[0] + length[1] + length[2]) / 2;
@@ -788,7 +791,8 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
     static const int idxs[4] = {2, 3, 0, 2};
     for (int i = 0; i < 3; i++) {
       int a = idxs[i], b = idxs[i + 1];
-      double ddx = (double)quad->p[b][0] - (double)quad->p[a][0], ddy = (double)quad->p[b][1] - (double)quad->p[a][1];
+      /* upstream: sq(quad->p[b][0] - quad->p[a][0]) with float p[][] -- the difference is a FLOAT operation, widened for sq() */
+      double ddx = (double)(quad->p[b][0] - quad->p[a][0]), ddy = (double)(quad->p[b][1] - quad->p[a][1]);
       length[i] = sqrt(ddx * ddx + ddy * ddy);
     }
     p = (length[0] + length[1] + length[2]) / 2;
@@ -797,10 +801,11 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
   }
   for (int i = 0; i < 4; i++) {
     int i0 = i, i1 = (i + 1) & 3, i2 = (i + 2) & 3;
-    double dx1 = (double)quad->p[i1][0] - (double)quad->p[i0][0], dy1 = (double)quad->p[i1][1] - (double)quad->p[i0][1];
-    double dx2 = (double)quad->p[i2][0] - (double)quad->p[i1][0], dy2 = (double)quad->p[i2][1] - (double)quad->p[i1][1];
+    /* upstream: double dx1 = quad->p[i1][0] - quad->p[i0][0]; -- float differences, then widened */
+    double dx1 = (double)(quad->p[i1][0] - quad->p[i0][0]), dy1 = (double)(quad->p[i1][1] - quad->p[i0][1]);
+    double dx2 = (double)(quad->p[i2][0] - quad->p[i1][0]), dy2 = (double)(quad->p[i2][1] - quad->p[i1][1]);
     double cos_dtheta = (dx1 * dx2 + dy1 * dy2) / sqrt((dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2));
-    const double cos_crit = (prm->variant & ATO_VAR_FLOAT_COS) ? (double)(float)prm->cos_critical_rad : prm->cos_critical_rad;
+    const double cos_crit = prm->cos_critical_rad;
     if ((cos_dtheta > cos_crit || cos_dtheta < -cos_crit) || dx1 * dy2 < dy1 * dx2) { ATO_STAT(9, sz_in); goto finish; }
   }
   res = 1;
@@ -820,8 +825,9 @@ static void refine_edges(const ato_params_t* prm, const uint8_t* im, int w, int 
   double lines[4][4];
   for (int edge = 0; edge < 4; edge++) {
     int a = edge, b = (edge + 1) & 3;
-    double nx = (double)quad->p[b][1] - (double)quad->p[a][1];
-    double ny = -(double)quad->p[b][0] + (double)quad->p[a][0];
+    /* upstream: double nx = quad->p[b][1] - quad->p[a][1]; double ny = -quad->p[b][0] + quad->p[a][0]; -- float operations */
+    double nx = (double)(quad->p[b][1] - quad->p[a][1]);
+    double ny = (double)(-quad->p[b][0] + quad->p[a][0]);
     double mag = sqrt(nx * nx + ny * ny);
     nx /= mag; ny /= mag;
     if (quad->reversed_border) { nx = -nx; ny = -ny; }
@@ -1027,8 +1033,10 @@ static float quad_decode(const ato_params_t* prm, const ato_family_t* fam, const
     const float* pat = &patterns[pi * 5];
     int is_white = (int)pat[4];
     for (int i = 0; i < wb; i++) {
-      double tagx01 = ((double)pat[0] + i * (double)pat[2]) / wb;
-      double tagy01 = ((double)pat[1] + i * (double)pat[3]) / wb;
+      /* upstream: (pattern[0] + i*pattern[2]) / (family->width_at_border) with float pattern[] and int operands: float
+       * multiplication, addition and DIVISION (exact for width 8, not for 5, 6, 7, 9 ...), then widened */
+      double tagx01 = (double)((pat[0] + (float)i * pat[2]) / (float)wb);
+      double tagy01 = (double)((pat[1] + (float)i * pat[3]) / (float)wb);
       double tagx = 2 * (tagx01 - 0.5), tagy = 2 * (tagy01 - 0.5);
       double px, py;
       homography_project(H, tagx, tagy, &px, &py);
@@ -1360,17 +1368,16 @@ int ato_detect(const ato_params_t* prm, const ato_family_t* fams, int nfam, cons
       ato_detection_t* det = &dets[nd++];
       memset(det, 0, sizeof(*det));
       det->family = fi; det->id = id; det->hamming = hamming; det->decision_margin = margin;
-      /* H' = H * Rz(rotation * 90 deg), with exact {0,+-1} entries */
-      static const double CS[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};
-      double c = CS[rotation][0], s = CS[rotation][1];
-      for (int r = 0; r < 3; r++) {
-        det->H[r * 3 + 0] = H[r * 3 + 0] * c + H[r * 3 + 1] * s;
-        det->H[r * 3 + 1] = H[r * 3 + 0] * -s + H[r * 3 + 1] * c;
-        det->H[r * 3 + 2] = H[r * 3 + 2];
-      }
-      if (prm->variant & ATO_VAR_TRIG_RZ) {   /* upstream: R from libm's cos / sin, full matrix product (matd_op "M*M") */
-        const double theta = rotation * M_PI / 2.0;
-        const double Rz[9] = {cos(theta), -sin(theta), 0, sin(theta), cos(theta), 0, 0, 0, 1};
+      /* H' = H * Rz(rotation * 90 deg) as upstream forms it: c = cos(theta), s = sin(theta) of theta = rotation * M_PI / 2.0
+       * from libm -- the correctly rounded values are written out as literals (cos(pi/2) is 6.1e-17, not 0) -- and the full
+       * 3x3 product of matd_op("M*M"): acc = 0; acc += a[i][k] * b[k][j] for k = 0, 1, 2 */
+      static const double CS[4][2] = {{1.0, 0.0},
+                                      {6.123233995736766e-17, 1.0},
+                                      {-1.0, 1.2246467991473532e-16},
+                                      {-1.8369701987210297e-16, -1.0}};
+      {
+        const double c = CS[rotation][0], sn = CS[rotation][1];
+        const double Rz[9] = {c, -sn, 0, sn, c, 0, 0, 0, 1};
         for (int r = 0; r < 3; r++)
           for (int cc = 0; cc < 3; cc++) {
             double acc = 0;

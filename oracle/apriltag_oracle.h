@@ -69,12 +69,10 @@ typedef struct {
 #define ATO_VAR_ATAN_NORMAL 2  /* refine_edges: normal = (cosf, sinf) of 0.5*atan2f(-2Cxy, Cyy-Cxx) */
 #define ATO_VAR_SVD_POLAR 4    /* homography_to_pose: R = U V^T from the SVD instead of Newton steps */
 #define ATO_VAR_FLOAT_DOT 8    /* fit_quad: border-direction dot accumulated in float, point by point */
-#define ATO_VAR_FLOAT_COS 16   /* quad_thresh_params.cos_critical_rad is a float field upstream: both angle tests compare
-                                * against (double)(float)cos(10 deg) instead of the double */
+/* (16 was FLOAT_COS: upstream's float cos_critical_rad is the definition now) */
 #define ATO_VAR_AT3_BIT_ORDER 32 /* quad_decode: white/black scores (floats) accumulated in AprilTag 3's bit order (four
                                 * rotated quadrant triangles, centre bit last) instead of row-major */
-#define ATO_VAR_TRIG_RZ 64     /* det->H = H * Rz with c = cos(rotation*M_PI/2), s = sin(...) from libm (cos(pi/2) = 6.1e-17)
-                                * and a full 3x3 product, instead of exact {0, +-1} entries */
+/* (64 was TRIG_RZ: H * Rz with libm's cos / sin values and the full 3x3 product is the definition now) */
 
 typedef struct {
   int32_t family;   /* index into the family list */

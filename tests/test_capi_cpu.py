@@ -120,9 +120,20 @@ def test_register_layout_family():
     bx, by = fl.standard_layout(9, 5)            # 41 bits: outer ring of a 9 x 9 grid + the 3 x 3 inside the 5 x 5 border
     assert len(bx) == 41
     codes = fl.toy_codes(41, 6, seed=3)
-    capi.register_family_ex(5, "custom48h12", bx, by, 5, 9, True, codes)   # (a name no other test expects to be missing)
-    assert L.amdAprilTagsFamilyFromName(b"custom48h12") == 5
-    assert capi.family_info("custom48h12")["codes"] == codes
+    # (the process-wide registry is left as it was found: other tests assert that these names are unknown)
+    try:
+        capi.register_family_ex(5, "custom48h12", bx, by, 5, 9, True, codes)
+        assert L.amdAprilTagsFamilyFromName(b"custom48h12") == 5
+        assert capi.family_info("custom48h12")["codes"] == codes
+    finally:
+        capi.unregister_family(5)
+    assert L.amdAprilTagsFamilyFromName(b"custom48h12") == -1
+    with pytest.raises(capi.AprilTagsError):     # a code word with a bit above the family's 41
+        capi.register_family_ex(6, "bad", bx, by, 5, 9, True, codes[:-1] + [codes[-1] | (1 << 41)])
+    with pytest.raises(capi.AprilTagsError):     # a name the slot cannot hold whole
+        capi.register_family_ex(6, "n" * 32, bx, by, 5, 9, True, codes)
+    with pytest.raises(capi.AprilTagsError):     # built-in slots cannot be emptied
+        capi.unregister_family(0)
     with pytest.raises(capi.AprilTagsError):     # one cell moved: no longer maps onto itself
         capi.register_family_ex(6, "bad", [bx[0] + 1] + bx[1:], by, 5, 9, True, codes)
     with pytest.raises(capi.AprilTagsError):     # repeated cell

@@ -167,6 +167,33 @@ def test_reference_pol_golden_through_c_abi(built):
         assert np.abs(R - np.diag([-1.0, -1.0, 1.0])).max() <= 0.02   # quaternion (0,0,0,1)
 
 
+def test_corner_convention_switch(built):
+    """amdAprilTagsConfig_t.corner_convention (the 180-degree reading of the reference's golden frame
+    is an inference, so the other reading stays selectable): AMDAT_CORNERS_ROTATED_180 returns the same detections with the
+    corner index turned by two and the orientation multiplied by Rz(pi) from the right; everything else is unchanged, and
+    an unknown value is refused at creation."""
+    img, K, _ = synth.scene_c2(seed=1234, sigma=2.0)
+    t = torch.from_numpy(img).cuda()
+    out = []
+    for conv in (0, 1):
+        det = AprilTagDetector(1920, 1080, intrinsics=_k4(K), tag_size=0.22, max_batch=1, corner_convention=conv)
+        tags, cnt = det.detect_batch_raw(t, max_tags=64)
+        det.close()
+        out.append([tags[i] for i in range(cnt[0])])
+    a, b = out
+    assert len(a) == len(b) == 10
+    for x, y in zip(a, b):
+        assert (x.id, x.family, x.hamming_error) == (y.id, y.family, y.hamming_error)
+        for i in range(4):
+            assert (x.corners[i].x, x.corners[i].y) == (y.corners[(i + 2) & 3].x, y.corners[(i + 2) & 3].y)
+        Rx = np.array(list(x.orientation)).reshape(3, 3).T
+        Ry = np.array(list(y.orientation)).reshape(3, 3).T
+        assert np.array_equal(Ry, Rx @ np.diag([-1.0, -1.0, 1.0]))
+        assert list(x.translation) == list(y.translation) and (x.center.x, x.center.y) == (y.center.x, y.center.y)
+    with pytest.raises(capi.AprilTagsError):
+        AprilTagDetector(1920, 1080, intrinsics=_k4(K), corner_convention=2)
+
+
 def _bt601(rgb):
     """numpy statement of the conversion: Y = (4899 R + 9617 G + 1868 B + 8192) >> 14 (the 14-bit fixed-point
     BT.601 weights 0.299 / 0.587 / 0.114 that cv_bridge / OpenCV apply for the reference's mono8 test input)."""
@@ -565,6 +592,7 @@ def test_cpp_multi_stream_host(built, tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["gpus"] == 1 and rec["streams"] == S and len(rec["streams_out"]) == S
+    assert len(rec["per_gpu_seconds"]) == 1 and rec["per_gpu_seconds"][0] > 0
 
     def fnv(h, data):
         for byte in data:
@@ -614,6 +642,8 @@ def test_bench_two_ranks_on_one_gpu(built):
     assert cfg["world_size_seen_by_gloo"] == 2 and cfg["streams"] == 8 and cfg["streams_per_gpu"] == 4
     assert cfg["frames_per_step_per_gpu"] == 32
     assert rec["parity_gate"] == "pass"
+    assert rec["parity_gate_frames_per_rank"] == [32, 32]        # every rank gated on every frame of its batch
+    assert len(cfg["per_rank_fps"]["ranks"]) == 2 and cfg["per_rank_fps"]["min"] > 0
     assert rec["value"] > 0 and abs(rec["value"] - 2 * 32 / (rec["ms_per_step"] * 1e-3)) < 0.01 * rec["value"]
 
 
@@ -634,6 +664,38 @@ def test_c99_example_runs(built, tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "1 detection(s)" in r.stdout and r.stdout.startswith("id 0 ")
+
+
+def test_tag36h11_registered_in_apriltag3_encoding(built):
+    """tag36h11 the way AprilTag 3 publishes it -- quadrant-spiral bit_x / bit_y and its own code words (the head of
+    tag36h11.c is asserted in tests/test_families_cpu.py) -- registered through amdAprilTagsRegisterFamilyEx must decode
+    frames rendered from the built-in row-major table to the same ids, corners and poses as the built-in family, and
+    bit for bit what the oracle returns for the same descriptor."""
+    import family_layouts as fl
+    from isaac_ros_apriltag_amd import capi
+    bx, by = fl.classic_spiral_layout(6)
+    codes, _ = synth.family_codes("tag36h11")
+    at3 = [fl.reencode(c, 6, bx, by) for c in codes]
+    assert at3[:len(fl.AT3_TAG36H11_HEAD)] == fl.AT3_TAG36H11_HEAD
+    capi.register_family_ex(6, "tag36h11_at3", bx, by, 8, 10, False, at3)
+    ofam = po.custom_family("tag36h11_at3", bx, by, 8, 10, False, at3)
+    img, K = synth.scene_c2_ids(ids=[0, 7, 100, 137, 298, 333, 402, 511, 560, 586], seed=1302, sigma=2.0)[:2]
+    t = torch.from_numpy(img).cuda()
+    res = {}
+    for name, ofm in (("tag36h11", "tag36h11"), ("tag36h11_at3", ofam)):
+        det = AprilTagDetector(1920, 1080, families=(name,), intrinsics=_k4(K), max_batch=1)
+        g = det.detect_batch_ex(t, max_dets=64)[0]
+        errs, odets = pu.compare_stages(det, 0, img, (ofm,), K, 1)
+        errs += pu.compare_detections(g, odets)
+        assert not errs, (name, errs[:4])
+        det.close()
+        res[name] = g
+    a, b = res["tag36h11"], res["tag36h11_at3"]
+    assert sorted(d["id"] for d in a) == [0, 7, 100, 137, 298, 333, 402, 511, 560, 586]
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert (x["id"], x["hamming"]) == (y["id"], y["hamming"])
+        assert np.array_equal(x["p"], y["p"]) and np.array_equal(x["R"], y["R"]) and np.array_equal(x["t"], y["t"])
 
 
 def test_apriltag3_layout_families(built):
@@ -818,6 +880,22 @@ def test_multi_camera_node(built):
               % (t_single * 1e3, S / t_single, t_multi * 1e3, S / t_multi))
         assert multi.last(3)[0] == want[3]
         assert t_multi < t_single
+        # VPI mode passes the skew K[1] (apriltag_node.cpp:215-225) and one batched handle has one skew: a stream whose
+        # K[1] differs from the handle's is refused, and a refused frame leaves nothing pending under an older header
+        vpi = node.AprilTagMultiCameraNode(2, backends="CPU", auto_flush=False)
+        try:
+            Ksk = list(Ks[0]); Ksk[1] = 2.5
+            assert vpi.on_frame(0, frames[0].ctypes.data, False, "mono8", 1920, 1080, 1920, Ksk, "cam0", (40, 0))
+            assert vpi.on_frame(1, frames[1].ctypes.data, False, "mono8", 1920, 1080, 1920, Ksk, "cam1", (40, 1))
+            Kother = list(Ks[1]); Kother[1] = 0.5
+            assert not vpi.on_frame(1, frames[1].ctypes.data, False, "mono8", 1920, 1080, 1920, Kother, "cam1", (41, 1))
+            assert vpi.flush() == 2 and vpi.last(1)[2] == (40, 1) and len(vpi.last(0)[0]) == 10
+            # a frame that fails staging (wrong size) drops what the slot held
+            assert vpi.on_frame(0, frames[0].ctypes.data, False, "mono8", 1920, 1080, 1920, Ksk, "cam0", (42, 0))
+            assert not vpi.on_frame(0, frames[0].ctypes.data, False, "mono8", 1280, 720, 1280, Ksk, "cam0", (43, 0))
+            assert vpi.flush() == 0
+        finally:
+            vpi.close()
     finally:
         multi.close()
         for n_ in singles:

@@ -48,15 +48,21 @@ def test_supported_tag_family(node_mod):
     # tag36h10 table (the offline regeneration does not reproduce the published 2320 codes), so without one the shell
     # refuses the family with the reference's message; once the host has registered a table under that name -- here a
     # stand-in of three 36-bit words -- the reference's case constructs.
+    registered = False
     if not _have_36h10():
         with pytest.raises(RuntimeError) as e:
             node_mod.AprilTagNode(tag_family="tag36h10", backends="CPU")
         assert MSG in str(e.value)
+        registered = True
         capi.register_family(capi.SLOT_TAG36H10, "tag36h10", 6, [0x1a42f9469, 0xd5d628584 ^ 0x5a5a5a5a5, 0x3c3c3c3c3])
-    assert _have_36h10()
-    node_mod.AprilTagNode(tag_family="tag36h10", backends="CPU").close()
-    with pytest.raises(RuntimeError):            # still not a cuAprilTags family
-        node_mod.AprilTagNode(tag_family="tag36h10", backends="CUDA")
+    try:
+        assert _have_36h10()
+        node_mod.AprilTagNode(tag_family="tag36h10", backends="CPU").close()
+        with pytest.raises(RuntimeError):            # still not a cuAprilTags family
+            node_mod.AprilTagNode(tag_family="tag36h10", backends="CUDA")
+    finally:
+        if registered:   # the stand-in table does not outlive the test (the registry is process-wide)
+            capi.unregister_family(capi.SLOT_TAG36H10)
 
 
 def test_defaults_and_vpi_families(node_mod):
