@@ -3,6 +3,7 @@
 //
 // Replaces the closed cuAprilTags calls of the reference node
 // (src/apriltag_node.cpp:450-452 create, :491-493 detect, :556 destroy).  gfx950 only.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -96,6 +97,23 @@ void init_families() {
 }
 
 bool is_registrable_slot(int slot) { return slot == AMDAT_TAG36H10 || (slot >= AMDAT_CUSTOM0 && slot < AMDAT_ENUM_SIZE); }
+
+// roctx ranges around the stages, behind the profiling switch: the marker library is looked up at run
+// time the first time profiling is on (libroctx64.so ships with ROCm; a host without it simply gets no ranges), so the
+// product library has no link-time dependency on the tracing stack and an unprofiled call never touches it.
+struct RoctxApi {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  RoctxApi() {
+    void* h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_LOCAL);
+    if (!h) h = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_LOCAL);
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop) { push = nullptr; pop = nullptr; }
+  }
+};
+static const RoctxApi& roctx() { static const RoctxApi api; return api; }
 
 const char* kStageNames[AMDAT_NUM_STAGES] = {"upload_clear", "threshold", "cc_local",  "cc_border",
                                              "cc_sizes",   "points",    "cluster_select", "scatter",
@@ -1011,7 +1029,16 @@ static int enqueue_submission(amdAprilTagsDetector_st* D, uint32_t n, uint32_t o
 static int run_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s) {
   const bool prof = D->profiling;
   int evi = 0;
-  const std::function<void()> mark = [&]() { if (prof) hipEventRecord(D->ev[evi++], s); };
+  // profiling: one HIP event per stage boundary, and a roctx range per stage (it spans the stage's enqueues; rocprofv3
+  // --marker-trace shows them beside the kernels they launched)
+  const std::function<void()> mark = [&]() {
+    if (!prof) return;
+    if (roctx().push) {
+      if (evi > 0) roctx().pop();
+      if (evi < AMDAT_NUM_STAGES) roctx().push(kStageNames[evi]);
+    }
+    hipEventRecord(D->ev[evi++], s);
+  };
   const std::function<void()> nomark = []() {};
 
   // Small submissions (the node's one-frame calls) are launch-bound: ~20 enqueues for well under a millisecond of

@@ -705,6 +705,145 @@ __device__ __forceinline__ int fq_pair_of(int t) {
   return (a << 4) | b;
 }
 
+// ---- the tail of the fit, shared by k_fit_quads and k_fit_small: segment fits between the selected maxima and the search over
+// the corner choices ---------------------------------------------------------------------------------------------------
+// Table layout (doubles) inside the dead key / moment region: for the 45 index pairs a < b < 10 (triangular index FQ_PIDX) the
+// error, mse and four line parameters of the forward segment a -> b; error and mse of the wrap-around segment b -> a and its
+// six moments (its line is needed for the one chosen corner set only: k_quad_finish fits it from the moments the candidate
+// record carries); behind them the 2 m + 1 staged rows of cumulative moments the fits read.
+#define FQ_PIDX(a, b) ((((a) * (19 - (a))) >> 1) + (b) - (a) - 1)   // a < b < 10 -> 0..44
+#define FQT_FERR 0
+#define FQT_FMSE 45
+#define FQT_FEX 90
+#define FQT_FEY 135
+#define FQT_FNX 180
+#define FQT_FNY 225
+#define FQT_WERR 270
+#define FQT_WMSE 315
+#define FQT_WMOM 360     // [45][4]: Mx, My, Mxx, Mxy
+#define FQT_WMOM2 540    // [45][2]: Myy, W
+#define FQT_ROWS 630     // [21][6]
+#define FQT_DOUBLES 756
+
+// the 210 corner choices m0 < m1 < m2 < m3 < 10 in lexicographic order: pair-table indices of the segments m0->m1, m1->m2,
+// m2->m3 (forward) and m0..m3 (wrap-around), 6 bits each, and m3 in bits 24..27
+struct ComboPairs { uint32_t v[210]; };
+constexpr ComboPairs make_combo_pairs() {
+  ComboPairs t{};
+  int c = 0;
+  for (int m0 = 0; m0 < 7; m0++)
+    for (int m1 = m0 + 1; m1 < 8; m1++)
+      for (int m2 = m1 + 1; m2 < 9; m2++)
+        for (int m3 = m2 + 1; m3 < 10; m3++)
+          t.v[c++] = (uint32_t)FQ_PIDX(m0, m1) | ((uint32_t)FQ_PIDX(m1, m2) << 6) | ((uint32_t)FQ_PIDX(m2, m3) << 12) |
+                     ((uint32_t)FQ_PIDX(m0, m3) << 18) | ((uint32_t)m3 << 24);
+  return t;
+}
+__device__ const ComboPairs g_combo_pairs = make_combo_pairs();
+
+
+// One segment fit: pair-table entry t (a < b), forward (dir 0: a -> b, with line parameters) or around the end (dir 1: b -> a,
+// error and mse only).  s_maxidx: the m selected maxima in ascending order; rows: FQT_ROWS region.
+__device__ __forceinline__ void fq_segment_fit(double* s_tab, const int* s_maxidx, int m, int szd, int t, int dir) {
+  const int pr = fq_pair_of(t), a = pr >> 4, b = pr & 15;   // a < b
+  if (b >= m) return;
+  const double* s_rows = s_tab + FQT_ROWS;
+  if (dir == 0) {
+    // fit_line_dev(lf, szd, i_a, i_b) with i_a < i_b -- row at b, minus the row before a unless a is point 0
+    double e, ms, lp[4];
+    const double* rb = s_rows + b * 6;
+    double Mx = rb[0], My = rb[1], Mxx = rb[2], Mxy = rb[3], Myy = rb[4], W = rb[5];
+    if (s_maxidx[a] > 0) {
+      const double* ra = s_rows + (m + a) * 6;
+      Mx -= ra[0]; My -= ra[1]; Mxx -= ra[2]; Mxy -= ra[3]; Myy -= ra[4]; W -= ra[5];
+    }
+    fit_line_moments(Mx, My, Mxx, Mxy, Myy, W, s_maxidx[b] - s_maxidx[a] + 1, lp, &e, &ms);
+    s_tab[FQT_FERR + t] = e; s_tab[FQT_FMSE + t] = ms; s_tab[FQT_FEX + t] = lp[0]; s_tab[FQT_FEY + t] = lp[1];
+    s_tab[FQT_FNX + t] = lp[2]; s_tab[FQT_FNY + t] = lp[3];
+  } else {
+    // fit_line_dev(lf, szd, i_b, i_a) with i_b > i_a -- (last row - row before b) + row at a
+    double e, ms;
+    const double* re = s_rows + 2 * m * 6;
+    const double* rp = s_rows + (m + b) * 6;
+    const double* ra = s_rows + a * 6;
+    double Mx = re[0] - rp[0], My = re[1] - rp[1], Mxx = re[2] - rp[2], Mxy = re[3] - rp[3], Myy = re[4] - rp[4], W = re[5] - rp[5];
+    Mx += ra[0]; My += ra[1]; Mxx += ra[2]; Mxy += ra[3]; Myy += ra[4]; W += ra[5];
+    fit_line_moments(Mx, My, Mxx, Mxy, Myy, W, szd - s_maxidx[b] + s_maxidx[a] + 1, nullptr, &e, &ms);
+    s_tab[FQT_WERR + t] = e; s_tab[FQT_WMSE + t] = ms;
+    s_tab[FQT_WMOM + t * 4 + 0] = Mx; s_tab[FQT_WMOM + t * 4 + 1] = My; s_tab[FQT_WMOM + t * 4 + 2] = Mxx; s_tab[FQT_WMOM + t * 4 + 3] = Mxy;
+    s_tab[FQT_WMOM2 + t * 2 + 0] = Myy; s_tab[FQT_WMOM2 + t * 2 + 1] = W;
+  }
+}
+
+// Best of the C(m, 4) corner choices and the candidate record, ONE wave (lane = 0..63), no workgroup barriers inside.  A
+// choice is looked at in two steps: the four mse bits of its segments (one bit per pair-table entry, from two ballots) and only
+// then the normals' dot product and the error sum.  Equal errors resolve to the smaller combination index (the CPU loop order).
+__device__ __forceinline__ void fq_corner_search(const double* s_tab, const uint32_t* s_cpairs, int m, int szd, int lane, const DetParams& P,
+                                                 FitCand* __restrict__ cands_all, FrameCounters* __restrict__ counters, int frame,
+                                                 unsigned long long cl_key, int q_reversed) {
+  // segments whose mse passes (a NaN passes, as in the serial comparison)
+  unsigned long long fok, wok;
+  {
+    bool f = false, w = false;
+    if (lane < 45 && (fq_pair_of(lane) & 15) < m) {
+      f = !(s_tab[FQT_FMSE + lane] > P.max_line_fit_mse);
+      w = !(s_tab[FQT_WMSE + lane] > P.max_line_fit_mse);
+    }
+    fok = __ballot(f); wok = __ballot(w);
+  }
+  double best_err = (double)HUGE_VALF;
+  int best_t = 1 << 30;
+  for (int t = lane; t < 210; t += 64) {
+    const uint32_t cp = s_cpairs[t];
+    const int p01 = cp & 63, p12 = (cp >> 6) & 63, p23 = (cp >> 12) & 63, p03 = (cp >> 18) & 63, q3 = (int)(cp >> 24);
+    const bool pass = q3 < m && ((fok >> p01) & 1ull) && ((fok >> p12) & 1ull) && ((fok >> p23) & 1ull) && ((wok >> p03) & 1ull);
+    if (pass) {
+      const double dotn = s_tab[FQT_FNX + p01] * s_tab[FQT_FNX + p12] + s_tab[FQT_FNY + p01] * s_tab[FQT_FNY + p12];
+      if (!(fabs(dotn) > P.cos_critical_rad)) {
+        const double e = s_tab[FQT_FERR + p01] + s_tab[FQT_FERR + p12] + s_tab[FQT_FERR + p23] + s_tab[FQT_WERR + p03];
+        if (e < best_err) { best_err = e; best_t = t; }
+      }
+    }
+  }
+  const unsigned long long mykey = ~double_sortable(best_err + 0.0);
+  const unsigned long long topkey = wave_max_u64(mykey);
+  const int bt = wave_min_i(mykey == topkey ? best_t : (1 << 30));
+  if (bt == (1 << 30)) return;
+  {
+    // the winning error is the decoded top key (double_sortable is invertible)
+    const unsigned long long sk = ~topkey;
+    const unsigned long long bits = (sk >> 63) ? (sk & 0x7FFFFFFFFFFFFFFFull) : ~sk;
+    const double bev = __longlong_as_double((long long)bits);
+    if (!((bev != (double)HUGE_VALF) && (bev / szd < P.max_line_fit_mse))) return;
+  }
+  // The lines of the best choice are table entries (the same fits, bit for bit): segments q0->q1, q1->q2, q2->q3 forward; of
+  // q3->q0 around the end the record takes the six moments.  Intersections, area and angle checks run in k_quad_finish, one
+  // thread per candidate, instead of here on a handful of lanes.
+  const uint32_t cp = s_cpairs[bt];
+  const int p01 = cp & 63, p12 = (cp >> 6) & 63, p23 = (cp >> 12) & 63, p03 = (cp >> 18) & 63;
+  uint32_t ci = 0;
+  if (lane == 0) ci = atomicAdd(&counters[frame].ncand, 1u);
+  ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)ci);
+  if (ci < P.cand_cap) {
+    FitCand* const cd = cands_all + (size_t)frame * P.cand_cap + ci;
+    if (lane < 3) {
+      const int pi = lane == 0 ? p01 : lane == 1 ? p12 : p23;
+      cd->line[lane][0] = s_tab[FQT_FEX + pi]; cd->line[lane][1] = s_tab[FQT_FEY + pi];
+      cd->line[lane][2] = s_tab[FQT_FNX + pi]; cd->line[lane][3] = s_tab[FQT_FNY + pi];
+    } else if (lane == 3) {
+      cd->line[3][0] = s_tab[FQT_WMOM + p03 * 4 + 0]; cd->line[3][1] = s_tab[FQT_WMOM + p03 * 4 + 1];
+      cd->line[3][2] = s_tab[FQT_WMOM + p03 * 4 + 2]; cd->line[3][3] = s_tab[FQT_WMOM + p03 * 4 + 3];
+      cd->wm[0] = s_tab[FQT_WMOM2 + p03 * 2 + 0]; cd->wm[1] = s_tab[FQT_WMOM2 + p03 * 2 + 1];
+    } else if (lane == 4) {
+      cd->key = cl_key;
+      cd->reversed_border = q_reversed;
+      cd->wrap_is_moments = 1;
+    }
+  } else if (lane == 0) {
+    atomicOr(&counters[frame].flags, AT_FLAG_CANDS);   // (internal: the host grows the list and repeats, or reports 0x8)
+  }
+}
+
 // Dynamic LDS layout: [0, 8*sort_cap) slope keys (later: raw/smoothed errors, then maxima candidates) |
 // FQ_TABLE_DOUBLES doubles for the group prefixes of the early-exit test (none in the one-wave class).  Clusters with size in (size_lo, size_hi] are processed by this
 // launch; those above sort_cap (only possible in the last class) sort in global scratch.
@@ -717,8 +856,7 @@ template <int NT, bool SPLIT>
 #define FQ_SMOOTH_REGS_OF(NT) ((NT) >= 1024 ? 8 : 16)   // smoothed errors per thread kept in registers (clusters up to that many x threads)
 #define FQ_TABLE_DOUBLES ((FQ_XG + 1) * 7)   // prefixes over FQ_XG groups, up to seven sums each
 // bytes of the key array region: the skewed keys, and at least the twelve pair tables + the 21 staged prefix rows that take the region over later
-#define FQ_KEY_BYTES(sort_cap) ((size_t)FQ_KP(sort_cap) * 8 > (size_t)((12 * 45 + 21 * 6) * 8) ? (size_t)FQ_KP(sort_cap) * 8 : (size_t)((12 * 45 + 21 * 6) * 8))
-#define FQ_PIDX(a, b) ((((a) * (19 - (a))) >> 1) + (b) - (a) - 1)   // a < b < 10 -> 0..44
+#define FQ_KEY_BYTES(sort_cap) ((size_t)FQ_KP(sort_cap) * 8 > (size_t)(756 * 8) ? (size_t)FQ_KP(sort_cap) * 8 : (size_t)(756 * 8))   /* 756 = FQT_DOUBLES */
 #ifndef FQ_WPE_64
 #define FQ_WPE_64 4
 #define FQ_WPE_128 4
@@ -745,11 +883,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
   // Twelve tables over the 45 index pairs a < b < 10 (triangular index FQ_PIDX): error, mse and the four line parameters
   // of the forward segment a -> b and of the wrap-around segment b -> a.  They live in the key array, which is dead once
   // the maxima are selected (4320 bytes: FQ_KEY_BYTES keeps the region at least that large).
-  double* const s_tab = reinterpret_cast<double*>(fq_smem);
-  double* const s_ferr = s_tab; double* const s_fmse = s_tab + 45; double* const s_fex = s_tab + 90; double* const s_fey = s_tab + 135;
-  double* const s_fnx = s_tab + 180; double* const s_fny = s_tab + 225;
-  double* const s_werr = s_tab + 270; double* const s_wmse = s_tab + 315; double* const s_wex = s_tab + 360; double* const s_wey = s_tab + 405;
-  double* const s_wnx = s_tab + 450; double* const s_wny = s_tab + 495;
+  double* const s_tab = reinterpret_cast<double*>(fq_smem);   // FQT_* layout
   constexpr int NW = NT / 64;
   __shared__ long long s_dot[NW][3];
   __shared__ int s_box[NW][4];
@@ -758,7 +892,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
   __shared__ int s_ncand;
   __shared__ int s_maxidx[16];
   __shared__ int s_nkept;
-  __shared__ uint16_t s_combo[210];
+  __shared__ uint32_t s_cpairs[210];
   __shared__ U128 s_wtot[NW * 6];   // [wave][moment]: wave totals of the current chunk
   __shared__ U128 s_woff[NW * 6];   // [wave][moment]: offset every lane of the wave adds
   __shared__ int s_wcnt[NW];
@@ -780,7 +914,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
   double* const gerrs_a = errs_scratch ? errs_scratch + (size_t)blockIdx.x * slot_cap * 2 : nullptr;
   double* const gerrs_b = errs_scratch ? gerrs_a + slot_cap : nullptr;
 
-  for (int t = tid; t < 210; t += NT) s_combo[t] = g_combo_table.v[t];
+  for (int t = tid; t < 210; t += NT) s_cpairs[t] = g_combo_pairs.v[t];
 
   FQ_HOOKS_DECL   // measurement hooks (FQ_TICK / FQ_COUNT / FQ_STOP_AT / FQ_TL_*): tools_hooks.h, nothing in the product build
 
@@ -1493,7 +1627,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     // last row -- so those rows are fetched ONCE (one lane per row, all loads in flight together) and parked in the key
     // region behind the pair tables; the fits then take them from LDS.  (Every fit used to start with its own three global
     // loads, round after round: the phase is ~15 us of the ~40 us every cluster of the one-wave class costs, mostly waiting.)
-    double* const s_rows = s_tab + 12 * 45;   // [2 m + 1][6]: rows 0 .. m-1 at the maxima, m .. 2m-1 before them, 2m the last row
+    double* const s_rows = s_tab + FQT_ROWS;   // [2 m + 1][6]: rows 0 .. m-1 at the maxima, m .. 2m-1 before them, 2m the last row
     for (int r = tid; r < 2 * m + 1; r += NT) {
       const int src = r < m ? s_maxidx[r] : r < 2 * m ? s_maxidx[r - m] - 1 : szd - 1;
       double row[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // (before point 0: nothing; the fit does not subtract it)
@@ -1506,91 +1640,17 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
       for (int j = 0; j < 6; j++) s_rows[r * 6 + j] = row[j];
     }
     __syncthreads();
-    for (int task = tid; task < 90; task += NT) {
-      const int t = task < 45 ? task : task - 45;
-      const int pr = fq_pair_of(t), a = pr >> 4, b = pr & 15;   // a < b
-      if (b < m) {
-        double e, ms, lp[4];
-        if (task < 45) {
-          // forward a -> b: fit_line_dev(lf, szd, i_a, i_b) with i_a < i_b -- row at b, minus the row before a unless a is point 0
-          const double* rb = s_rows + b * 6;
-          double Mx = rb[0], My = rb[1], Mxx = rb[2], Mxy = rb[3], Myy = rb[4], W = rb[5];
-          if (s_maxidx[a] > 0) {
-            const double* ra = s_rows + (m + a) * 6;
-            Mx -= ra[0]; My -= ra[1]; Mxx -= ra[2]; Mxy -= ra[3]; Myy -= ra[4]; W -= ra[5];
-          }
-          fit_line_moments(Mx, My, Mxx, Mxy, Myy, W, s_maxidx[b] - s_maxidx[a] + 1, lp, &e, &ms);
-          s_ferr[t] = e; s_fmse[t] = ms; s_fex[t] = lp[0]; s_fey[t] = lp[1]; s_fnx[t] = lp[2]; s_fny[t] = lp[3];
-        } else {
-          // around the end, b -> a: fit_line_dev(lf, szd, i_b, i_a) with i_b > i_a -- (last row - row before b) + row at a
-          const double* re = s_rows + 2 * m * 6;
-          const double* rp = s_rows + (m + b) * 6;
-          const double* ra = s_rows + a * 6;
-          double Mx = re[0] - rp[0], My = re[1] - rp[1], Mxx = re[2] - rp[2], Mxy = re[3] - rp[3], Myy = re[4] - rp[4], W = re[5] - rp[5];
-          Mx += ra[0]; My += ra[1]; Mxx += ra[2]; Mxy += ra[3]; Myy += ra[4]; W += ra[5];
-          fit_line_moments(Mx, My, Mxx, Mxy, Myy, W, szd - s_maxidx[b] + s_maxidx[a] + 1, lp, &e, &ms);
-          s_werr[t] = e; s_wmse[t] = ms; s_wex[t] = lp[0]; s_wey[t] = lp[1]; s_wnx[t] = lp[2]; s_wny[t] = lp[3];
-        }
-      }
+    // 45 forward + 45 wrap-around segment fits (tools_hooks-free shared tail: fq_segment_fit / fq_corner_search above)
+    if (NT == 64) {
+      if (tid < 45) { fq_segment_fit(s_tab, s_maxidx, m, szd, tid, 0); fq_segment_fit(s_tab, s_maxidx, m, szd, tid, 1); }
+    } else {
+      // wave 0: the forward fits, wave 1: the wrap-around ones (uniform paths per wave)
+      if (tid < 45) fq_segment_fit(s_tab, s_maxidx, m, szd, tid, 0);
+      else if (tid >= 64 && tid < 64 + 45) fq_segment_fit(s_tab, s_maxidx, m, szd, tid - 64, 1);
     }
     __syncthreads();
-    // Everything below runs in wave 0 without workgroup barriers (the other waves go on to the barrier at
-    // the top of the cluster loop): best of the C(m,4) corner choices, four line fits, intersections, checks.
-    if (tid < 64) {
-      const int lane = tid;
-      double best_err = (double)HUGE_VALF;
-      int best_t = 1 << 30;
-      for (int t = lane; t < 210; t += 64) {
-        const uint32_t my_combo = s_combo[t];
-        const int q0 = my_combo & 15, q1 = (my_combo >> 4) & 15, q2 = (my_combo >> 8) & 15, q3 = (my_combo >> 12) & 15;
-        if (q3 < m) {
-          const int p01 = FQ_PIDX(q0, q1), p12 = FQ_PIDX(q1, q2), p23 = FQ_PIDX(q2, q3), p03 = FQ_PIDX(q0, q3);
-          const double mse01 = s_fmse[p01], mse12 = s_fmse[p12], mse23 = s_fmse[p23];
-          const double mse30 = s_wmse[p03];
-          const double dotn = s_fnx[p01] * s_fnx[p12] + s_fny[p01] * s_fny[p12];
-          if (!(mse01 > P.max_line_fit_mse) && !(mse12 > P.max_line_fit_mse) && !(fabs(dotn) > P.cos_critical_rad) &&
-              !(mse23 > P.max_line_fit_mse) && !(mse30 > P.max_line_fit_mse)) {
-            const double e = s_ferr[p01] + s_ferr[p12] + s_ferr[p23] + s_werr[p03];
-            if (e < best_err) { best_err = e; best_t = t; }
-          }
-        }
-      }
-      // arg-min over the wave; equal errors resolve to the smaller combination index (the CPU loop order)
-      const unsigned long long mykey = ~double_sortable(best_err + 0.0);
-      const unsigned long long topkey = wave_max_u64(mykey);
-      const int bt = wave_min_i(mykey == topkey ? best_t : (1 << 30));
-      const double be = __longlong_as_double((long long)__shfl((long long)__double_as_longlong(best_err),
-                                                                 (int)__ffsll((long long)__ballot(mykey == topkey && best_t == bt)) - 1, 64));
-      const bool found = (bt != (1 << 30)) && (be != (double)HUGE_VALF) && (be / szd < P.max_line_fit_mse);
-      if (found) {
-        // The four lines of the best choice are table entries (the same fits, bit for bit): segments q0->q1, q1->q2,
-        // q2->q3 forward, q3->q0 around the end.  Intersections, area and angle checks need a handful of lanes for a few
-        // hundred dependent double-precision instructions; they run in k_quad_finish, one thread per candidate, instead
-        // of here on 5 lanes of 64 (a third of the one-wave class's cycles went into this tail).
-        const uint32_t cmb = s_combo[bt];
-        const int q0 = cmb & 15, q1 = (cmb >> 4) & 15, q2 = (cmb >> 8) & 15, q3 = (cmb >> 12) & 15;
-        uint32_t ci = 0;
-        if (lane == 0) ci = atomicAdd(&counters[frame].ncand, 1u);
-        ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)ci);
-        if (ci < P.cand_cap) {
-          FitCand* const cd = cands_all + (size_t)frame * P.cand_cap + ci;
-          if (lane < 4) {
-            const int pi = lane == 0 ? FQ_PIDX(q0, q1) : lane == 1 ? FQ_PIDX(q1, q2) : lane == 2 ? FQ_PIDX(q2, q3) : FQ_PIDX(q0, q3);
-            const bool wrap = lane == 3;
-            cd->line[lane][0] = wrap ? s_wex[pi] : s_fex[pi];
-            cd->line[lane][1] = wrap ? s_wey[pi] : s_fey[pi];
-            cd->line[lane][2] = wrap ? s_wnx[pi] : s_fnx[pi];
-            cd->line[lane][3] = wrap ? s_wny[pi] : s_fny[pi];
-          } else if (lane == 4) {
-            cd->key = cl.key;
-            cd->reversed_border = q_reversed;
-            cd->wrap_is_moments = 0;
-          }
-        } else if (lane == 0) {
-          atomicOr(&counters[frame].flags, AT_FLAG_CANDS);   // (internal: the host grows the list and repeats, or reports 0x8)
-        }
-      }
-    }
+    // wave 0 alone, without workgroup barriers (the other waves go on to the barrier at the top of the cluster loop)
+    if (tid < 64) fq_corner_search(s_tab, s_cpairs, m, szd, tid, P, cands_all, counters, frame, cl.key, q_reversed);
     FQ_TICK(7)
   }
 }

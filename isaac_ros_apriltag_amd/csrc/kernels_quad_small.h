@@ -25,22 +25,6 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
-// the 210 corner choices m0 < m1 < m2 < m3 < 10 in lexicographic order: pair-table indices of the segments m0->m1, m1->m2,
-// m2->m3 (forward) and m0..m3 (wrap-around), 6 bits each, and m3 in bits 24..27
-struct ComboPairs { uint32_t v[210]; };
-constexpr ComboPairs make_combo_pairs() {
-  ComboPairs t{};
-  int c = 0;
-  for (int m0 = 0; m0 < 7; m0++)
-    for (int m1 = m0 + 1; m1 < 8; m1++)
-      for (int m2 = m1 + 1; m2 < 9; m2++)
-        for (int m3 = m2 + 1; m3 < 10; m3++)
-          t.v[c++] = (uint32_t)FQ_PIDX(m0, m1) | ((uint32_t)FQ_PIDX(m1, m2) << 6) | ((uint32_t)FQ_PIDX(m2, m3) << 12) |
-                     ((uint32_t)FQ_PIDX(m0, m3) << 18) | ((uint32_t)m3 << 24);
-  return t;
-}
-__device__ const ComboPairs g_combo_pairs = make_combo_pairs();
-
 #ifndef FS_WPE
 #define FS_WPE 4   // waves per SIMD the register allocation must allow
 #endif
@@ -50,7 +34,7 @@ __device__ const ComboPairs g_combo_pairs = make_combo_pairs();
 #ifndef FS_GRID_K4
 #define FS_GRID_K4 10   // persistent workgroups per CU of the K = 4 class (14.6 KB of LDS each)
 #endif
-#define FS_TAB_BYTES ((12 * 45 + 90 + 21 * 6) * 8)   // pair tables + staged moment rows
+#define FS_TAB_BYTES (FQT_DOUBLES * 8)   // pair tables + staged moment rows
 #define FS_LDS_BYTES(K) ((64 * (K) * 56) > FS_TAB_BYTES ? (64 * (K) * 56) : FS_TAB_BYTES)
 
 template <int K>
@@ -63,15 +47,10 @@ __global__ __launch_bounds__(64, FS_WPE) void k_fit_small(const FrameDesc* __res
   extern __shared__ __attribute__((aligned(16))) unsigned char fs_smem[];
   double* const rows = reinterpret_cast<double*>(fs_smem);   // [CAP][6] cumulative moments of the kept points
   double* const errs = rows + CAP * 6;                        // [CAP] windowed errors, then the smoothed ones, then the maxima list
-  // the pair tables and the staged rows take the rows' place once the maxima are selected
+  // the pair tables and the staged rows (FQT_* layout, kernels_quad.h) take the rows' place once the maxima are selected
   double* const s_tab = rows;
-  double* const s_ferr = s_tab; double* const s_fmse = s_tab + 45; double* const s_fex = s_tab + 90; double* const s_fey = s_tab + 135;
-  double* const s_fnx = s_tab + 180; double* const s_fny = s_tab + 225;
-  double* const s_werr = s_tab + 270; double* const s_wmse = s_tab + 315;
-  double* const s_wmom = s_tab + 360;          // [45][4]: Mx, My, Mxx, Mxy of the wrap-around segments ...
-  double* const s_wmom2 = s_tab + 360 + 180;   // [45][2]: ... Myy, W  (together the six moments k_quad_finish fits the line from)
-  double* const s_rows = s_tab + 12 * 45 + 90; // [21][6]  (behind the tables: 630 doubles, 756 in all)
-  static_assert((12 * 45 + 90 + 21 * 6) * 8 <= 64 * 2 * 56, "tables fit the K = 2 layout");
+  double* const s_rows = s_tab + FQT_ROWS;
+  static_assert(FQT_DOUBLES * 8 <= 64 * 2 * 56, "tables fit the K = 2 layout");
   __shared__ uint32_t s_cpairs[210];
   __shared__ int s_maxidx[16];
 
@@ -79,7 +58,6 @@ __global__ __launch_bounds__(64, FS_WPE) void k_fit_small(const FrameDesc* __res
   const int W = P.W, H = P.H;
   const uint32_t nwork = min(*work_n, work_cap);
   for (int t = lane; t < 210; t += 64) s_cpairs[t] = g_combo_pairs.v[t];
-  const int my_pair = g_pair_table.v[lane < 45 ? lane : 44];   // (a << 4) | b of the lane's pair-table entry: read once per workgroup
 
   // Software pipeline over the work list: while cluster c is being fitted, the loads of cluster c + 1 are in flight -- its
   // work item (stage 1, issued before c's box reductions), its cluster record and frame (stage 2, before c's sort) and its
@@ -149,6 +127,7 @@ __global__ __launch_bounds__(64, FS_WPE) void k_fit_small(const FrameDesc* __res
     stage1(nxt); pf = 1;
     if (sz < 24 || sz > CAP) break;   // (the work list only holds clusters of this class)
 
+    AT_MARK("box")
     // ---- the lane's K points, bounding box and exact gradient dot -------------------------------------------------
     uint32_t pp[K];
 #pragma unroll
@@ -177,6 +156,7 @@ __global__ __launch_bounds__(64, FS_WPE) void k_fit_small(const FrameDesc* __res
     if (!P.normal_border && !q_reversed) break;
 
     stage2(nxt); pf = 2;
+    AT_MARK("keys")
     // ---- slope keys (the statements of k_fit_quads) and the sort, in registers ---------------------------------------
     const float cx = (float)cxd, cy = (float)cyd;
     unsigned long long v[K];
@@ -195,8 +175,10 @@ __global__ __launch_bounds__(64, FS_WPE) void k_fit_small(const FrameDesc* __res
                                              ((unsigned long long)x << 4) | (unsigned long long)(p & 15u));
       v[j] = (lane + 64 * j < sz) ? key : AT_KEY_PAD;
     }
+    AT_MARK("sort")
     fq_wave_sort_regs<K>(v);
 
+    AT_MARK("walk1")
     // ---- moment sweep: walk 1 (terms of the lane's kept points), one scan, walk 2 (rounded prefixes to LDS) ------------
     // lane l owns the sorted positions l K + j; the key before its first one comes from lane l - 1 (wave_shr:1)
     unsigned long long prev;
@@ -240,6 +222,7 @@ __global__ __launch_bounds__(64, FS_WPE) void k_fit_small(const FrameDesc* __res
       st_xy[j] = ((keep ? 1u : 0u) << 31) | (py << 14) | px;
       st_g[j] = G;
     }
+    AT_MARK("scan")
     D2 off[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
@@ -252,6 +235,7 @@ __global__ __launch_bounds__(64, FS_WPE) void k_fit_small(const FrameDesc* __res
 #define OP(C, M) kincl += __builtin_amdgcn_update_dpp(0, kincl, C, M, 0xF, true);
     AT_DPP_STEPS(OP)
 #undef OP
+    AT_MARK("walk2")
     int pos = kincl - kept;
     const int szd = __builtin_amdgcn_readlane(kincl, 63);
     if (szd < 24) break;
@@ -276,6 +260,7 @@ __global__ __launch_bounds__(64, FS_WPE) void k_fit_small(const FrameDesc* __res
     __syncthreads();   // (fence: the rows are read by other lanes below)
 
     stage3(nxt); pf = 3;
+    AT_MARK("errors")
     // ---- windowed line-fit error, smoothing, local maxima ------------------------------------------------------------
     const int ksz = min(20, szd / 12);
     double sm[K];
@@ -291,6 +276,7 @@ __global__ __launch_bounds__(64, FS_WPE) void k_fit_small(const FrameDesc* __res
       }
     }
     __syncthreads();
+    AT_MARK("smooth")
     const float f0 = 0x1.6c0504p-7f, f1 = 0x1.152aaap-3f, f2 = 0x1.368b3p-1f;
     const double F0 = (double)f0, F1 = (double)f1, F2 = (double)f2;
     auto wrap = [szd](int k) { return k < 0 ? k + szd : (k >= szd ? k - szd : k); };
@@ -345,6 +331,7 @@ __global__ __launch_bounds__(64, FS_WPE) void k_fit_small(const FrameDesc* __res
     __syncthreads();
     if (nmaxima < 4) break;
 
+    AT_MARK("top10")
     // ---- at most max_nmaxima corners: those whose value exceeds the (max_nmaxima + 1)-th largest --------------------------
     int m;
     if (nmaxima > P.max_nmaxima) {
@@ -397,6 +384,7 @@ __global__ __launch_bounds__(64, FS_WPE) void k_fit_small(const FrameDesc* __res
     __syncthreads();
     if (m < 4) break;
 
+    AT_MARK("rows")
     // ---- the 2 m + 1 moment rows the segment fits read, then the 45 + 45 fits ---------------------------------------------
     {
       double row[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -414,97 +402,12 @@ __global__ __launch_bounds__(64, FS_WPE) void k_fit_small(const FrameDesc* __res
       }
     }
     __syncthreads();
-    if (lane < 45) {
-      const int t = lane;
-      const int pr = my_pair, a = pr >> 4, b = pr & 15;   // a < b
-      if (b < m) {
-        {   // forward a -> b with line parameters
-          double e, ms, lp[4];
-          const double* rb = s_rows + b * 6;
-          double Mx = rb[0], My = rb[1], Mxx = rb[2], Mxy = rb[3], Myy = rb[4], Wm = rb[5];
-          if (s_maxidx[a] > 0) {
-            const double* ra = s_rows + (m + a) * 6;
-            Mx -= ra[0]; My -= ra[1]; Mxx -= ra[2]; Mxy -= ra[3]; Myy -= ra[4]; Wm -= ra[5];
-          }
-          fit_line_moments(Mx, My, Mxx, Mxy, Myy, Wm, s_maxidx[b] - s_maxidx[a] + 1, lp, &e, &ms);
-          s_ferr[t] = e; s_fmse[t] = ms; s_fex[t] = lp[0]; s_fey[t] = lp[1]; s_fnx[t] = lp[2]; s_fny[t] = lp[3];
-        }
-        {   // around the end, b -> a: error and mse only; the moments are kept for k_quad_finish
-          double e, ms;
-          const double* re = s_rows + 2 * m * 6;
-          const double* rp = s_rows + (m + b) * 6;
-          const double* ra = s_rows + a * 6;
-          double Mx = re[0] - rp[0], My = re[1] - rp[1], Mxx = re[2] - rp[2], Mxy = re[3] - rp[3], Myy = re[4] - rp[4], Wm = re[5] - rp[5];
-          Mx += ra[0]; My += ra[1]; Mxx += ra[2]; Mxy += ra[3]; Myy += ra[4]; Wm += ra[5];
-          fit_line_moments(Mx, My, Mxx, Mxy, Myy, Wm, szd - s_maxidx[b] + s_maxidx[a] + 1, nullptr, &e, &ms);
-          s_werr[t] = e; s_wmse[t] = ms;
-          s_wmom[t * 4 + 0] = Mx; s_wmom[t * 4 + 1] = My; s_wmom[t * 4 + 2] = Mxx; s_wmom[t * 4 + 3] = Mxy;
-          s_wmom2[t * 2 + 0] = Myy; s_wmom2[t * 2 + 1] = Wm;
-        }
-      }
-    }
+    AT_MARK("pairfits")
+    if (lane < 45) { fq_segment_fit(s_tab, s_maxidx, m, szd, lane, 0); fq_segment_fit(s_tab, s_maxidx, m, szd, lane, 1); }
     __syncthreads();
-    // segments whose mse passes, one bit per pair-table index (a NaN passes, as in the serial comparison)
-    unsigned long long fok, wok;
-    {
-      bool f = false, w = false;
-      if (lane < 45) {
-        const int pr = my_pair;
-        if ((pr & 15) < m) { f = !(s_fmse[lane] > P.max_line_fit_mse); w = !(s_wmse[lane] > P.max_line_fit_mse); }
-      }
-      fok = __ballot(f); wok = __ballot(w);
-    }
-    double best_err = (double)HUGE_VALF;
-    int best_t = 1 << 30;
-    for (int t = lane; t < 210; t += 64) {
-      const uint32_t cp = s_cpairs[t];
-      const int p01 = cp & 63, p12 = (cp >> 6) & 63, p23 = (cp >> 12) & 63, p03 = (cp >> 18) & 63, q3 = (int)(cp >> 24);
-      const bool pass = q3 < m && ((fok >> p01) & 1ull) && ((fok >> p12) & 1ull) && ((fok >> p23) & 1ull) && ((wok >> p03) & 1ull);
-      if (pass) {
-        const double dotn = s_fnx[p01] * s_fnx[p12] + s_fny[p01] * s_fny[p12];
-        if (!(fabs(dotn) > P.cos_critical_rad)) {
-          const double e = s_ferr[p01] + s_ferr[p12] + s_ferr[p23] + s_werr[p03];
-          if (e < best_err) { best_err = e; best_t = t; }
-        }
-      }
-    }
-    // arg-min over the wave; equal errors resolve to the smaller combination index (the CPU loop order)
-    const unsigned long long mykey = ~double_sortable(best_err + 0.0);
-    const unsigned long long topkey = wave_max_u64(mykey);
-    const int bt = wave_min_i(mykey == topkey ? best_t : (1 << 30));
-    if (bt == (1 << 30)) break;
-    {
-      // the winning error is the decoded top key (double_sortable is invertible)
-      const unsigned long long sk = ~topkey;
-      const unsigned long long bits = (sk >> 63) ? (sk & 0x7FFFFFFFFFFFFFFFull) : ~sk;
-      const double bev = __longlong_as_double((long long)bits);
-      const bool found = (bev != (double)HUGE_VALF) && (bev / szd < P.max_line_fit_mse);
-      if (!found) break;
-    }
-    {
-      const uint32_t cp = s_cpairs[bt];
-      const int p01 = cp & 63, p12 = (cp >> 6) & 63, p23 = (cp >> 12) & 63, p03 = (cp >> 18) & 63;
-      uint32_t ci = 0;
-      if (lane == 0) ci = atomicAdd(&counters[frame].ncand, 1u);
-      ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)ci);
-      if (ci < P.cand_cap) {
-        FitCand* const cd = cands_all + (size_t)frame * P.cand_cap + ci;
-        if (lane < 3) {
-          const int pi = lane == 0 ? p01 : lane == 1 ? p12 : p23;
-          cd->line[lane][0] = s_fex[pi]; cd->line[lane][1] = s_fey[pi]; cd->line[lane][2] = s_fnx[pi]; cd->line[lane][3] = s_fny[pi];
-        } else if (lane == 3) {
-          cd->line[3][0] = s_wmom[p03 * 4 + 0]; cd->line[3][1] = s_wmom[p03 * 4 + 1];
-          cd->line[3][2] = s_wmom[p03 * 4 + 2]; cd->line[3][3] = s_wmom[p03 * 4 + 3];
-          cd->wm[0] = s_wmom2[p03 * 2 + 0]; cd->wm[1] = s_wmom2[p03 * 2 + 1];
-        } else if (lane == 4) {
-          cd->key = cl_key;
-          cd->reversed_border = q_reversed;
-          cd->wrap_is_moments = 1;
-        }
-      } else if (lane == 0) {
-        atomicOr(&counters[frame].flags, AT_FLAG_CANDS);
-      }
-    }
+    AT_MARK("combos")
+    fq_corner_search(s_tab, s_cpairs, m, szd, lane, P, cands_all, counters, frame, cl_key, q_reversed);
+    AT_MARK("end")
     } while (0);
     if (pf < 1) stage1(nxt);
     if (pf < 2) stage2(nxt);

@@ -11,6 +11,13 @@
 // into dead-code elimination of the phases before it.
 #pragma once
 
+// -DAMDAT_ASM_MARKS: phase markers as assembler comments (static instruction counts per phase from hipcc -S)
+#ifdef AMDAT_ASM_MARKS
+#define AT_MARK(name) asm volatile("; ==MARK " name);
+#else
+#define AT_MARK(name)
+#endif
+
 // ---- k_cc_local ---------------------------------------------------------------------------------------------------------
 #ifdef AMDAT_CC_STOP
 #define CC_STOP_AT(n) if (AMDAT_CC_STOP == (n) && P.max_nmaxima == 10) return;
