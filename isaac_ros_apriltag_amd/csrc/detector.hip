@@ -599,7 +599,7 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
 #endif
     const int sb0 = P.split_moments ? FS_B0 : 0, sb1 = P.split_moments ? FS_B1 : 0;
     c[0] = {64, 0, 0, sb0, minu((unsigned)FS_GRID_K2 * cus, 4096u * (unsigned)B), sb0, FQ_POP0, 2};
-    c[1] = {64, 0, sb0, sb1, minu((unsigned)FS_GRID_K4 * cus, 4096u * (unsigned)B), sb1, FQ_POP0, 4};
+    c[1] = {64, 0, sb0, sb1, minu((unsigned)FS_GRID_K4 * cus, 4096u * (unsigned)B), sb1 > 256 ? sb1 : 256, FQ_POP0, 4};   // (slot: 256 rows of moments)
     FqClass* const q = c + FQ_C0;   // the classes of k_fit_quads
     q[0] = {64, FQ_B01, sb1, FQ_B01, minu((unsigned)FQ_GRID_64 * cus, 4096u * (unsigned)B), FQ_B01, FQ_POP0};
     q[1] = {128, FQ_B12, FQ_B01, FQ_B12, minu((unsigned)FQ_GRID_128 * cus, 1024u * (unsigned)B), FQ_B12, FQ_POP1};
@@ -639,10 +639,10 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   if (ok) { const int rc = alloc_point_buffers(D); if (rc == AMDAT_BATCH_TOO_LARGE) { free_all(D); delete D; return rc; } ok = rc == AMDAT_SUCCESS; }
   for (int k = 0; k < FQ_NCLS; k++) {
     FqClass& c = D->cls[k];
-    if (P.max_cluster_points <= c.lo || c.small_k || c.hi <= c.lo) continue;
+    if (P.max_cluster_points <= c.lo || c.small_k == 2 || c.hi <= c.lo) continue;   // (k_fit_small<2> keeps its moments in LDS)
     alloc((void**)&c.d_lf, (size_t)c.grid * c.slot_cap * 48);
     // smoothed errors stay in registers up to FQ_SMOOTH_REGS_OF(threads) points per thread; larger clusters need a second array
-    if (c.slot_cap > FQ_SMOOTH_REGS_OF(c.nt) * c.nt || c.slot_cap > c.sort_cap) alloc((void**)&c.d_errs, (size_t)c.grid * c.slot_cap * 16);
+    if (!c.small_k && (c.slot_cap > FQ_SMOOTH_REGS_OF(c.nt) * c.nt || c.slot_cap > c.sort_cap)) alloc((void**)&c.d_errs, (size_t)c.grid * c.slot_cap * 16);
   }
   if (D->cls[FQ_NCLS - 1].slot_cap > D->cls[FQ_NCLS - 1].sort_cap) {   // clusters beyond the LDS key array exist
     const FqClass& c = D->cls[FQ_NCLS - 1];
@@ -906,9 +906,9 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
       const bool filtered = prefilter && c >= pf_first;
       if (cl.small_k) {
 #define FS_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work + D->work_layout.off[c], D->d_workctl + c,               \
-                D->work_layout.cap[c], D->d_workctl + 8 + c, D->d_cands, D->d_counters, pop, P
-        if (cl.small_k == 2) hipLaunchKernelGGL(k_fit_small<2>, grid, dim3(64), FS_LDS_BYTES(2), sc, FS_ARGS);
-        else hipLaunchKernelGGL(k_fit_small<4>, grid, dim3(64), FS_LDS_BYTES(4), sc, FS_ARGS);
+                D->work_layout.cap[c], D->d_workctl + 8 + c, cl.d_lf, D->d_cands, D->d_counters, pop, P
+        if (cl.small_k == 2) hipLaunchKernelGGL((k_fit_small<2, false>), grid, dim3(64), FS_LDS_BYTES(2, false), sc, FS_ARGS);
+        else hipLaunchKernelGGL((k_fit_small<4, true>), grid, dim3(64), FS_LDS_BYTES(4, true), sc, FS_ARGS);
 #undef FS_ARGS
         return true;
       }

@@ -868,8 +868,8 @@ template <int NT, bool SPLIT>
 #define FQ_GRID_64 16
 #define FQ_GRID_128 8
 #endif
-// second launch-bound argument = minimum waves per SIMD the register allocation must allow
-__global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 : NT == 256 ? FQ_WPE_256 : 4)) void k_fit_quads(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
+// (the body of k_fit_quads)
+__device__ __forceinline__ void fit_quads_body(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
                                                    const uint32_t* __restrict__ pts_all, const ClusterRec* __restrict__ clusters_all,
                                                    const uint32_t* __restrict__ work, const uint32_t* __restrict__ work_n, uint32_t work_cap,
                                                    uint32_t* __restrict__ work_cursor, double* __restrict__ lf_scratch,
@@ -1653,6 +1653,20 @@ __global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 
     if (tid < 64) fq_corner_search(s_tab, s_cpairs, m, szd, tid, P, cands_all, counters, frame, cl.key, q_reversed);
     FQ_TICK(7)
   }
+}
+
+// second launch-bound argument = minimum waves per SIMD the register allocation must allow
+template <int NT, bool SPLIT>
+__global__ __launch_bounds__(NT, (NT == 64 ? FQ_WPE_64 : NT == 128 ? FQ_WPE_128 : NT == 256 ? FQ_WPE_256 : 4)) void k_fit_quads(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
+                                                   const uint32_t* __restrict__ pts_all, const ClusterRec* __restrict__ clusters_all,
+                                                   const uint32_t* __restrict__ work, const uint32_t* __restrict__ work_n, uint32_t work_cap,
+                                                   uint32_t* __restrict__ work_cursor, double* __restrict__ lf_scratch,
+                                                   unsigned long long* __restrict__ keys_scratch, double* __restrict__ errs_scratch,
+                                                   FitCand* __restrict__ cands_all, FrameCounters* __restrict__ counters,
+                                                   unsigned long long* __restrict__ prof, int sort_cap, int slot_cap,
+                                                   int pop, DetParams P) {
+  fit_quads_body<NT, SPLIT>(frames, gray_all, pts_all, clusters_all, work, work_n, work_cap, work_cursor, lf_scratch, keys_scratch, errs_scratch,
+                            cands_all, counters, prof, sort_cap, slot_cap, pop, P);
 }
 
 // ---- k_fit_prefilter: the cheap exits of the quad fit for the clusters of the large classes, ahead of k_fit_quads ---------

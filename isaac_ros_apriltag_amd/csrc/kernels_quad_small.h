@@ -32,25 +32,31 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 #define FS_GRID_K2 16   // persistent workgroups per CU of the K = 2 class
 #endif
 #ifndef FS_GRID_K4
-#define FS_GRID_K4 10   // persistent workgroups per CU of the K = 4 class (14.6 KB of LDS each)
+#define FS_GRID_K4 16   // persistent workgroups per CU of the K = 4 class
 #endif
 #define FS_TAB_BYTES (FQT_DOUBLES * 8)   // pair tables + staged moment rows
-#define FS_LDS_BYTES(K) ((64 * (K) * 56) > FS_TAB_BYTES ? (64 * (K) * 56) : FS_TAB_BYTES)
+// LDS of a workgroup: GROWS = false -- moments [64 K][6] | errors [64 K], the tables over the moments once they are dead;
+//                     GROWS = true  -- tables | errors [64 K]; the moments live in the workgroup's global scratch slot
+#define FS_LDS_BYTES(K, GROWS) ((GROWS) ? (FS_TAB_BYTES + 64 * (K) * 8) : ((64 * (K) * 56) > FS_TAB_BYTES ? (64 * (K) * 56) : FS_TAB_BYTES))
 
-template <int K>
-__global__ __launch_bounds__(64, FS_WPE) void k_fit_small(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
+template <int K, bool GROWS>
+__device__ __forceinline__ void fit_small_body(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
                                                           const uint32_t* __restrict__ pts_all, const ClusterRec* __restrict__ clusters_all,
                                                           const uint32_t* __restrict__ work, const uint32_t* __restrict__ work_n, uint32_t work_cap,
-                                                          uint32_t* __restrict__ work_cursor, FitCand* __restrict__ cands_all,
+                                                          uint32_t* __restrict__ work_cursor, double* __restrict__ lf_scratch, FitCand* __restrict__ cands_all,
                                                           FrameCounters* __restrict__ counters, int pop, DetParams P) {
   constexpr int CAP = 64 * K;
   extern __shared__ __attribute__((aligned(16))) unsigned char fs_smem[];
-  double* const rows = reinterpret_cast<double*>(fs_smem);   // [CAP][6] cumulative moments of the kept points
-  double* const errs = rows + CAP * 6;                        // [CAP] windowed errors, then the smoothed ones, then the maxima list
-  // the pair tables and the staged rows (FQT_* layout, kernels_quad.h) take the rows' place once the maxima are selected
-  double* const s_tab = rows;
+  // [CAP][6] cumulative moments of the kept points: in LDS, or (GROWS: the K = 4 class, whose 12 KB of moments would cut
+  // the resident workgroups to 10 per CU) in the workgroup's slot of a global scratch array, which stays in L2
+  double* const lds = reinterpret_cast<double*>(fs_smem);
+  double* const rows = GROWS ? lf_scratch + (size_t)blockIdx.x * CAP * 6 : lds;
+  // [CAP] windowed errors, then the smoothed ones, then the maxima list
+  double* const errs = GROWS ? lds + FQT_DOUBLES : lds + CAP * 6;
+  // the pair tables and the staged rows (FQT_* layout, kernels_quad.h): in the moments' place once the maxima are selected
+  double* const s_tab = lds;
   double* const s_rows = s_tab + FQT_ROWS;
-  static_assert(FQT_DOUBLES * 8 <= 64 * 2 * 56, "tables fit the K = 2 layout");
+  static_assert(GROWS || FQT_DOUBLES * 8 <= 64 * K * 56, "tables fit the moment region");
   __shared__ uint32_t s_cpairs[210];
   __shared__ int s_maxidx[16];
 
@@ -414,4 +420,13 @@ __global__ __launch_bounds__(64, FS_WPE) void k_fit_small(const FrameDesc* __res
     if (pf < 3) stage3(nxt);
     cur = nxt;
   }
+}
+
+template <int K, bool GROWS>
+__global__ __launch_bounds__(64, FS_WPE) void k_fit_small(const FrameDesc* __restrict__ frames, const uint8_t* __restrict__ gray_all,
+                                                          const uint32_t* __restrict__ pts_all, const ClusterRec* __restrict__ clusters_all,
+                                                          const uint32_t* __restrict__ work, const uint32_t* __restrict__ work_n, uint32_t work_cap,
+                                                          uint32_t* __restrict__ work_cursor, double* __restrict__ lf_scratch, FitCand* __restrict__ cands_all,
+                                                          FrameCounters* __restrict__ counters, int pop, DetParams P) {
+  fit_small_body<K, GROWS>(frames, gray_all, pts_all, clusters_all, work, work_n, work_cap, work_cursor, lf_scratch, cands_all, counters, pop, P);
 }
