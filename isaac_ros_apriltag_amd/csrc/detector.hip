@@ -402,9 +402,17 @@ static void free_all(amdAprilTagsDetector_st* D) {
 // written here: after (re)allocation, and after a submission that did not run to its end (tables_dirty).
 static int clear_hash_tables(amdAprilTagsDetector_st* D) {
   const size_t B = D->cfg.max_batch;
-  if (hipMemset(D->d_hkeys, 0xFF, B * (size_t)D->P.hcap * 8) != hipSuccess) return AMDAT_HIP_ERROR;
-  if (hipMemset(D->d_hcnt, 0, B * (size_t)D->P.hcap * 4) != hipSuccess) return AMDAT_HIP_ERROR;
-  if (hipDeviceSynchronize() != hipSuccess) return AMDAT_HIP_ERROR;
+  if (D->own_stream) {
+    // on the handle's own (non-blocking) stream, waited for on the host: a regrowth inside a detect call does not stall the
+    // caller's other streams the way a null-stream fill and a device-wide synchronisation would
+    if (hipMemsetAsync(D->d_hkeys, 0xFF, B * (size_t)D->P.hcap * 8, D->own_stream) != hipSuccess) return AMDAT_HIP_ERROR;
+    if (hipMemsetAsync(D->d_hcnt, 0, B * (size_t)D->P.hcap * 4, D->own_stream) != hipSuccess) return AMDAT_HIP_ERROR;
+    if (hipStreamSynchronize(D->own_stream) != hipSuccess) return AMDAT_HIP_ERROR;
+  } else {   // (creation: the streams do not exist yet)
+    if (hipMemset(D->d_hkeys, 0xFF, B * (size_t)D->P.hcap * 8) != hipSuccess) return AMDAT_HIP_ERROR;
+    if (hipMemset(D->d_hcnt, 0, B * (size_t)D->P.hcap * 4) != hipSuccess) return AMDAT_HIP_ERROR;
+    if (hipDeviceSynchronize() != hipSuccess) return AMDAT_HIP_ERROR;
+  }
   D->tables_dirty = false;
   return AMDAT_SUCCESS;
 }
@@ -810,7 +818,14 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
   P.frame0 = 0;
   launch_threshold(D, P, n, s);
   mark();
-  hipLaunchKernelGGL(k_cc_local, dim3((P.W + CC_T - 1) / CC_T, (P.H + CC_T - 1) / CC_T, n), dim3(256), 0, s, D->d_thr,
+#ifndef AMDAT_CC_WIDE
+#define AMDAT_CC_WIDE 1
+#endif
+  if (AMDAT_CC_WIDE && small_submission(P, n))   // sixteen waves per tile: a quarter of the rows per lane (latency, not throughput)
+    hipLaunchKernelGGL((k_cc_local<16>), dim3((P.W + CC_T - 1) / CC_T, (P.H + CC_T - 1) / CC_T, n), dim3(1024), 0, s, D->d_thr,
+                     D->d_label, D->d_csize, D->d_roots, D->d_counters, P);
+  else
+    hipLaunchKernelGGL((k_cc_local<4>), dim3((P.W + CC_T - 1) / CC_T, (P.H + CC_T - 1) / CC_T, n), dim3(256), 0, s, D->d_thr,
                      D->d_label, D->d_csize, D->d_roots, D->d_counters, P);
   mark();
   {

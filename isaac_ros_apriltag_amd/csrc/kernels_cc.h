@@ -27,7 +27,6 @@
 
 #define CC_T 64  // tile edge
 #define CC_UROWS 4   // (2 rows: 3.38 ms, 4: 3.34, 8: 4.6 -- the list costs a workgroup slot per CU)
-#define CC_UREQ (CC_UROWS * 3 * 64)   // link requests of CC_UROWS rows of one wave (at most three per pixel)
 
 // (relaxed workgroup-scope atomic loads, not volatile ones: a volatile access keeps the generic address space and
 // compiles to flat_load ... sc0 sc1 through the shared aperture instead of ds_read_b32)
@@ -89,12 +88,18 @@ __device__ __forceinline__ void glb_union(uint32_t* L, uint32_t a, uint32_t b) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ thr_all, uint32_t* __restrict__ label_all,
+// NW waves per tile: 4 (throughput: a lane walks 16 rows, 7 workgroups per CU) or 16 (small submissions: 4 rows per lane --
+// a one-frame call has two tiles per CU and is over when the slowest tile is, so the chain per wave is what counts).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict__ thr_all, uint32_t* __restrict__ label_all,
                                                   uint32_t* __restrict__ csize_all, uint32_t* __restrict__ roots_all,
                                                   FrameCounters* __restrict__ counters, DetParams P) {
   // (the threshold tile is only read into registers right after the load; the link-request lists of the union pass take
   // over its space -- a barrier lies between -- which brings the block from 26.6 to 22.6 KB of LDS: 7 blocks per CU, not 6)
-  __shared__ __attribute__((aligned(16))) uint8_t s_tile_or_requests[(CC_T * CC_T > 4 * CC_UREQ * 2) ? CC_T * CC_T : 4 * CC_UREQ * 2];
+  constexpr int ROWS = CC_T / NW;                                   // rows of a wave's strip
+  constexpr int UROWS = ROWS < CC_UROWS ? ROWS : CC_UROWS;          // rows per batch of link requests
+  constexpr int UREQ = UROWS * 3 * 64;                              // link requests of UROWS rows of one wave (at most three per pixel)
+  __shared__ __attribute__((aligned(16))) uint8_t s_tile_or_requests[(CC_T * CC_T > NW * UREQ * 2) ? CC_T * CC_T : NW * UREQ * 2];
   uint8_t* const st = s_tile_or_requests;
   uint16_t* const s_ureq = reinterpret_cast<uint16_t*>(s_tile_or_requests);
   __shared__ uint32_t sl[CC_T * CC_T];
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   const uint8_t* thr = thr_all + (size_t)frame * H * P.WS;
   const int tid = threadIdx.x;
 
-  {  // load the tile: 16 bytes per thread, out-of-image pixels become 127
+  if (tid < 256) {  // load the tile: 16 bytes per thread, out-of-image pixels become 127
     const int row = tid >> 2, seg = tid & 3;
     const int gy = Y0 + row, gx = X0 + seg * 16;
     uint32_t w[4] = {0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu};
@@ -128,20 +133,20 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   const int gx = X0 + lane;
   const bool src_ok = gx >= 1 && gx <= W - 2;  // this column may be a link source
 
-  // The lane's column of the wave's 16 rows stays in registers from here on, and so does the row above the strip; left and
+  // The lane's column of the wave's ROWS rows stays in registers from here on, and so does the row above the strip; left and
   // right neighbours come over the DPP network (wave_shr:1 / wave_shl:1), not from the byte array again -- the three passes
   // below used to re-read it eight times per pixel.
-  uint32_t vv[16];
+  uint32_t vv[ROWS];
 #pragma unroll
-  for (int k = 0; k < 16; k++) vv[k] = st[(wv * 16 + k) * CC_T + lane];
-  const uint32_t vtop = wv > 0 ? (uint32_t)st[(wv * 16 - 1) * CC_T + lane] : 127u;
+  for (int k = 0; k < ROWS; k++) vv[k] = st[(wv * ROWS + k) * CC_T + lane];
+  const uint32_t vtop = wv > 0 ? (uint32_t)st[(wv * ROWS - 1) * CC_T + lane] : 127u;
 #define CC_LEFT(x) ((uint32_t)__builtin_amdgcn_update_dpp(127, (int)(x), 0x138, 0xF, 0xF, false))    /* lane i <- lane i - 1 (lane 0: 127) */
 #define CC_RIGHT(x) ((uint32_t)__builtin_amdgcn_update_dpp(127, (int)(x), 0x130, 0xF, 0xF, false))   /* lane i <- lane i + 1 (lane 63: 127) */
   // ---- 1. run labelling per row (wave ballot, no atomics) -------------------------------------
   uint32_t linkmask = 0;   // bit k: the pixel continues the run of its left neighbour
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int r = wv * 16 + k;
+  for (int k = 0; k < ROWS; k++) {
+    const int r = wv * ROWS + k;
     const uint32_t v = vv[k];
     const uint32_t vleft = CC_LEFT(v);   // (in every lane: a DPP read from an inactive lane returns the fill value)
     const bool link = lane > 0 && v != 127 && src_ok && vleft == v;
@@ -162,14 +167,14 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   // under the three conditions directly ran each call on the few lanes that had that link and as long as the
   // longest chase among them.)  Entry = pixel << 2 | partner (0: up, 1: up-left, 2: up-right).
   {
-    uint16_t* ureq = s_ureq + wv * CC_UREQ;
+    uint16_t* ureq = s_ureq + wv * UREQ;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int k0 = 0; k0 < 16; k0 += CC_UROWS) {
+    for (int k0 = 0; k0 < ROWS; k0 += UROWS) {
       uint32_t nreq = 0;   // uniform
 #pragma unroll
-      for (int kk = 0; kk < CC_UROWS; kk++) {
-        const int r = wv * 16 + k0 + kk;
+      for (int kk = 0; kk < UROWS; kk++) {
+        const int r = wv * ROWS + k0 + kk;
         bool up = false, upl = false, upr = false;
         const uint32_t me = (uint32_t)(r * CC_T + lane);
         {
@@ -209,18 +214,18 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
 
   CC_STOP_AT(2)
   // ---- 3. flatten into registers, then count pixels per root (one LDS atomic per run) ----------
-  uint32_t root[16];
-  for (int k = 0; k < 16; k++) {
-    const int r = wv * 16 + k;
+  uint32_t root[ROWS];
+  for (int k = 0; k < ROWS; k++) {
+    const int r = wv * ROWS + k;
     const uint32_t l = sl[r * CC_T + lane];
     root[k] = (l == AT_NO_LABEL) ? AT_NO_LABEL : lds_find<CC_FLATTEN_HOPS>(sl, (uint32_t)(r * CC_T + lane));
   }
   __syncthreads();
-  for (int k = 0; k < 16; k++) sl[(wv * 16 + k) * CC_T + lane] = 0;
+  for (int k = 0; k < ROWS; k++) sl[(wv * ROWS + k) * CC_T + lane] = 0;
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int r = wv * 16 + k;
+  for (int k = 0; k < ROWS; k++) {
+    const int r = wv * ROWS + k;
     const uint32_t v = vv[k];
     const bool link = (linkmask >> k) & 1u;
     const unsigned long long S = ~__ballot(link);  // run starts
@@ -245,8 +250,8 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   // this tile (its label and size are final here), so the passes over the list (k_cc_sizes, k_cc_resolve) skip the
   // interior specks that make up most components of a noisy frame.
   uint32_t myroots = 0;
-  for (int k = 0; k < 16; k++) {
-    const uint32_t me = (uint32_t)((wv * 16 + k) * CC_T + lane);
+  for (int k = 0; k < ROWS; k++) {
+    const uint32_t me = (uint32_t)((wv * ROWS + k) * CC_T + lane);
     if (root[k] != AT_NO_LABEL && root[k] == me && (sl[me] >> 31)) myroots++;
   }
   uint32_t rpos = myroots ? atomicAdd(&s_nroots, myroots) : 0;
@@ -255,8 +260,8 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ th
   __syncthreads();
   rpos += s_rbase;
   if (gx < W) {
-    for (int k = 0; k < 16; k++) {
-      const int r = wv * 16 + k;
+    for (int k = 0; k < ROWS; k++) {
+      const int r = wv * ROWS + k;
       const int gy = Y0 + r;
       if (gy >= H) break;
       const uint32_t me = (uint32_t)(r * CC_T + lane);

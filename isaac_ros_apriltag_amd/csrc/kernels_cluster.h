@@ -122,32 +122,34 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   const int tid = threadIdx.x;
 
   {
-    // tile + halo: 17 x 66 = 1122 entries, up to 5 per thread.  Two dependent loads per entry (pixel -> tile-local root l,
-    // then label[l] = representative | size bit, kernels_cc.h), issued level by level for all of a thread's entries so
-    // that their latencies overlap instead of adding up.
-    constexpr int NE = (PT_LH * PT_LW + 255) / 256;
-    uint32_t v[NE], l[NE], r[NE];
+    // tile + halo: 17 rows x 66 columns.  A wave takes rows wv, wv + 4, ... with lane = column (64 coalesced entries per
+    // row, no division to find an entry's place), the 2 x 17 halo entries go to the first 34 threads.  Two dependent loads
+    // per entry (pixel -> tile-local root l, then label[l] = representative | size bit, kernels_cc.h), issued level by level
+    // for all of a thread's entries so that their latencies overlap instead of adding up.
+    constexpr int NR = (PT_LH + 3) / 4;   // rows per wave (5; the last one exists for wave 0 only)
+    const int lane_ = tid & 63, wv_ = tid >> 6;
+    uint32_t v[NR + 1], l[NR + 1], r[NR + 1];
+    int si[NR + 1];                        // slab index of the entry, -1: none
+    const int gxm = X0 + lane_;
 #pragma unroll
-    for (int e = 0; e < NE; e++) {
-      const int i = tid + e * 256;
+    for (int e = 0; e <= NR; e++) {
+      int ly, gx;
+      if (e < NR) { ly = wv_ + 4 * e; gx = gxm; si[e] = ly < PT_LH ? ly * PT_LW + lane_ + 1 : -1; }
+      else { ly = tid >> 1; gx = (tid & 1) ? X0 + PT_TW : X0 - 1; si[e] = tid < 2 * PT_LH ? ly * PT_LW + ((tid & 1) ? PT_LW - 1 : 0) : -1; }
+      const int gy = Y0 + ly;
       v[e] = 127; l[e] = AT_NO_LABEL; r[e] = 0;
-      if (i < PT_LH * PT_LW) {
-        const int ly = i / PT_LW, lx = i % PT_LW;
-        const int gx = X0 + lx - 1, gy = Y0 + ly;
-        if (gx >= 0 && gx < W && gy < H) {
-          v[e] = thr[(size_t)gy * P.WS + gx];
-          l[e] = label[(size_t)gy * W + gx];
-        }
+      if (si[e] >= 0 && gx >= 0 && gx < W && gy < H) {
+        v[e] = thr[(uint32_t)gy * (uint32_t)P.WS + (uint32_t)gx];
+        l[e] = label[(uint32_t)gy * (uint32_t)W + (uint32_t)gx];
       }
     }
 #pragma unroll
-    for (int e = 0; e < NE; e++)
+    for (int e = 0; e <= NR; e++)
       if (v[e] != 127 && l[e] != AT_NO_LABEL) r[e] = label[l[e] & AT_LABEL_MASK];
 #pragma unroll
-    for (int e = 0; e < NE; e++) {
-      const int i = tid + e * 256;
+    for (int e = 0; e <= NR; e++) {
       const uint32_t lab = (r[e] >> 31) ? ((r[e] & AT_LABEL_MASK) | (v[e] == 255u ? 0x80000000u : 0u)) : AT_NO_LABEL;
-      if (i < PT_LH * PT_LW) slab[i] = lab;
+      if (si[e] >= 0) slab[si[e]] = lab;
     }
   }
   tkey[tid] = AT_EMPTY_KEY;
@@ -470,8 +472,11 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ st
       const uint32_t pix = (w[u] >> 19) & 1023u;
       const int ly = (int)(pix >> 6), plx = (int)(pix & 63u), d = (int)((w[u] >> 29) & 3u);
       const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
-      const int step = (w[u] >> 31) ? -255 : 255;
-      pts[off[u] + tb[u].y + ((w[u] >> 8) & 2047u)] = pack_point(2 * (X0 + plx) + ddx, 2 * (Y0 + ly) + ddy, ddx * step, ddy * step);
+      // packed point = x << 18 | y << 4 | (sign of gx + 1) << 2 | (sign of gy + 1), the gradient (dx, dy) * (+-255): pack_point
+      // without its divisions by 255
+      const int sgn = (w[u] >> 31) ? -1 : 1;
+      pts[off[u] + tb[u].y + ((w[u] >> 8) & 2047u)] = ((uint32_t)(2 * (X0 + plx) + ddx) << 18) | ((uint32_t)(2 * (Y0 + ly) + ddy) << 4) |
+                                                       ((uint32_t)(ddx * sgn + 1) << 2) | (uint32_t)(ddy * sgn + 1);
     }
   }
   uint32_t nl = counters[frame].nlong;
