@@ -921,11 +921,14 @@ __device__ __forceinline__ void fit_quads_body(const FrameDesc* __restrict__ fra
   // Work is popped `pop` clusters at a time: one device-scope atomic on a single word saturates near 90
   // returns per microsecond (MI355X_MICROARCH.md, "dequeue"), which a one-cluster pop of the small classes
   // (0.7 M clusters per 256-frame submission) would hit.
-  uint32_t next_item = 0, chunk_left = 0;   // uniform
+  // The FIRST item of a workgroup is its own index -- no atomic: a one-frame submission has about as many clusters as the
+  // persistent grid has workgroups, and 4096 workgroups popping their first item from one cursor word (about 90 returns per
+  // microsecond) put the last cluster's start some 40 us behind the first's.  The cursor hands out the items from gridDim.x on.
+  uint32_t next_item = blockIdx.x, chunk_left = 1;   // uniform
   for (;;) {
     __syncthreads();   // the previous cluster's LDS use (and s_item) is finished in every wave
     if (chunk_left == 0) {
-      if (tid == 0) s_item = atomicAdd(work_cursor, (uint32_t)pop);
+      if (tid == 0) s_item = gridDim.x + atomicAdd(work_cursor, (uint32_t)pop);
       __syncthreads();
       next_item = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);   // uniform: keeps everything derived from it in SGPRs
       chunk_left = (uint32_t)pop;

@@ -70,11 +70,12 @@ __device__ __forceinline__ void fit_small_body(const FrameDesc* __restrict__ fra
   // points (stage 3, before c's error pass).  A cluster used to start with four dependent global round trips (list cursor /
   // item / record / points) in front of its first instruction, a fifth of its time when the kernel runs alone.
   typedef const __attribute__((address_space(1))) uint32_t* gptr32;
-  uint32_t next_item = 0, chunk_left = 0;   // uniform
+  uint32_t next_item = blockIdx.x, chunk_left = 1;   // uniform; the first item is the workgroup's own index (no atomic), the cursor
+                                                      // hands out the items from gridDim.x on (see k_fit_quads)
   auto next_index = [&]() -> uint32_t {
     if (chunk_left == 0) {
       uint32_t got = 0;
-      if (lane == 0) got = atomicAdd(work_cursor, (uint32_t)pop);
+      if (lane == 0) got = gridDim.x + atomicAdd(work_cursor, (uint32_t)pop);
       next_item = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
       chunk_left = (uint32_t)pop;
     }
