@@ -72,7 +72,7 @@ __device__ __forceinline__ uint32_t glb_find(const uint32_t* L, uint32_t i) {
 // Lock-free union (the larger root is pointed at the smaller one; entries only ever decrease towards the root, which is
 // what keeps concurrent unions correct).  Trees are never rebalanced, so a giant component's chain of tile-local roots
 // grows with the number of tiles it has crossed.  Two shortcuts were measured and dropped: path halving inside the find
-// (grandparent links at every hop: 1.27-1.36 vs 1.35-1.39 ms, noise) and pointing both START entries at the final root
+// (grandparent links at every hop: 1.27-1.36 vs 1.35-1.39 ms, noise; round 4 again: 0.71 vs 0.68 ms, one frame 0.41 vs 0.41 ms) and pointing both START entries at the final root
 // with an atomicMin after the union (1.54 ms: two more atomics on entries that are already contended).  What does help
 // is launching the frames of a submission interleaved (at_frame_block): the unions of one frame then contend with the
 // unions of other frames for the atomic units instead of with each other for the same few roots.
