@@ -874,11 +874,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
     // A small submission is about latency: all classes start together.
     // cheap exits of the large classes (bounding box, border direction, sector test) at full occupancy, ahead of their
     // persistent workgroups, which pop the survivors from the compact lists it writes (d_work2, counts at d_workctl + 16)
-#ifndef AMDAT_FQ_NO_PREFILTER
-    const bool prefilter = P.max_cluster_points > D->cls[D->prefilter_class].lo && D->d_work2;
-#else
-    const bool prefilter = false;
-#endif
+    const bool prefilter = FQ_SOUND_EXIT_PREFILTER && P.max_cluster_points > D->cls[D->prefilter_class].lo && D->d_work2;   // (tools_hooks.h: 1)
     uint32_t* const work2 = D->d_work2 ? D->d_work2 - D->work_layout.off[D->prefilter_class] : nullptr;   // (indexed with the common layout)
     // A small submission (the node's one-frame calls) is over when its slowest chain is: there the 256-thread class starts
     // at once beside the small classes (its in-kernel test after the first walk still drops most of its clusters) and

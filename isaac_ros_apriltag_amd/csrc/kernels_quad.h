@@ -1034,13 +1034,10 @@ __device__ __forceinline__ void fit_quads_body(const FrameDesc* __restrict__ fra
     const bool padded = in_lds && (1 << lpow) <= sort_cap;
     if (padded)
       for (int i = sz + tid; i < (1 << lpow); i += NT) skeys[FQ_KP(i)] = AT_KEY_PAD;
-#ifndef AMDAT_FQ_NO_PRESORT_EXIT
-    constexpr bool kPresort = SPLIT && NT >= FQ_PRESORT_MIN_NT;
+    constexpr bool kPresort = FQ_SOUND_EXIT_PRESORT && SPLIT && NT >= FQ_PRESORT_MIN_NT;   // (tools_hooks.h: 1 in the product build)
     if constexpr (kPresort)
       for (int t = tid; t < (FQ_XG + 1) * 7; t += NT) chunk[t] = 0.0;   // sector sums (pair-table region: free until the maxima exist)
-#endif
     __syncthreads();
-#ifndef AMDAT_FQ_NO_PRESORT_EXIT
     if constexpr (kPresort) {
       // ---- sound early exit before the sort (see fq_sector above) -------------------------------------------------
       // Every lane walks a run of consecutive keys of the (still unsorted) list -- points arrive tile by tile, so a run
@@ -1097,7 +1094,6 @@ __device__ __forceinline__ void fit_quads_body(const FrameDesc* __restrict__ fra
       FQ_COUNT(0, sz)
       if (!feas_pre) { FQ_COUNT(1, sz) continue; }
     }
-#endif
     // (a wave's own LDS accesses are ordered: the one-wave class needs no barrier around the register sort)
 #ifndef FQ_REGSORT_MAX_LPOW
 #define FQ_REGSORT_MAX_LPOW 8
@@ -1217,11 +1213,10 @@ __device__ __forceinline__ void fit_quads_body(const FrameDesc* __restrict__ fra
         }
         pos += s_coff[wv];
         szd = s_coff[NW];
-#ifndef AMDAT_FQ_NO_EARLY_EXIT
         // ---- sound early exit (see fq_arc_possible above): no four cut points can give four admissible arcs ------
         // The kept points of the sorted order are cut into FQ_XG groups (runs of NT / FQ_XG lanes); the inclusive
         // moment prefix at the end of every group goes to LDS (the pair-table region is free until the maxima exist).
-        {
+        if constexpr (FQ_SOUND_EXIT_AFTER_WALK1) {   // (tools_hooks.h: 1 in the product build)
           constexpr int LPG = NT / FQ_XG;
           double* const sP = chunk;   // [(FQ_XG + 1)][6]
           if (tid < 6) sP[tid] = 0.0;
@@ -1233,7 +1228,6 @@ __device__ __forceinline__ void fit_quads_body(const FrameDesc* __restrict__ fra
           __syncthreads();
           if (!fq_feasible<NT, 6, 5>(sP, P.max_line_fit_mse, W, H, s_okf, s_okw, &s_feasible)) { FQ_COUNT(2, sz) continue; }
         }
-#endif
       } else {
 #pragma unroll
         for (int j = 0; j < 6; j++) { off[j].hi = incl[j].hi - acc[j].hi; off[j].lo = incl[j].lo - acc[j].lo; }

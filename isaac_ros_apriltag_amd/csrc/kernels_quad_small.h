@@ -15,6 +15,10 @@
 //     normals or errors, with the pair indices of the 210 choices from a compile-time table.
 // One wave per cluster, no workgroup barriers that synchronise anything (a one-wave workgroup's barrier is only a
 // compiler fence).
+// K = 2 (clusters up to 128 points, moments in LDS) is the instance the library launches.  K = 4 (129 .. 256 points, GROWS: moments
+// in a global scratch slot, because 12 KB of them per workgroup would cut the resident workgroups to 10 per CU) compiles and is
+// bit-exact too, but measured no gain over k_fit_quads<64> for its sizes and is off: FS_B1 == FS_B0 in
+// detector.hip's class table leaves its class empty.
 #pragma once
 #include "kernels_quad.h"
 

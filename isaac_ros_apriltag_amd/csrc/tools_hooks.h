@@ -7,6 +7,7 @@
 //   -DAMDAT_PT_STOP=n       k_points returns after phase n                  (tools/pt_phase_insts.sh)
 //   -DAMDAT_CC_STOP=n       k_cc_local returns after phase n
 //   -DAMDAT_FQ_SKIP=mask    the launch sequence leaves out k_fit_quads classes (bits 0..4) or the prefilter (bit 5)
+//   -DAMDAT_FQ_NO_*         one of the quad fit's sound early exits compiled out (see below)
 // The stop builds key on P.max_nmaxima == 10 (always true) so that the compiler cannot fold the early exit at compile time
 // into dead-code elimination of the phases before it.
 #pragma once
@@ -100,6 +101,24 @@
 #else
 #define PF_HOOKS_DECL (void)prof;
 #define PF_TICK(slot)
+#endif
+
+// ---- the SOUND early exits of the quad fit can be compiled out, one by one, to show that no result depends on them
+// (-DAMDAT_FQ_NO_PRESORT_EXIT, -DAMDAT_FQ_NO_EARLY_EXIT, -DAMDAT_FQ_NO_PREFILTER: the A/B builds give the same bytes) ---------
+#ifdef AMDAT_FQ_NO_PRESORT_EXIT
+#define FQ_SOUND_EXIT_PRESORT 0
+#else
+#define FQ_SOUND_EXIT_PRESORT 1
+#endif
+#ifdef AMDAT_FQ_NO_EARLY_EXIT
+#define FQ_SOUND_EXIT_AFTER_WALK1 0
+#else
+#define FQ_SOUND_EXIT_AFTER_WALK1 1
+#endif
+#ifdef AMDAT_FQ_NO_PREFILTER
+#define FQ_SOUND_EXIT_PREFILTER 0
+#else
+#define FQ_SOUND_EXIT_PREFILTER 1
 #endif
 
 // ---- launch sequence (detector.hip) ---------------------------------------------------------------------------------------

@@ -159,3 +159,21 @@ def test_c99_example_compiles_and_links(tmp_path):
                            "-Wl,-rpath," + libdir, "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
+
+
+def test_no_measurement_hooks_in_the_kernel_sources():
+    """VERDICT round 3, hygiene: the tools-only switches (phase stops, cycle counters, timelines, class skips) live in
+    csrc/tools_hooks.h / tools_timeline.h only; the kernel sources and detector.hip invoke macros that expand to nothing in
+    the product build and carry no `#if` on those switches themselves."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "isaac_ros_apriltag_amd", "csrc")
+    pat = re.compile(r"^\s*#\s*(if|ifdef|ifndef|elif).*AMDAT_\w*(STOP|PROFILE|TIMELINE|SKIP|ASM_MARKS)")
+    offenders = []
+    for f in sorted(os.listdir(csrc)):
+        if f in ("tools_hooks.h", "tools_timeline.h") or not f.endswith((".h", ".hip")):
+            continue
+        for n, line in enumerate(open(os.path.join(csrc, f)), 1):
+            if pat.search(line):
+                offenders.append("%s:%d %s" % (f, n, line.strip()))
+    assert not offenders, offenders
