@@ -173,3 +173,45 @@ def test_register_sort_network_sorts(K):
                 S >>= 1
         flat = [v[l][j] for l in range(64) for j in range(K)]
         assert flat == sorted(keys)
+
+
+def _pidx(a, b):
+    return ((a * (19 - a)) >> 1) + b - a - 1
+
+
+def test_pair_and_corner_choice_tables():
+    """Index algebra of the quad fit's tail (kernels_quad.h: FQ_PIDX, fq_pair_of, make_combo_pairs): the triangular index
+    of the 45 pairs a < b < 10, its closed-form inverse, and the packed pair indices of the 210 corner choices in upstream's
+    loop order m0 < m1 < m2 < m3 (lexicographic: the first of equal errors wins)."""
+    pairs = [(a, b) for a in range(9) for b in range(a + 1, 10)]
+    assert [_pidx(a, b) for a, b in pairs] == list(range(45))
+    for t, (a, b) in enumerate(pairs):   # fq_pair_of
+        a2 = sum(t >= s for s in (9, 17, 24, 30, 35, 39, 42, 44))
+        b2 = t - ((a2 * (19 - a2)) >> 1) + a2 + 1
+        assert (a2, b2) == (a, b)
+    combos = [(m0, m1, m2, m3) for m0 in range(7) for m1 in range(m0 + 1, 8) for m2 in range(m1 + 1, 9) for m3 in range(m2 + 1, 10)]
+    assert len(combos) == 210 and combos == sorted(combos)
+    for m0, m1, m2, m3 in combos:
+        cp = _pidx(m0, m1) | (_pidx(m1, m2) << 6) | (_pidx(m2, m3) << 12) | (_pidx(m0, m3) << 18) | (m3 << 24)
+        assert (cp & 63, (cp >> 6) & 63, (cp >> 12) & 63, (cp >> 18) & 63, cp >> 24) == (_pidx(m0, m1), _pidx(m1, m2), _pidx(m2, m3), _pidx(m0, m3), m3)
+        assert max(_pidx(m0, m1), _pidx(m1, m2), _pidx(m2, m3), _pidx(m0, m3)) < 45 and cp < (1 << 28)
+
+
+def test_packed_gradient_sign_sums():
+    """k_fit_small reduces the border-direction sums in 32 bits: the signs of the two gradient components of a cluster's
+    points travel packed as sgn(gx) * 65536 + sgn(gy) and are separated after the wave sum (up to 256 points)."""
+    import random
+    rng = random.Random(3)
+    for _ in range(2000):
+        n = rng.randint(1, 256)
+        gx = [rng.choice((-1, 0, 1)) for _ in range(n)]
+        gy = [rng.choice((-1, 0, 1)) for _ in range(n)]
+        if rng.random() < 0.1:
+            gx = [rng.choice((-1, 1))] * n
+            gy = [rng.choice((-1, 1))] * n
+        sg = sum(a * 65536 + b for a, b in zip(gx, gy))
+        sg32 = (sg + (1 << 31)) % (1 << 32) - (1 << 31)            # int32 arithmetic
+        low = sg32 & 0xFFFF
+        sgy = low - 65536 if low >= 32768 else low                  # (int)(short)
+        sgx = (sg32 - sgy) >> 16
+        assert (sgx, sgy) == (sum(gx), sum(gy))
