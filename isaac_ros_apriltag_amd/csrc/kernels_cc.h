@@ -140,67 +140,70 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
 #pragma unroll
   for (int k = 0; k < ROWS; k++) vv[k] = st[(wv * ROWS + k) * CC_T + lane];
   const uint32_t vtop = wv > 0 ? (uint32_t)st[(wv * ROWS - 1) * CC_T + lane] : 127u;
-#define CC_LEFT(x) ((uint32_t)__builtin_amdgcn_update_dpp(127, (int)(x), 0x138, 0xF, 0xF, false))    /* lane i <- lane i - 1 (lane 0: 127) */
-#define CC_RIGHT(x) ((uint32_t)__builtin_amdgcn_update_dpp(127, (int)(x), 0x130, 0xF, 0xF, false))   /* lane i <- lane i + 1 (lane 63: 127) */
-  // ---- 1. run labelling per row (wave ballot, no atomics) -------------------------------------
+  // Class masks of the wave's rows (bit i = lane i) and of the row above the strip.  The link rules below are stated on these
+  // 64-bit masks with SCALAR shifts and logic -- a row of 64 pixels per instruction -- instead of per pixel on the vector unit
+  // (DPP moves of four neighbours and a dozen compares per pixel and row: the kernel is VALU-issue bound).
+  // (the masks of a row are formed where they are used -- two compares per row and pass -- so that only two rows' worth of them
+  // are live in scalar registers at a time)
+  const unsigned long long SRC = __ballot(src_ok);              // columns that may be a link source (1 <= x <= W - 2)
+  const unsigned long long LSRC = __ballot(gx - 1 >= 1);        // ... whose left neighbour is one
+  const unsigned long long RSRC = __ballot(gx + 1 <= W - 2);    // ... whose right neighbour is one
+  // (a lane's own bit of a uniform mask is the mask used as the execution mask -- inverse ballot, no vector instruction -- and
+  // the number of set bits below the lane is v_mbcnt on the scalar mask)
+  auto mine = [](unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); };
+  auto below_me = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+  // ---- 1. run labelling per row (wave masks, no atomics) --------------------------------------
   uint32_t linkmask = 0;   // bit k: the pixel continues the run of its left neighbour
 #pragma unroll
   for (int k = 0; k < ROWS; k++) {
     const int r = wv * ROWS + k;
-    const uint32_t v = vv[k];
-    const uint32_t vleft = CC_LEFT(v);   // (in every lane: a DPP read from an inactive lane returns the fill value)
-    const bool link = lane > 0 && v != 127 && src_ok && vleft == v;
-    if (link) linkmask |= 1u << k;
-    const unsigned long long L = __ballot(link);
+    // link: same class as the left neighbour (inside the tile: the shift leaves bit 0 clear) and a valid source column
+    const unsigned long long W_ = __ballot(vv[k] == 255u), B_ = __ballot(vv[k] == 0u);
+    const unsigned long long L = ((W_ & (W_ << 1)) | (B_ & (B_ << 1))) & SRC;
+    if (mine(L)) linkmask |= 1u << k;
     const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
     const unsigned long long m = ~L & below;  // run starts at or below this lane (lane 0 always set)
     const int s = 63 - __clzll((long long)m);
-    sl[r * CC_T + lane] = (v == 127) ? AT_NO_LABEL : (uint32_t)(r * CC_T + s);
+    sl[r * CC_T + lane] = (vv[k] == 127) ? AT_NO_LABEL : (uint32_t)(r * CC_T + s);
   }
   __syncthreads();
 
   CC_STOP_AT(1)   // (tools_hooks.h: nothing in the product build)
   // ---- 2. unions with the row above (only the first pixel of every overlap) -------------------
   // A lane has at most three links to the row above (up, up-left, up-right) and most lanes have none, so the link
-  // requests of four rows at a time are compacted into a wave-private list (ballot + popcount, no atomics) and the
+  // requests of four rows at a time are compacted into a wave-private list (mask + popcount, no atomics) and the
   // unions -- root chases and atomicMin retries -- run DENSE over it, every lane on a real link.  (Calling the union
   // under the three conditions directly ran each call on the few lanes that had that link and as long as the
   // longest chase among them.)  Entry = pixel << 2 | partner (0: up, 1: up-left, 2: up-right).
+  // The rules, per source pixel (x, y) of class c (x a source column, y > 0), on masks C = class c in this row, Cu = in the
+  // row above:  up: Cu, unless the left neighbour is a source of the class with its own up link to the same run (C << 1, Cu << 1);
+  // white only -- up-left: Wu << 1 and not Wu, unless the left neighbour is a white source; up-right: Wu >> 1, unless the
+  // right neighbour is a source and the pixel above or the right neighbour is white (they carry the link).
   {
     uint16_t* ureq = s_ureq + wv * UREQ;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned long long Wu = __ballot(vtop == 255u), Bu = __ballot(vtop == 0u);   // the row above the one in hand
 #pragma unroll
     for (int k0 = 0; k0 < ROWS; k0 += UROWS) {
       uint32_t nreq = 0;   // uniform
 #pragma unroll
       for (int kk = 0; kk < UROWS; kk++) {
-        const int r = wv * ROWS + k0 + kk;
-        bool up = false, upl = false, upr = false;
+        const int k = k0 + kk;   // (compile-time after unrolling)
+        const int r = wv * ROWS + k;
         const uint32_t me = (uint32_t)(r * CC_T + lane);
-        {
-          const int k = k0 + kk;   // (compile-time after unrolling: the register rows are indexed statically)
-          const uint32_t v = vv[k], vu = k > 0 ? vv[k - 1] : vtop;
-          // (the DPP moves run in every lane, outside the conditions)
-          const uint32_t vl = CC_LEFT(v), vul = CC_LEFT(vu), vur = CC_RIGHT(vu), vr = CC_RIGHT(v);
-          if (r > 0 && v != 127 && src_ok) {
-            const bool left_src = gx - 1 >= 1;  // (x-1) is itself a valid link source
-            up = vu == v && !(lane > 0 && left_src && vl == v && vul == v);
-            if (v == 255) {
-              upl = lane > 0 && vul == 255 && vu != 255 && !(left_src && vl == 255);
-              if (lane < 63) {
-                const bool right_src = gx + 1 <= W - 2;
-                upr = vur == 255 && !(right_src && (vu == 255 || vr == 255));
-              }
-            }
-          }
-        }
-        const unsigned long long m0 = __ballot(up), m1 = __ballot(upl), m2 = __ballot(upr);
-        if (up) ureq[nreq + (uint32_t)__popcll(m0 & lt_mask)] = (uint16_t)(me << 2);
+        uint32_t v2 = vv[k];
+        asm volatile("" : "+v"(v2));   // (opaque copy: the compiler otherwise keeps pass 1's 2 x ROWS masks alive for this pass and spills them)
+        const unsigned long long W_ = __ballot(v2 == 255u), B_ = __ballot(v2 == 0u);
+        const unsigned long long rows_ok = r > 0 ? SRC : 0ull;
+        const unsigned long long m0 = ((W_ & Wu & ~((W_ << 1) & (Wu << 1) & LSRC)) | (B_ & Bu & ~((B_ << 1) & (Bu << 1) & LSRC))) & rows_ok;
+        const unsigned long long m1 = W_ & (Wu << 1) & ~Wu & ~((W_ << 1) & LSRC) & rows_ok;
+        const unsigned long long m2 = W_ & (Wu >> 1) & ~((Wu | (W_ >> 1)) & RSRC) & rows_ok;
+        if (mine(m0)) ureq[nreq + below_me(m0)] = (uint16_t)(me << 2);
         nreq += (uint32_t)__popcll(m0);
-        if (upl) ureq[nreq + (uint32_t)__popcll(m1 & lt_mask)] = (uint16_t)((me << 2) | 1u);
+        if (mine(m1)) ureq[nreq + below_me(m1)] = (uint16_t)((me << 2) | 1u);
         nreq += (uint32_t)__popcll(m1);
-        if (upr) ureq[nreq + (uint32_t)__popcll(m2 & lt_mask)] = (uint16_t)((me << 2) | 2u);
+        if (mine(m2)) ureq[nreq + below_me(m2)] = (uint16_t)((me << 2) | 2u);
         nreq += (uint32_t)__popcll(m2);
+        Wu = W_; Bu = B_;
       }
       // (wave-private list: the wave's own LDS writes are visible to its later reads in program order)
       for (uint32_t i = (uint32_t)lane; i < nreq; i += 64) {
