@@ -39,21 +39,26 @@
 #ifndef CC_FLATTEN_HOPS
 #define CC_FLATTEN_HOPS 4
 #endif
+// The tile's parent array holds BYTE offsets into itself (pixel index << 2) while the unions run: a hop is then one LDS load
+// whose result is the next hop's address -- no shift per hop (the finds are a fifth of the kernel's vector instructions).
+__device__ __forceinline__ uint32_t* lds_at(uint32_t* L, uint32_t byte_off) {
+  return reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(L) + byte_off);
+}
 template <int HOPS = CC_FIND_HOPS>
-__device__ __forceinline__ uint32_t lds_find(const uint32_t* L, uint32_t i) {
+__device__ __forceinline__ uint32_t lds_find(uint32_t* L, uint32_t i) {   // i and the result: byte offsets
 #pragma unroll
-  for (int h = 0; h < HOPS; h++) i = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (int h = 0; h < HOPS; h++) i = __hip_atomic_load(lds_at(L, i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   uint32_t p;
-  while ((p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != i) i = p;
+  while ((p = __hip_atomic_load(lds_at(L, i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != i) i = p;
   return i;
 }
-__device__ __forceinline__ void lds_union(uint32_t* L, uint32_t a, uint32_t b) {
+__device__ __forceinline__ void lds_union(uint32_t* L, uint32_t a, uint32_t b) {   // byte offsets
   for (;;) {
     a = lds_find(L, a);
     b = lds_find(L, b);
     if (a == b) return;
     if (a < b) { uint32_t t = a; a = b; b = t; }
-    uint32_t old = atomicMin(&L[a], b);
+    uint32_t old = atomicMin(lds_at(L, a), b);
     if (old == a) return;
     a = old;
   }
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
     const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
     const unsigned long long m = ~L & below;  // run starts at or below this lane (lane 0 always set)
     const int s = 63 - __clzll((long long)m);
-    sl[r * CC_T + lane] = (vv[k] == 127) ? AT_NO_LABEL : (uint32_t)(r * CC_T + s);
+    sl[r * CC_T + lane] = (vv[k] == 127) ? AT_NO_LABEL : (uint32_t)(r * CC_T + s) << 2;   // (byte offset of the run's first pixel)
   }
   __syncthreads();
 
@@ -208,8 +213,8 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
       // (wave-private list: the wave's own LDS writes are visible to its later reads in program order)
       for (uint32_t i = (uint32_t)lane; i < nreq; i += 64) {
         const uint32_t q = ureq[i];
-        const uint32_t me = q >> 2, t = q & 3u;
-        lds_union(sl, me, me - CC_T - (t == 1u ? 1u : 0u) + (t == 2u ? 1u : 0u));
+        const uint32_t me4 = q & ~3u, t = q & 3u;   // (the entry's pixel << 2 IS the pixel's byte offset)
+        lds_union(sl, me4, me4 - 4u * CC_T - ((t & 1u) << 2) + ((t & 2u) << 1));
       }
     }
   }
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
   for (int k = 0; k < ROWS; k++) {
     const int r = wv * ROWS + k;
     const uint32_t l = sl[r * CC_T + lane];
-    root[k] = (l == AT_NO_LABEL) ? AT_NO_LABEL : lds_find<CC_FLATTEN_HOPS>(sl, (uint32_t)(r * CC_T + lane));
+    root[k] = (l == AT_NO_LABEL) ? AT_NO_LABEL : lds_find<CC_FLATTEN_HOPS>(sl, (uint32_t)(r * CC_T + lane) << 2) >> 2;   // (pixel index again)
   }
   __syncthreads();
   for (int k = 0; k < ROWS; k++) sl[(wv * ROWS + k) * CC_T + lane] = 0;
