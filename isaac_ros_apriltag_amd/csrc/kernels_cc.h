@@ -54,8 +54,18 @@ __device__ __forceinline__ uint32_t lds_find(uint32_t* L, uint32_t i) {   // i a
 }
 __device__ __forceinline__ void lds_union(uint32_t* L, uint32_t a, uint32_t b) {   // byte offsets
   for (;;) {
-    a = lds_find(L, a);
-    b = lds_find(L, b);
+    // (the two chases advance together: two independent loads in flight per step)
+#pragma unroll
+    for (int h = 0; h < CC_FIND_HOPS; h++) {
+      a = __hip_atomic_load(lds_at(L, a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      b = __hip_atomic_load(lds_at(L, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    for (;;) {
+      const uint32_t pa = __hip_atomic_load(lds_at(L, a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t pb = __hip_atomic_load(lds_at(L, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (pa == a && pb == b) break;
+      a = pa; b = pb;
+    }
     if (a == b) return;
     if (a < b) { uint32_t t = a; a = b; b = t; }
     uint32_t old = atomicMin(lds_at(L, a), b);
@@ -169,7 +179,9 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
     const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
     const unsigned long long m = ~L & below;  // run starts at or below this lane (lane 0 always set)
     const int s = 63 - __clzll((long long)m);
-    sl[r * CC_T + lane] = (vv[k] == 127) ? AT_NO_LABEL : (uint32_t)(r * CC_T + s) << 2;   // (byte offset of the run's first pixel)
+    // (byte offset of the run's first pixel; a pixel without a class is no link source or partner under any rule below, so it
+    // stays its own root and the flatten pass needs no case for it)
+    sl[r * CC_T + lane] = (vv[k] == 127) ? (uint32_t)(r * CC_T + lane) << 2 : (uint32_t)(r * CC_T + s) << 2;
   }
   __syncthreads();
 
@@ -222,12 +234,28 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
 
   CC_STOP_AT(2)
   // ---- 3. flatten into registers, then count pixels per root (one LDS atomic per run) ----------
+  // (the chases of the wave's rows advance together, one hop of every row per step: ROWS independent loads in flight instead of
+  // one chain after the other; hops past a root are harmless, it maps to itself)
   uint32_t root[ROWS];
-  for (int k = 0; k < ROWS; k++) {
-    const int r = wv * ROWS + k;
-    const uint32_t l = sl[r * CC_T + lane];
-    root[k] = (l == AT_NO_LABEL) ? AT_NO_LABEL : lds_find<CC_FLATTEN_HOPS>(sl, (uint32_t)(r * CC_T + lane) << 2) >> 2;   // (pixel index again)
+#pragma unroll
+  for (int k = 0; k < ROWS; k++) root[k] = (uint32_t)((wv * ROWS + k) * CC_T + lane) << 2;
+#pragma unroll
+  for (int h = 0; h < CC_FLATTEN_HOPS + 1; h++) {
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) root[k] = __hip_atomic_load(lds_at(sl, root[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
+  for (;;) {
+    bool moved = false;
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+      const uint32_t p = __hip_atomic_load(lds_at(sl, root[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      moved |= p != root[k];
+      root[k] = p;
+    }
+    if (!__any(moved)) break;
+  }
+#pragma unroll
+  for (int k = 0; k < ROWS; k++) root[k] = (vv[k] == 127) ? AT_NO_LABEL : root[k] >> 2;   // (pixel index again)
   __syncthreads();
   for (int k = 0; k < ROWS; k++) sl[(wv * ROWS + k) * CC_T + lane] = 0;
   __syncthreads();
@@ -267,23 +295,30 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
   if (tid == 0) s_rbase = s_nroots ? atomicAdd(&counters[frame].nroots, s_nroots) : 0;
   __syncthreads();
   rpos += s_rbase;
-  if (gx < W) {
-    for (int k = 0; k < ROWS; k++) {
+  // (straight-line per row: every lane forms its label -- the select of "no label" included -- and the row goes out as one
+  // predicated store; only the size and the list entry of a root, one lane per component, sit under a branch.  An early exit
+  // from the unrolled row loop had the compiler build a state machine around every row.)
+  {
+    const bool col_ok = gx < W;
+    uint32_t gi = (uint32_t)((Y0 + wv * ROWS) * W + gx);   // (W * H pixels of a frame index 32 bits: the labels are such indices)
+#pragma unroll
+    for (int k = 0; k < ROWS; k++, gi += (uint32_t)W) {
       const int r = wv * ROWS + k;
-      const int gy = Y0 + r;
-      if (gy >= H) break;
       const uint32_t me = (uint32_t)(r * CC_T + lane);
-      const size_t gi = (size_t)gy * W + gx;
-      if (root[k] == AT_NO_LABEL) { label[gi] = AT_NO_LABEL; continue; }
-      const uint32_t rr = root[k] / CC_T, rc = root[k] % CC_T;
-      uint32_t lab = (uint32_t)((Y0 + rr) * W + X0 + rc);
-      if (root[k] == me) {
-        const uint32_t cs = sl[me];
-        csize[gi] = cs & 0x7FFFFFFFu;
-        if (cs >> 31) roots[rpos++] = (uint32_t)gi;
-        else if ((int)cs >= P.min_component_size) lab |= AT_LABEL_BIG;   // complete inside this tile: size and representative are final
+      const uint32_t rt = root[k];
+      const uint32_t cs = sl[me];
+      const bool isroot = rt == me;   // (AT_NO_LABEL is no pixel index)
+      uint32_t lab = (uint32_t)((Y0 + (int)(rt / CC_T)) * W + X0 + (int)(rt % CC_T));
+      // complete inside this tile (no perimeter flag): size and representative are final
+      if (isroot && !(cs >> 31) && (int)cs >= P.min_component_size) lab |= AT_LABEL_BIG;
+      if (rt == AT_NO_LABEL) lab = AT_NO_LABEL;
+      if (col_ok && Y0 + r < H) {
+        label[gi] = lab;
+        if (isroot) {
+          csize[gi] = cs & 0x7FFFFFFFu;
+          if (cs >> 31) roots[rpos++] = gi;
+        }
       }
-      label[gi] = lab;
     }
   }
 }
