@@ -214,12 +214,16 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
         const unsigned long long m0 = ((W_ & Wu & ~((W_ << 1) & (Wu << 1) & LSRC)) | (B_ & Bu & ~((B_ << 1) & (Bu << 1) & LSRC))) & rows_ok;
         const unsigned long long m1 = W_ & (Wu << 1) & ~Wu & ~((W_ << 1) & LSRC) & rows_ok;
         const unsigned long long m2 = W_ & (Wu >> 1) & ~((Wu | (W_ >> 1)) & RSRC) & rows_ok;
-        if (mine(m0)) ureq[nreq + below_me(m0)] = (uint16_t)(me << 2);
-        nreq += (uint32_t)__popcll(m0);
-        if (mine(m1)) ureq[nreq + below_me(m1)] = (uint16_t)((me << 2) | 1u);
-        nreq += (uint32_t)__popcll(m1);
-        if (mine(m2)) ureq[nreq + below_me(m2)] = (uint16_t)((me << 2) | 2u);
-        nreq += (uint32_t)__popcll(m2);
+        // One entry per pixel with a link -- its up link, else its up-left link, else its up-right one (up and up-left exclude
+        // each other) -- and a second entry for the few pixels that have an up-right link besides: one compaction per row, and
+        // the second one behind a scalar branch.
+        const unsigned long long mp = m0 | m1 | m2, ms = m2 & (m0 | m1);
+        if (mine(mp)) ureq[nreq + below_me(mp)] = (uint16_t)((me << 2) | (mine(m0) ? 0u : mine(m1) ? 1u : 2u));
+        nreq += (uint32_t)__popcll(mp);
+        if (ms) {
+          if (mine(ms)) ureq[nreq + below_me(ms)] = (uint16_t)((me << 2) | 2u);
+          nreq += (uint32_t)__popcll(ms);
+        }
         Wu = W_; Bu = B_;
       }
       // (wave-private list: the wave's own LDS writes are visible to its later reads in program order)
