@@ -105,8 +105,12 @@ __device__ __forceinline__ void glb_union(uint32_t* L, uint32_t a, uint32_t b) {
 
 // NW waves per tile: 4 (throughput: a lane walks 16 rows, 7 workgroups per CU) or 16 (small submissions: 4 rows per lane --
 // a one-frame call has two tiles per CU and is over when the slowest tile is, so the chain per wave is what counts).
+// (register budget of k_cc_local: at least this many waves per SIMD)
+#ifndef CC_LOCAL_MIN_WAVES
+#define CC_LOCAL_MIN_WAVES 7
+#endif
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict__ thr_all, uint32_t* __restrict__ label_all,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CC_LOCAL_MIN_WAVES, 8))) void k_cc_local(const uint8_t* __restrict__ thr_all, uint32_t* __restrict__ label_all,
                                                   uint32_t* __restrict__ csize_all, uint32_t* __restrict__ roots_all,
                                                   FrameCounters* __restrict__ counters, DetParams P) {
   // (the threshold tile is only read into registers right after the load; the link-request lists of the union pass take
@@ -146,14 +150,27 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
 
   const int lane = tid & 63, wv = tid >> 6;
   const int gx = X0 + lane;
+  // Byte offset of the lane's pixel in the first row of the wave's strip: row k of the strip is this plus the CONSTANT k * 256, in
+  // the parent array (an immediate offset of the LDS instruction) and as a label (one OR).  Every pass takes an opaque copy:
+  // formed from the row index per row, the compiler kept the ROWS offsets in a register each from the first pass to the last.
+  const uint32_t me4w = (uint32_t)(wv * ROWS * CC_T + lane) << 2;
+  auto fresh = [](uint32_t x) { asm volatile("" : "+v"(x)); return x; };
   const bool src_ok = gx >= 1 && gx <= W - 2;  // this column may be a link source
 
   // The lane's column of the wave's ROWS rows stays in registers from here on, and so does the row above the strip; left and
   // right neighbours come over the DPP network (wave_shr:1 / wave_shl:1), not from the byte array again -- the three passes
   // below used to re-read it eight times per pixel.
-  uint32_t vv[ROWS];
+  // (four rows to a register, read back with byte selects: sixteen separate registers cost the kernel a wave of occupancy)
+  uint32_t vv4[(ROWS + 3) / 4];
 #pragma unroll
-  for (int k = 0; k < ROWS; k++) vv[k] = st[(wv * ROWS + k) * CC_T + lane];
+  for (int j = 0; j < (ROWS + 3) / 4; j++) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int b = 0; b < 4 && 4 * j + b < ROWS; b++) w |= (uint32_t)st[(wv * ROWS + 4 * j + b) * CC_T + lane] << (8 * b);
+    asm volatile("" : "+v"(w));   // (opaque: keeps the compiler from carrying the bytes unpacked)
+    vv4[j] = w;
+  }
+  auto px = [&](int k) { return (vv4[k >> 2] >> (8 * (k & 3))) & 0xFFu; };
   const uint32_t vtop = wv > 0 ? (uint32_t)st[(wv * ROWS - 1) * CC_T + lane] : 127u;
   // Class masks of the wave's rows (bit i = lane i) and of the row above the strip.  The link rules below are stated on these
   // 64-bit masks with SCALAR shifts and logic -- a row of 64 pixels per instruction -- instead of per pixel on the vector unit
@@ -168,21 +185,31 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
   auto mine = [](unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); };
   auto below_me = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
   // ---- 1. run labelling per row (wave masks, no atomics) --------------------------------------
-  uint32_t linkmask = 0;   // bit k: the pixel continues the run of its left neighbour
+  // The LAST pixel of a black or white run keeps the run's length (one byte per row, four rows to a register): pass 3 adds it
+  // to the component's count from there, with no run geometry to work out again.
+  static_assert(CC_T == 64, "a tile row is one wave wide; byte offsets split into row (>> 8) and column");
+  uint32_t runlen[(ROWS + 3) / 4];
+#pragma unroll
+  for (int j = 0; j < (ROWS + 3) / 4; j++) runlen[j] = 0;
+  const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+  const uint32_t strip4 = fresh((uint32_t)(wv * ROWS * CC_T) << 2);   // byte offset of the strip's first pixel
+  uint32_t* const sl1 = lds_at(sl, fresh(me4w));
 #pragma unroll
   for (int k = 0; k < ROWS; k++) {
-    const int r = wv * ROWS + k;
-    // link: same class as the left neighbour (inside the tile: the shift leaves bit 0 clear) and a valid source column
-    const unsigned long long W_ = __ballot(vv[k] == 255u), B_ = __ballot(vv[k] == 0u);
-    const unsigned long long L = ((W_ & (W_ << 1)) | (B_ & (B_ << 1))) & SRC;
-    if (mine(L)) linkmask |= 1u << k;
-    const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    // link: same class as the left neighbour (inside the tile: the shift leaves bit 0 clear) and a valid source column.
+    // Pixels without a class form runs like the others here: no rule below makes them a link source or partner, their entries are
+    // chased by nobody, and the flatten pass overrides their label -- so the label store needs no case for them.
+    const unsigned long long W_ = __ballot(px(k) == 255u), B_ = __ballot(px(k) == 0u), N_ = ~(W_ | B_);
+    const unsigned long long L = ((W_ & (W_ << 1)) | (B_ & (B_ << 1)) | (N_ & (N_ << 1))) & SRC;
     const unsigned long long m = ~L & below;  // run starts at or below this lane (lane 0 always set)
     const int s = 63 - __clzll((long long)m);
-    // (byte offset of the run's first pixel; a pixel without a class is no link source or partner under any rule below, so it
-    // stays its own root and the flatten pass needs no case for it)
-    sl[r * CC_T + lane] = (vv[k] == 127) ? (uint32_t)(r * CC_T + lane) << 2 : (uint32_t)(r * CC_T + s) << 2;
+    sl1[k * CC_T] = strip4 + (uint32_t)(k * CC_T * 4) + ((uint32_t)s << 2);   // byte offset of the run's first pixel
+    const unsigned long long ends = (~(L >> 1) | (1ull << 63)) & ~N_;   // last pixels of the black and white runs
+    runlen[k >> 2] |= (mine(ends) ? (uint32_t)(lane + 1 - s) : 0u) << (8 * (k & 3));
   }
+  // (opaque: the compiler otherwise sees through the packing and carries the ROWS lengths in a register each)
+#pragma unroll
+  for (int j = 0; j < (ROWS + 3) / 4; j++) asm volatile("" : "+v"(runlen[j]));
   __syncthreads();
 
   CC_STOP_AT(1)   // (tools_hooks.h: nothing in the product build)
@@ -198,6 +225,7 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
   // right neighbour is a source and the pixel above or the right neighbour is white (they carry the link).
   {
     uint16_t* ureq = s_ureq + wv * UREQ;
+    const uint32_t me4 = fresh(me4w);
     unsigned long long Wu = __ballot(vtop == 255u), Bu = __ballot(vtop == 0u);   // the row above the one in hand
 #pragma unroll
     for (int k0 = 0; k0 < ROWS; k0 += UROWS) {
@@ -205,12 +233,11 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
 #pragma unroll
       for (int kk = 0; kk < UROWS; kk++) {
         const int k = k0 + kk;   // (compile-time after unrolling)
-        const int r = wv * ROWS + k;
-        const uint32_t me = (uint32_t)(r * CC_T + lane);
-        uint32_t v2 = vv[k];
+        const uint32_t e4 = me4 | (uint32_t)(k * CC_T * 4);   // the pixel's byte offset: the entry's upper 14 bits
+        uint32_t v2 = px(k);
         asm volatile("" : "+v"(v2));   // (opaque copy: the compiler otherwise keeps pass 1's 2 x ROWS masks alive for this pass and spills them)
         const unsigned long long W_ = __ballot(v2 == 255u), B_ = __ballot(v2 == 0u);
-        const unsigned long long rows_ok = r > 0 ? SRC : 0ull;
+        const unsigned long long rows_ok = SRC;   // (the tile's first row has no row above: vtop is 127 there, Wu = Bu = 0 and every rule below comes out empty)
         const unsigned long long m0 = ((W_ & Wu & ~((W_ << 1) & (Wu << 1) & LSRC)) | (B_ & Bu & ~((B_ << 1) & (Bu << 1) & LSRC))) & rows_ok;
         const unsigned long long m1 = W_ & (Wu << 1) & ~Wu & ~((W_ << 1) & LSRC) & rows_ok;
         const unsigned long long m2 = W_ & (Wu >> 1) & ~((Wu | (W_ >> 1)) & RSRC) & rows_ok;
@@ -218,10 +245,10 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
         // each other) -- and a second entry for the few pixels that have an up-right link besides: one compaction per row, and
         // the second one behind a scalar branch.
         const unsigned long long mp = m0 | m1 | m2, ms = m2 & (m0 | m1);
-        if (mine(mp)) ureq[nreq + below_me(mp)] = (uint16_t)((me << 2) | (mine(m0) ? 0u : mine(m1) ? 1u : 2u));
+        if (mine(mp)) ureq[nreq + below_me(mp)] = (uint16_t)(e4 | (mine(m0) ? 0u : mine(m1) ? 1u : 2u));
         nreq += (uint32_t)__popcll(mp);
         if (ms) {
-          if (mine(ms)) ureq[nreq + below_me(ms)] = (uint16_t)((me << 2) | 2u);
+          if (mine(ms)) ureq[nreq + below_me(ms)] = (uint16_t)(e4 | 2u);
           nreq += (uint32_t)__popcll(ms);
         }
         Wu = W_; Bu = B_;
@@ -229,8 +256,8 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
       // (wave-private list: the wave's own LDS writes are visible to its later reads in program order)
       for (uint32_t i = (uint32_t)lane; i < nreq; i += 64) {
         const uint32_t q = ureq[i];
-        const uint32_t me4 = q & ~3u, t = q & 3u;   // (the entry's pixel << 2 IS the pixel's byte offset)
-        lds_union(sl, me4, me4 - 4u * CC_T - ((t & 1u) << 2) + ((t & 2u) << 1));
+        const uint32_t p4 = q & ~3u, t = q & 3u;
+        lds_union(sl, p4, p4 - 4u * CC_T - ((t & 1u) << 2) + ((t & 2u) << 1));
       }
     }
   }
@@ -241,10 +268,13 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
   // (the chases of the wave's rows advance together, one hop of every row per step: ROWS independent loads in flight instead of
   // one chain after the other; hops past a root are harmless, it maps to itself)
   uint32_t root[ROWS];
+  {
+    uint32_t* const sl3 = lds_at(sl, fresh(me4w));
 #pragma unroll
-  for (int k = 0; k < ROWS; k++) root[k] = (uint32_t)((wv * ROWS + k) * CC_T + lane) << 2;
+    for (int k = 0; k < ROWS; k++) root[k] = __hip_atomic_load(&sl3[k * CC_T], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (the pixel's own entry)
+  }
 #pragma unroll
-  for (int h = 0; h < CC_FLATTEN_HOPS + 1; h++) {
+  for (int h = 0; h < CC_FLATTEN_HOPS; h++) {
 #pragma unroll
     for (int k = 0; k < ROWS; k++) root[k] = __hip_atomic_load(lds_at(sl, root[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
@@ -258,23 +288,25 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
     }
     if (!__any(moved)) break;
   }
+  // (root[] stays in byte offsets: the count pass addresses with it, the write pass splits it into row and column)
 #pragma unroll
-  for (int k = 0; k < ROWS; k++) root[k] = (vv[k] == 127) ? AT_NO_LABEL : root[k] >> 2;   // (pixel index again)
+  for (int k = 0; k < ROWS; k++) root[k] = (px(k) == 127u) ? AT_NO_LABEL : root[k];
   __syncthreads();
-  for (int k = 0; k < ROWS; k++) sl[(wv * ROWS + k) * CC_T + lane] = 0;
+  {
+    uint32_t* const sl3 = lds_at(sl, fresh(me4w));
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) sl3[k * CC_T] = 0;
+  }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < ROWS; k++) {
-    const int r = wv * ROWS + k;
-    const uint32_t v = vv[k];
-    const bool link = (linkmask >> k) & 1u;
-    const unsigned long long S = ~__ballot(link);  // run starts
-    if (!link && v != 127) {
-      const unsigned long long higher = (lane == 63) ? 0ull : (S & ~((2ull << lane) - 1ull));
-      const int e = higher ? __ffsll((long long)higher) - 1 : 64;
-      atomicAdd(&sl[root[k]], (uint32_t)(e - lane));
-      // a component can only ever merge with another tile's through a pixel on the tile's perimeter: flag it (bit 31)
-      if (r == 0 || r == CC_T - 1 || lane == 0 || e == 64) atomicOr(&sl[root[k]], 0x80000000u);
+    const uint32_t len = (runlen[k >> 2] >> (8 * (k & 3))) & 0xFFu;   // (nonzero on the last pixel of a black or white run)
+    if (len) {
+      atomicAdd(lds_at(sl, root[k]), len);
+      // a component can only ever merge with another tile's through a pixel on the tile's perimeter: flag it (bit 31).
+      // (first or last row of the tile, a run from column 0 -- its length is then the lane + 1 -- or one up to column 63)
+      const bool edge_row = (k == 0 && wv == 0) || (k == ROWS - 1 && wv == NW - 1);
+      if (edge_row || len == (uint32_t)(lane + 1) || lane == 63) atomicOr(lds_at(sl, root[k]), 0x80000000u);
     }
   }
   __syncthreads();
@@ -290,9 +322,12 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
   // this tile (its label and size are final here), so the passes over the list (k_cc_sizes, k_cc_resolve) skip the
   // interior specks that make up most components of a noisy frame.
   uint32_t myroots = 0;
-  for (int k = 0; k < ROWS; k++) {
-    const uint32_t me = (uint32_t)((wv * ROWS + k) * CC_T + lane);
-    if (root[k] != AT_NO_LABEL && root[k] == me && (sl[me] >> 31)) myroots++;
+  {
+    const uint32_t me4 = fresh(me4w);
+    const uint32_t* const sl4 = lds_at(sl, me4);
+#pragma unroll
+    for (int k = 0; k < ROWS; k++)
+      if (root[k] == (me4 | (uint32_t)(k * CC_T * 4)) && (sl4[k * CC_T] >> 31)) myroots++;   // (AT_NO_LABEL is no pixel's byte offset)
   }
   uint32_t rpos = myroots ? atomicAdd(&s_nroots, myroots) : 0;
   __syncthreads();
@@ -304,19 +339,21 @@ __global__ __launch_bounds__(NW * 64) void k_cc_local(const uint8_t* __restrict_
   // from the unrolled row loop had the compiler build a state machine around every row.)
   {
     const bool col_ok = gx < W;
-    uint32_t gi = (uint32_t)((Y0 + wv * ROWS) * W + gx);   // (W * H pixels of a frame index 32 bits: the labels are such indices)
+    const int gyw = Y0 + wv * ROWS;   // image row of the strip's first row
+    uint32_t gi = (uint32_t)(gyw * W + gx);   // (W * H pixels of a frame index 32 bits: the labels are such indices)
+    const uint32_t me4 = fresh(me4w);
+    const uint32_t* const sl4 = lds_at(sl, me4);
 #pragma unroll
     for (int k = 0; k < ROWS; k++, gi += (uint32_t)W) {
-      const int r = wv * ROWS + k;
-      const uint32_t me = (uint32_t)(r * CC_T + lane);
-      const uint32_t rt = root[k];
-      const uint32_t cs = sl[me];
-      const bool isroot = rt == me;   // (AT_NO_LABEL is no pixel index)
-      uint32_t lab = (uint32_t)((Y0 + (int)(rt / CC_T)) * W + X0 + (int)(rt % CC_T));
+      const uint32_t rt = root[k];    // byte offset of the root pixel in the tile
+      const uint32_t cs = sl4[k * CC_T];
+      const bool isroot = rt == (me4 | (uint32_t)(k * CC_T * 4));   // (AT_NO_LABEL is no pixel's byte offset)
+      // (24-bit multiply: one full-rate instruction; rows and the width are far below 2^24)
+      uint32_t lab = __umul24((uint32_t)Y0 + (rt >> 8), (uint32_t)W) + (uint32_t)X0 + ((rt >> 2) & (CC_T - 1));
       // complete inside this tile (no perimeter flag): size and representative are final
       if (isroot && !(cs >> 31) && (int)cs >= P.min_component_size) lab |= AT_LABEL_BIG;
       if (rt == AT_NO_LABEL) lab = AT_NO_LABEL;
-      if (col_ok && Y0 + r < H) {
+      if (col_ok && gyw < H - k) {
         label[gi] = lab;
         if (isroot) {
           csize[gi] = cs & 0x7FFFFFFFu;
