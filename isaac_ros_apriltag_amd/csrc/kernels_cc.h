@@ -107,22 +107,25 @@ __device__ __forceinline__ void glb_union(uint32_t* L, uint32_t a, uint32_t b) {
 // a one-frame call has two tiles per CU and is over when the slowest tile is, so the chain per wave is what counts).
 // (register budget of k_cc_local: at least this many waves per SIMD)
 #ifndef CC_LOCAL_MIN_WAVES
-#define CC_LOCAL_MIN_WAVES 7
+#define CC_LOCAL_MIN_WAVES 8
 #endif
 template <int NW>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CC_LOCAL_MIN_WAVES, 8))) void k_cc_local(const uint8_t* __restrict__ thr_all, uint32_t* __restrict__ label_all,
                                                   uint32_t* __restrict__ csize_all, uint32_t* __restrict__ roots_all,
                                                   FrameCounters* __restrict__ counters, DetParams P) {
   // (the threshold tile is only read into registers right after the load; the link-request lists of the union pass take
-  // over its space -- a barrier lies between -- which brings the block from 26.6 to 22.6 KB of LDS: 7 blocks per CU, not 6)
+  // over its space -- a barrier lies between)
   constexpr int ROWS = CC_T / NW;                                   // rows of a wave's strip
   constexpr int UROWS = ROWS < CC_UROWS ? ROWS : CC_UROWS;          // rows per batch of link requests
-  constexpr int UREQ = UROWS * 3 * 64;                              // link requests of UROWS rows of one wave (at most three per pixel)
+  constexpr int UREQ = UROWS * 2 * 64;                              // link requests of UROWS rows of one wave (at most two entries per pixel)
   __shared__ __attribute__((aligned(16))) uint8_t s_tile_or_requests[(CC_T * CC_T > NW * UREQ * 2) ? CC_T * CC_T : NW * UREQ * 2];
   uint8_t* const st = s_tile_or_requests;
   uint16_t* const s_ureq = reinterpret_cast<uint16_t*>(s_tile_or_requests);
   __shared__ uint32_t sl[CC_T * CC_T];
-  __shared__ uint32_t s_nroots, s_rbase;
+  // (the two words of the root-list pass live in the request area, dead by then: with 4 waves the block is 20 KB of LDS to the
+  // byte -- eight blocks per CU, and at 57 registers eight waves per SIMD)
+  uint32_t& s_nroots = reinterpret_cast<uint32_t*>(s_tile_or_requests)[0];
+  uint32_t& s_rbase = reinterpret_cast<uint32_t*>(s_tile_or_requests)[1];
   const int frame = (int)blockIdx.z + P.frame0;
   const int X0 = blockIdx.x * CC_T, Y0 = blockIdx.y * CC_T;
   const int W = P.W, H = P.H;
