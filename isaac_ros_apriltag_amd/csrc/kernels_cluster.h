@@ -48,7 +48,8 @@ __device__ __forceinline__ uint32_t hash_insert(unsigned long long* hkeys, uint3
 
 // per-block table in LDS: returns entry index or -1 when full
 // (slot = top byte of a 32-bit multiplicative hash of the two labels: two quarter-rate multiplies instead of the four
-// of the frame table's 64-bit golden-ratio multiply, paid here once per emitted point)
+// of the frame table's 64-bit golden-ratio multiply, paid here once per emitted point.  Two full-rate 24-bit multiplies with
+// 24-bit constants spread the keys so much worse that the kernel went from 3.3 to 4.5 ms.)
 __device__ __forceinline__ uint32_t ltab_hash(uint64_t key) {
   const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
   return (lo * 0x9E3779B1u + hi * 0x85EBCA77u) >> 24;
@@ -217,18 +218,52 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   __syncthreads();
   PT_TICK(2)
   PT_STOP_AT(4, stage_all[(size_t)frame * P.pcap + (blk_ % 64u) * 256 + tid] = emask ^ off ^ elist[tid])
-  // pass 2, DENSE over the list (entry q belongs to thread q mod 256): pair key -> block table entry e (one insert), and
-  // the emission's rank inside its (block, pair) group from the value the counting atomic returns -- on a full wave of
-  // real emissions the returning LDS atomic costs what a leader loop over the wave's distinct entries does, and the
-  // insert is paid once per emission instead of once per (pixel, direction) slot.  Record |= e << 12 | rank << 20
-  // (e = 255: the table was full, the pair goes straight to the frame table in pass 3).
+  // pass 2, DENSE over the list (entry q belongs to thread q mod 256): pair key -> block table entry e (one insert), the
+  // emission's rank inside its (block, pair) group from the value the counting atomic returns -- on a full wave of real
+  // emissions the returning LDS atomic costs what a leader loop over the wave's distinct entries does, and the insert is
+  // paid once per emission instead of once per (pixel, direction) slot -- and, with both in hand, the staging record itself:
+  // the stores of a wave are 64 consecutive words.  (The records used to go back to the list for a third pass behind a
+  // barrier, which read the tile again for the sign bit: 0.7 ms of the kernel for a copy.)
+  // A staging record is ONE word -- block-table entry (8 bits) | rank inside the (block, pair) group (11) | pixel of the tile
+  // (10) | direction (2) | sign of the value step (1) -- because everything else k_scatter needs is per block: the tile origin
+  // follows from the block index, the pair-table slot and the block's base rank inside the cluster from the table entry (btab),
+  // the range of the block's records from its header (bhdr).  (8-byte records {slot | rank, packed point} were 40 % more bytes
+  // through the staging buffer and back.)  The few emissions without a table entry -- block table full, or beyond the list --
+  // take their slot and rank from the frame table one by one and go to a side list of long records.
+  const uint32_t base = sbase;
+  if (base + total > P.pcap) {
+    if (tid == 0) atomicOr(&counters[frame].flags, 0x1u);
+  }
+  uint32_t* stage = stage_all + (size_t)frame * P.pcap;
+  if (tid == 0) bhdr_all[(size_t)frame * bpf + blk_] = make_uint2(base, base + total > P.pcap ? (base < P.pcap ? P.pcap - base : 0u) : total);
+  // an emission that is not counted in the block table: straight to the frame table and to the long records; its staging word
+  // says "not here" (entry 255: k_scatter skips it)
+  auto emit_long = [&](uint32_t pixd, uint32_t pos) {
+    const int ly = (int)(pixd & 1023u) >> 6, plx = (int)(pixd & 63u), d = (int)((pixd >> 10) & 3u);
+    const int c = ly * PT_LW + plx + 1;
+    const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
+    const uint32_t s0 = slab[c], s1 = slab[c + ddy * PT_LW + ddx];
+    const uint32_t r0 = s0 & AT_LABEL_MASK, r1 = s1 & AT_LABEL_MASK;
+    const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
+    const uint32_t slot = hash_insert(hkeys, P.hcap, P.hshift, key);
+    if (slot == AT_INVALID_SLOT) atomicOr(&counters[frame].flags, 0x2u);
+    else {
+      const uint32_t rk = atomicAdd(&hcnt[slot], 1u);
+      const uint32_t li = atomicAdd(&counters[frame].nlong, 1u);
+      const int v0 = (s0 >> 31) ? 255 : 0, v1 = (s1 >> 31) ? 255 : 0;
+      if (li < P.lcap) long_all[(size_t)frame * P.lcap + li] = make_uint4(slot, rk, pack_point(2 * (X0 + plx) + ddx, 2 * (Y0 + ly) + ddy, ddx * (v1 - v0), ddy * (v1 - v0)), 0u);
+      else atomicOr(&counters[frame].flags, 0x1u);   // (the point buffers grow together)
+    }
+    if (pos < P.pcap) __builtin_nontemporal_store(0xFFFFFFFFu, stage + pos);
+  };
   const uint32_t nlist = total < PT_ELIST ? total : PT_ELIST;
   for (uint32_t q = tid; q < nlist; q += 256) {
     const uint32_t rec = elist[q];
     const int ly = (int)(rec & 1023u) >> 6, plx = (int)(rec & 63u), d = (int)((rec >> 10) & 3u);
     const int c = ly * PT_LW + plx + 1;
     const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
-    const uint32_t r0 = slab[c] & AT_LABEL_MASK, r1 = slab[c + ddy * PT_LW + ddx] & AT_LABEL_MASK;
+    const uint32_t s0 = slab[c];
+    const uint32_t r0 = s0 & AT_LABEL_MASK, r1 = slab[c + ddy * PT_LW + ddx] & AT_LABEL_MASK;
     const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
     const int e = ltab_insert(tkey, key);
     uint32_t ee = 255u, rk = 0u;
@@ -250,63 +285,28 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     } else
 #endif
     if (e >= 0 && e < 255) { ee = (uint32_t)e; rk = atomicAdd(&tcnt[e], 1u); }
-    elist[q] = rec | (ee << 12) | (rk << 20);
+    if (ee != 255u) {
+      // (pixel | direction << 10 of the list record are the word's bits 19..30 as they stand; value step v1 - v0 = +-255: bit 31
+      // set when it is negative, v0 white.  Written once, read once by k_scatter two kernels later: non-temporal stores keep it
+      // out of the caches' way.)
+      const uint32_t w = ee | (rk << 8) | ((rec & 0xFFFu) << 19) | (s0 & 0x80000000u);
+      if (base + q < P.pcap) __builtin_nontemporal_store(w, stage + base + q);
+    } else emit_long(rec, base + q);
   }
-  __syncthreads();
   PT_TICK(3)
   PT_STOP_AT(3, stage_all[(size_t)frame * P.pcap + (blk_ % 64u) * 256 + tid] = emask ^ off ^ elist[tid] ^ sbase)
-  const uint32_t base = sbase;
-  if (base + total > P.pcap) {
-    if (tid == 0) atomicOr(&counters[frame].flags, 0x1u);
-  }
-  // pass 3: the staging records, dense over the list again (the stores of a wave are 64 consecutive words).  A record is
-  // ONE word -- block-table entry (8 bits) | rank inside the (block, pair) group (11) | pixel of the tile (10) | direction (2)
-  // | sign of the value step (1) -- because everything else k_scatter needs is per block: the tile origin follows from the
-  // block index, the pair-table slot and the block's base rank inside the cluster from the table entry (btab), the range
-  // of the block's records from its header (bhdr).  (8-byte records {slot | rank, packed point} were 40 % more bytes
-  // through the staging buffer and back.)  The few emissions without a table entry -- block table full, or beyond the
-  // list -- take their slot and rank from the frame table one by one and go to a side list of long records.
-  uint32_t* stage = stage_all + (size_t)frame * P.pcap;
-  if (tid == 0) bhdr_all[(size_t)frame * bpf + blk_] = make_uint2(base, base + total > P.pcap ? (base < P.pcap ? P.pcap - base : 0u) : total);
-  auto emit = [&](uint32_t rec, uint32_t pos) {
-    const int ly = (int)(rec & 1023u) >> 6, plx = (int)(rec & 63u), d = (int)((rec >> 10) & 3u);
-    const uint32_t e = (rec >> 12) & 255u;
-    const int c = ly * PT_LW + plx + 1;
-    const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
-    const int n = c + ddy * PT_LW + ddx;
-    const uint32_t s0 = slab[c], s1 = slab[n];
-    uint32_t w = 0xFFFFFFFFu;   // entry 255 = "not here": k_scatter skips the word
-    if (e != 255u) {
-      // value step v1 - v0 = +-255: bit 31 set when it is negative (v0 white)
-      w = e | ((rec >> 20) << 8) | ((rec & 1023u) << 19) | ((uint32_t)d << 29) | (s0 & 0x80000000u);
-    } else {  // not counted in the block table: this point goes straight to the frame table and to the long records
-      const uint32_t r0 = s0 & AT_LABEL_MASK, r1 = s1 & AT_LABEL_MASK;
-      const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
-      const uint32_t slot = hash_insert(hkeys, P.hcap, P.hshift, key);
-      if (slot == AT_INVALID_SLOT) atomicOr(&counters[frame].flags, 0x2u);
-      else {
-        const uint32_t rk = atomicAdd(&hcnt[slot], 1u);
-        const uint32_t li = atomicAdd(&counters[frame].nlong, 1u);
-        const int v0 = (s0 >> 31) ? 255 : 0, v1 = (s1 >> 31) ? 255 : 0;
-        if (li < P.lcap) long_all[(size_t)frame * P.lcap + li] = make_uint4(slot, rk, pack_point(2 * (X0 + plx) + ddx, 2 * (Y0 + ly) + ddy, ddx * (v1 - v0), ddy * (v1 - v0)), 0u);
-        else atomicOr(&counters[frame].flags, 0x1u);   // (the point buffers grow together)
-      }
-    }
-    // written once, read once by k_scatter two kernels later: non-temporal stores keep it out of the caches' way
-    if (pos < P.pcap) __builtin_nontemporal_store(w, stage + pos);
-  };
-  for (uint32_t q = tid; q < nlist; q += 256) emit(elist[q], base + q);
   if (off + cnt > PT_ELIST) {   // this thread's emissions beyond the list
     uint32_t q = off, m = emask;
     while (m) {
       const int sidx = __ffs((int)m) - 1;
       m &= m - 1;
-      if (q >= PT_ELIST)
-        emit((uint32_t)(((tid >> 6) + 4 * (sidx >> 2)) * 64 + lx) | ((uint32_t)(sidx & 3) << 10) | (255u << 12), base + q);
+      if (q >= PT_ELIST) emit_long((uint32_t)(((tid >> 6) + 4 * (sidx >> 2)) * 64 + lx) | ((uint32_t)(sidx & 3) << 10), base + q);
       q++;
     }
   }
+  __syncthreads();   // the block table's counts are complete
   PT_TICK(4)
+  PT_STOP_AT(5, (void)0)
   {
     // LAST, with nothing waiting for it: one global insert + one global add per distinct pair of this block; the add's
     // return value is the base rank of the block's points inside the cluster.  Slot and base go straight to the block's
