@@ -93,8 +93,12 @@ __device__ __forceinline__ uint32_t glb_find(const uint32_t* L, uint32_t i) {
 // unions of other frames for the atomic units instead of with each other for the same few roots.
 __device__ __forceinline__ void glb_union(uint32_t* L, uint32_t a, uint32_t b) {
   for (;;) {
-    a = glb_find(L, a);
-    b = glb_find(L, b);
+    // (the two chases advance together: two independent L2 round trips in flight per step, not one after the other)
+    for (;;) {
+      const uint32_t pa = glb_load(&L[a]), pb = glb_load(&L[b]);
+      if (pa == a && pb == b) break;
+      a = pa; b = pb;
+    }
     if (a == b) return;
     if (a < b) { uint32_t t = a; a = b; b = t; }
     uint32_t old = atomicMin(&L[a], b);
@@ -438,11 +442,18 @@ __global__ __launch_bounds__(256) void k_cc_border(const uint8_t* __restrict__ t
   // device-scope loads of the find start at the roots.  Along a tile border most links join the SAME two tile-local
   // roots again and again (the big components of a textured background cross it dozens of times): a wave keeps one
   // request per distinct pair of roots (a few leader rounds; what they do not cover is simply linked twice).
+  // (the first hops of all three requests are loaded before the first union: six independent loads in flight; a stale entry of
+  // a pixel that IS a root only names an ancestor the find passes through anyway)
+  uint32_t fa[3], fb[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    uint32_t a = AT_NO_LABEL, b2 = AT_NO_LABEL;
-    if (ra[k] != AT_NO_LABEL) {
-      a = label[ra[k]] & AT_LABEL_MASK; b2 = label[rb[k]] & AT_LABEL_MASK;
+    fa[k] = fb[k] = AT_NO_LABEL;
+    if (ra[k] != AT_NO_LABEL) { fa[k] = label[ra[k]] & AT_LABEL_MASK; fb[k] = label[rb[k]] & AT_LABEL_MASK; }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    uint32_t a = fa[k], b2 = fb[k];
+    if (a != AT_NO_LABEL) {
       if (a > b2) { const uint32_t t = a; a = b2; b2 = t; }
       if (a == b2) a = b2 = AT_NO_LABEL;   // already the same tile-local root
     }
