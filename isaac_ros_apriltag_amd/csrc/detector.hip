@@ -854,7 +854,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
   mark();
   {
     const uint32_t gxt = (uint32_t)((P.W + PT_TW - 1) / PT_TW), gyt = (uint32_t)((P.H + PT_TH - 1) / PT_TH);
-    hipLaunchKernelGGL(k_scatter, dim3(gxt * gyt, 1, n), dim3(256), 0, s, D->d_stage, D->d_bhdr, D->d_btab, D->d_long, D->d_hoff, D->d_pts,
+    hipLaunchKernelGGL(k_scatter, dim3((gxt * gyt + 3) / 4, 1, n), dim3(256), 0, s, D->d_stage, D->d_bhdr, D->d_btab, D->d_long, D->d_hoff, D->d_pts,
                        D->d_counters, gxt, gyt, P);
   }
   mark();

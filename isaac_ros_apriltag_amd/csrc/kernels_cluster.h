@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void k_cluster_select(unsigned long long* __re
 
 
 #ifndef SC_U
-#define SC_U 8   // records of a thread in flight together (2: 1.41 ms, 4: 1.20, 8: 1.13 per 256 frames)
+#define SC_U 8   // records of a lane in flight together (block per tile: 2: 1.41 ms, 4: 1.20, 8: 1.13 per 256 frames)
 #endif
 // One block per block of k_points (same tile): final position of a staged point = cluster range start (hoff of its pair's
 // slot) + the block's base rank inside the cluster + the point's rank inside the block's group; no atomics.  The packed
@@ -444,22 +444,25 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ st
                                                  const uint32_t* __restrict__ hoff_all, uint32_t* __restrict__ pts_all,
                                                  const FrameCounters* __restrict__ counters, uint32_t gx_tiles, uint32_t gy_tiles,
                                                  DetParams P) {
+  // One WAVE per tile of k_points (four tiles per block).  With a block per tile a thread had three records and the block was
+  // gone after four dependent round trips -- header, staging word, table entry, range start -- so the kernel ran at the pace of
+  // 8 blocks per CU times that latency; a wave per tile puts four times the records behind every wave slot's chain.
   const int frame = (int)blockIdx.z + P.frame0;
-  const uint32_t bpf = gx_tiles * gy_tiles, blk = blockIdx.x;
+  const uint32_t bpf = gx_tiles * gy_tiles, blk = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   const uint32_t* hoff = hoff_all + (size_t)frame * P.hcap;
   uint32_t* pts = pts_all + (size_t)frame * P.pcap;
-  const uint2 hdr = bhdr_all[(size_t)frame * bpf + blk];
+  const uint2 hdr = blk < bpf ? bhdr_all[(size_t)frame * bpf + blk] : make_uint2(0u, 0u);
   const uint2* btab = btab_all + ((size_t)frame * bpf + blk) * PT_TB;
   const uint32_t* stage = stage_all + (size_t)frame * P.pcap + hdr.x;
   const int X0 = (int)(blk % gx_tiles) * PT_TW, Y0 = (int)(blk / gx_tiles) * PT_TH;
   // Three dependent loads per record (staging word -> table entry -> range start).  A tile has a few records per thread:
   // they are taken SC_U at a time, level by level, so that the latencies of a thread's records overlap instead of adding up.
-  for (uint32_t i0 = threadIdx.x; i0 < hdr.y; i0 += SC_U * 256) {
+  for (uint32_t i0 = lane; i0 < hdr.y; i0 += SC_U * 64) {
     uint32_t w[SC_U], off[SC_U];
     uint2 tb[SC_U];
 #pragma unroll
     for (int u = 0; u < SC_U; u++) {
-      const uint32_t i = i0 + (uint32_t)u * 256u;
+      const uint32_t i = i0 + (uint32_t)u * 64u;
       w[u] = i < hdr.y ? __builtin_nontemporal_load(stage + i) : 0xFFFFFFFFu;
     }
 #pragma unroll
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ st
   }
   uint32_t nl = counters[frame].nlong;
   if (nl > P.lcap) nl = P.lcap;
-  for (uint32_t i = blk * 256 + threadIdx.x; i < nl; i += bpf * 256) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nl; i += gridDim.x * 256) {
     const uint4 r = long_all[(size_t)frame * P.lcap + i];
     const uint32_t off = hoff[r.x];
     if (off != AT_INVALID_SLOT) pts[off + r.y] = r.z;
