@@ -28,5 +28,5 @@ for c in range(5):
 pf = det.debug(0, 8).view(np.uint64)[60:64].astype(np.float64)
 print("prefilter cycles: box+dot %.0f%%, sector sums %.0f%%, scan + 32-sector test %.0f%%, 64-sector test %.0f%%" % tuple(100 * pf / max(pf.sum(), 1)))
 pt = det.debug(0, 8).view(np.uint64)[64:70].astype(np.float64)
-print("k_points cycles: tile load %.0f%%, emission tests + scan %.0f%%, list %.0f%%, block table %.0f%%, stores %.0f%%, frame table %.0f%%" % tuple(100 * pt / max(pt.sum(), 1)))
+print("k_points cycles: tile load %.0f%%, emission tests + scan %.0f%%, list %.0f%%, block table + staging stores %.0f%%, leftovers + barrier %.0f%%, frame table %.0f%%" % tuple(100 * pt / max(pt.sum(), 1)))
 det.close()
