@@ -52,10 +52,12 @@ def build_amd(force=False):
 
 def build_amd_variant(tag, defines):
     """Measurement builds for tools/ (e.g. -DAMDAT_FQ_PROFILE: per-phase cycle counters in the quad-fit kernel).
-    The product library carries none of this; the variant is written next to it as libapriltag_amd_<tag>.so."""
+    The product library carries none of this; the variant is written next to it as libapriltag_amd_<tag>.so.
+    An entry of `defines` that starts with "-" is passed to the compiler as it stands (e.g. "-mllvm", "-amdgpu-sched-strategy=max-ilp")."""
     out = os.path.join(_HERE, "libapriltag_amd_%s.so" % tag)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-fno-fast-math", "-Wno-unused-value", "-Wno-unused-function", "-Wno-pass-failed"] + ["-D" + d for d in defines] + \
+           "-fno-fast-math", "-Wno-unused-value", "-Wno-unused-function", "-Wno-pass-failed"] + \
+          [d if d.startswith("-") else "-D" + d for d in defines] + \
           [os.path.join(_CSRC, "detector.hip"), "-o", out]
     subprocess.check_call(cmd)
     return out
