@@ -174,10 +174,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CC_LOCA
     uint32_t w = 0;
 #pragma unroll
     for (int b = 0; b < 4 && 4 * j + b < ROWS; b++) w |= (uint32_t)st[(wv * ROWS + 4 * j + b) * CC_T + lane] << (8 * b);
+    // (the bytes become class codes -- black 0, no class 2, white 3: bit 7 and bit 0 of the values 0 / 127 / 255 -- so that the
+    // row passes compare against inline constants; 255 had to be put into a scalar register again for every row)
+    w = ((w >> 7) & 0x01010101u) | ((w << 1) & 0x02020202u);
     asm volatile("" : "+v"(w));   // (opaque: keeps the compiler from carrying the bytes unpacked)
     vv4[j] = w;
   }
-  auto px = [&](int k) { return (vv4[k >> 2] >> (8 * (k & 3))) & 0xFFu; };
+  constexpr uint32_t CLS_BLACK = 0u, CLS_NONE = 2u, CLS_WHITE = 3u;
+  auto px = [&](int k) { return (vv4[k >> 2] >> (8 * (k & 3))) & 0xFFu; };   // class code of the lane's pixel in row k
   const uint32_t vtop = wv > 0 ? (uint32_t)st[(wv * ROWS - 1) * CC_T + lane] : 127u;
   // Class masks of the wave's rows (bit i = lane i) and of the row above the strip.  The link rules below are stated on these
   // 64-bit masks with SCALAR shifts and logic -- a row of 64 pixels per instruction -- instead of per pixel on the vector unit
@@ -190,7 +194,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CC_LOCA
   // (a lane's own bit of a uniform mask is the mask used as the execution mask -- inverse ballot, no vector instruction -- and
   // the number of set bits below the lane is v_mbcnt on the scalar mask)
   auto mine = [](unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); };
-  auto below_me = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+  // (plus `base`: v_mbcnt adds its count to an accumulator operand, so a list position base + count costs no extra add)
+  auto below_me = [](unsigned long long m, uint32_t base) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base)); };
   // ---- 1. run labelling per row (wave masks, no atomics) --------------------------------------
   // The LAST pixel of a black or white run keeps the run's length (one byte per row, four rows to a register): pass 3 adds it
   // to the component's count from there, with no run geometry to work out again.
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CC_LOCA
     // link: same class as the left neighbour (inside the tile: the shift leaves bit 0 clear) and a valid source column.
     // Pixels without a class form runs like the others here: no rule below makes them a link source or partner, their entries are
     // chased by nobody, and the flatten pass overrides their label -- so the label store needs no case for them.
-    const unsigned long long W_ = __ballot(px(k) == 255u), B_ = __ballot(px(k) == 0u), N_ = ~(W_ | B_);
+    const unsigned long long W_ = __ballot(px(k) == CLS_WHITE), B_ = __ballot(px(k) == CLS_BLACK), N_ = ~(W_ | B_);
     const unsigned long long L = ((W_ & (W_ << 1)) | (B_ & (B_ << 1)) | (N_ & (N_ << 1))) & SRC;
     const unsigned long long m = ~L & below;  // run starts at or below this lane (lane 0 always set)
     const int s = 63 - __clzll((long long)m);
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CC_LOCA
         const uint32_t e4 = me4 | (uint32_t)(k * CC_T * 4);   // the pixel's byte offset: the entry's upper 14 bits
         uint32_t v2 = px(k);
         asm volatile("" : "+v"(v2));   // (opaque copy: the compiler otherwise keeps pass 1's 2 x ROWS masks alive for this pass and spills them)
-        const unsigned long long W_ = __ballot(v2 == 255u), B_ = __ballot(v2 == 0u);
+        const unsigned long long W_ = __ballot(v2 == CLS_WHITE), B_ = __ballot(v2 == CLS_BLACK);
         const unsigned long long rows_ok = SRC;   // (the tile's first row has no row above: vtop is 127 there, Wu = Bu = 0 and every rule below comes out empty)
         const unsigned long long m0 = ((W_ & Wu & ~((W_ << 1) & (Wu << 1) & LSRC)) | (B_ & Bu & ~((B_ << 1) & (Bu << 1) & LSRC))) & rows_ok;
         const unsigned long long m1 = W_ & (Wu << 1) & ~Wu & ~((W_ << 1) & LSRC) & rows_ok;
@@ -252,10 +257,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CC_LOCA
         // each other) -- and a second entry for the few pixels that have an up-right link besides: one compaction per row, and
         // the second one behind a scalar branch.
         const unsigned long long mp = m0 | m1 | m2, ms = m2 & (m0 | m1);
-        if (mine(mp)) ureq[nreq + below_me(mp)] = (uint16_t)(e4 | (mine(m0) ? 0u : mine(m1) ? 1u : 2u));
+        uint32_t t = mine(m1) ? 1u : 2u;   // (two selects on the scalar masks; the nested conditional came out as branches)
+        t = mine(m0) ? 0u : t;
+        if (mine(mp)) ureq[below_me(mp, nreq)] = (uint16_t)(e4 | t);
         nreq += (uint32_t)__popcll(mp);
         if (ms) {
-          if (mine(ms)) ureq[nreq + below_me(ms)] = (uint16_t)(e4 | 2u);
+          if (mine(ms)) ureq[below_me(ms, nreq)] = (uint16_t)(e4 | 2u);
           nreq += (uint32_t)__popcll(ms);
         }
         Wu = W_; Bu = B_;
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CC_LOCA
   }
   // (root[] stays in byte offsets: the count pass addresses with it, the write pass splits it into row and column)
 #pragma unroll
-  for (int k = 0; k < ROWS; k++) root[k] = (px(k) == 127u) ? AT_NO_LABEL : root[k];
+  for (int k = 0; k < ROWS; k++) root[k] = (px(k) == CLS_NONE) ? AT_NO_LABEL : root[k];
   __syncthreads();
   {
     uint32_t* const sl3 = lds_at(sl, fresh(me4w));
