@@ -30,9 +30,9 @@
 
 // (relaxed workgroup-scope atomic loads, not volatile ones: a volatile access keeps the generic address space and
 // compiles to flat_load ... sc0 sc1 through the shared aperture instead of ds_read_b32)
-// A root maps to itself, so hops past the root are harmless: the first CC_FIND_HOPS hops are taken unconditionally (a load
-// and an address shift each -- no compare, no exec-mask bookkeeping; the divergent loop's scalar instructions were as many as
-// the kernel's vector instructions), the loop only finishes the rare longer chains.
+// A root maps to itself, so hops past the root are harmless: the first CC_FIND_HOPS hops of a chase are taken unconditionally
+// (a load each -- no compare, no exec-mask bookkeeping; the divergent loop's scalar instructions were as many as the kernel's
+// vector instructions), the loop only finishes the rare longer chains.
 #ifndef CC_FIND_HOPS
 #define CC_FIND_HOPS 2
 #endif
@@ -43,14 +43,6 @@
 // whose result is the next hop's address -- no shift per hop (the finds are a fifth of the kernel's vector instructions).
 __device__ __forceinline__ uint32_t* lds_at(uint32_t* L, uint32_t byte_off) {
   return reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(L) + byte_off);
-}
-template <int HOPS = CC_FIND_HOPS>
-__device__ __forceinline__ uint32_t lds_find(uint32_t* L, uint32_t i) {   // i and the result: byte offsets
-#pragma unroll
-  for (int h = 0; h < HOPS; h++) i = __hip_atomic_load(lds_at(L, i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  uint32_t p;
-  while ((p = __hip_atomic_load(lds_at(L, i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != i) i = p;
-  return i;
 }
 __device__ __forceinline__ void lds_union(uint32_t* L, uint32_t a, uint32_t b) {   // byte offsets
   for (;;) {
@@ -78,11 +70,6 @@ __device__ __forceinline__ void lds_union(uint32_t* L, uint32_t a, uint32_t b) {
 // before k_cc_resolve, and those touch no tile border)
 __device__ __forceinline__ uint32_t glb_load(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint32_t glb_find(const uint32_t* L, uint32_t i) {
-  uint32_t p;
-  while ((p = glb_load(&L[i])) != i) i = p;
-  return i;
 }
 // Lock-free union (the larger root is pointed at the smaller one; entries only ever decrease towards the root, which is
 // what keeps concurrent unions correct).  Trees are never rebalanced, so a giant component's chain of tile-local roots
