@@ -40,6 +40,9 @@ __device__ __forceinline__ uint32_t hash_insert(unsigned long long* hkeys, uint3
   return AT_INVALID_SLOT;
 }
 
+#define PT_WHITE 0x80000000u   // slab word of k_points: class bits (white / black; neither: not in a counted component) ...
+#define PT_BLACK 0x40000000u
+#define PT_REP_MASK 0x3FFFFFFFu   // ... above the component's representative (a pixel index: images below 2^30 pixels)
 #define PT_TB 256  // entries of the per-block component-pair table
 #ifndef PT_ELIST
 #define PT_ELIST 2048   // emissions of one tile kept in the LDS list of pass 2 (the tile has 1024 pixels; tools builds shrink it
@@ -98,10 +101,12 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
                                                 unsigned long long* __restrict__ prof, uint32_t gx_tiles, uint32_t gy_tiles, uint32_t nframes,
                                                 DetParams P) {
   PT_HOOKS_DECL   // (tools_hooks.h: measurement hooks, nothing in the product build)
-  // tile + halo, one word per pixel: representative of the pixel's component if it is large enough, bit 31 = the pixel is
-  // white; AT_NO_LABEL = no component that counts (value 127, or too small).  Two labelled pixels have different values
-  // exactly when bit 31 differs, so the emission tests read this one array (a separate byte array of the values cost a
-  // second LDS read per test, and its four-pixels-per-bank byte reads were most of the kernel's LDS bank conflicts).
+  // tile + halo, one word per pixel: representative of the pixel's component if it is large enough, with the pixel's class in
+  // the two top bits -- white 10, black 01 -- and 0 = no component that counts (value 127, or too small).  Two pixels lie on
+  // opposite sides of an edge between counted components exactly when the XOR of their words has BOTH top bits set, so an
+  // emission test is one XOR and one compare on this one array (a separate byte array of the values cost a second LDS read
+  // per test, and its four-pixels-per-bank byte reads were most of the kernel's LDS bank conflicts; "labelled?" as compares
+  // of their own, under branches, were a third of the test pass's instructions).
   __shared__ uint32_t slab[PT_LH * PT_LW];
   __shared__ uint32_t sscan[4];
   __shared__ uint32_t sbase;
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
       if (v[e] != 127 && l[e] != AT_NO_LABEL) r[e] = label[l[e] & AT_LABEL_MASK];
 #pragma unroll
     for (int e = 0; e <= NR; e++) {
-      const uint32_t lab = (r[e] >> 31) ? ((r[e] & AT_LABEL_MASK) | (v[e] == 255u ? 0x80000000u : 0u)) : AT_NO_LABEL;
+      const uint32_t lab = (r[e] >> 31) ? ((r[e] & PT_REP_MASK) | (v[e] == 255u ? PT_WHITE : PT_BLACK)) : 0u;
       if (si[e] >= 0) slab[si[e]] = lab;
     }
   }
@@ -161,38 +166,37 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
 
   const int lx = tid & 63;
   const int gx = X0 + lx;
-  const int DX[4] = {1, 0, -1, 1}, DY[4] = {0, 1, 1, 1};
-  // pass 1: which (pixel, direction) of this thread emits -- a 16-bit mask and a count, nothing else.  The component-pair
+  // pass 1: which (pixel, direction) of this thread emits -- a 16-bit mask and a count, nothing else.  Directions 0..3 =
+  // (1,0), (0,1), (-1,1), (1,1).  The component-pair
   // table is NOT touched here: about one test in five emits, so table work inside this loop runs on a fifth of the
   // lanes and as long as the busiest lane; it is done on the compacted list instead (pass 2), where every lane has an
   // emission.
   // (History of this pass: aggregating the table inserts and counter atomics over the wave -- one leader per distinct
   // key -- was measured slower, 9.6 vs 6.1 ms: a 64-pixel row step meets too many distinct component pairs.  Taking
   // the rank from the counting atomic's return value INSIDE this sparse loop was slower too, 7.8 ms.)
-  uint32_t cnt = 0;
+  // (straight-line: every lane reads its pixel's six words and forms the four tests; validity of the source pixel is two masks)
   uint32_t emask = 0;
+  {
+    auto opposite = [](uint32_t a, uint32_t b) { return (a ^ b) > 0xBFFFFFFFu; };   // one white, one black, both counted
+    const bool gx_ok = gx >= 1 && gx <= W - 2;
+    const bool left_is_source = gx - 1 >= 1;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int ly = (tid >> 6) + 4 * k;
-    const int gy = Y0 + ly;
-    if (gx < 1 || gx > W - 2 || gy < 1 || gy > H - 2) continue;
-    const int c = ly * PT_LW + lx + 1;
-    const uint32_t s0 = slab[c];
-    if (s0 == AT_NO_LABEL) continue;
-    // upstream's connected_last: the left neighbour (a valid source itself) emitted its (1,1) point,
-    // which is this pixel's (-1,1) half-pixel location
-    const uint32_t s_l = slab[c - 1], s_d = slab[c + PT_LW];
-    const bool left_emits = gx - 1 >= 1 && s_l != AT_NO_LABEL && s_d != AT_NO_LABEL && ((s_l ^ s_d) >> 31);
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-      if (d == 2 && left_emits) continue;
-      const int n = c + DY[d] * PT_LW + DX[d];
-      const uint32_t s_n = (d == 1) ? s_d : slab[n];
-      if (s_n == AT_NO_LABEL || !((s0 ^ s_n) >> 31)) continue;
-      emask |= 1u << (k * 4 + d);
-      cnt++;
+    for (int k = 0; k < 4; k++) {
+      const int ly = (tid >> 6) + 4 * k;
+      const int gy = Y0 + ly;
+      const bool ok = gx_ok && gy >= 1 && gy <= H - 2;
+      const int c = ly * PT_LW + lx + 1;
+      const uint32_t s0 = slab[c], s_l = slab[c - 1], s_r = slab[c + 1];
+      const uint32_t s_dl = slab[c + PT_LW - 1], s_d = slab[c + PT_LW], s_dr = slab[c + PT_LW + 1];
+      // upstream's connected_last: the left neighbour (a valid source itself) emitted its (1,1) point,
+      // which is this pixel's (-1,1) half-pixel location
+      const bool left_emits = left_is_source && opposite(s_l, s_d);
+      const uint32_t e0 = (ok && opposite(s0, s_r)) ? 1u : 0u, e1 = (ok && opposite(s0, s_d)) ? 2u : 0u;
+      const uint32_t e2 = (ok && !left_emits && opposite(s0, s_dl)) ? 4u : 0u, e3 = (ok && opposite(s0, s_dr)) ? 8u : 0u;
+      emask |= (e0 | e1 | e2 | e3) << (4 * k);
     }
   }
+  const uint32_t cnt = (uint32_t)__popc(emask);
   uint32_t total;
   const uint32_t off = block_excl_scan256(cnt, sscan, &total);  // contains __syncthreads
   PT_TICK(1)
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     const int c = ly * PT_LW + plx + 1;
     const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
     const uint32_t s0 = slab[c], s1 = slab[c + ddy * PT_LW + ddx];
-    const uint32_t r0 = s0 & AT_LABEL_MASK, r1 = s1 & AT_LABEL_MASK;
+    const uint32_t r0 = s0 & PT_REP_MASK, r1 = s1 & PT_REP_MASK;
     const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
     const uint32_t slot = hash_insert(hkeys, P.hcap, P.hshift, key);
     if (slot == AT_INVALID_SLOT) atomicOr(&counters[frame].flags, 0x2u);
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     const int c = ly * PT_LW + plx + 1;
     const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
     const uint32_t s0 = slab[c];
-    const uint32_t r0 = s0 & AT_LABEL_MASK, r1 = slab[c + ddy * PT_LW + ddx] & AT_LABEL_MASK;
+    const uint32_t r0 = s0 & PT_REP_MASK, r1 = slab[c + ddy * PT_LW + ddx] & PT_REP_MASK;
     const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
     const int e = ltab_insert(tkey, key);
     uint32_t ee = 255u, rk = 0u;
