@@ -173,3 +173,22 @@ def test_staging_word_from_the_list_record():
         s0 = (neg << 31) | rng.randrange(1 << 21)
         w = e | (rk << 8) | ((rec & 0xFFF) << 19) | (s0 & 0x80000000)
         assert w == e | (rk << 8) | (pix << 19) | (d << 29) | (neg << 31)
+
+
+def test_points_class_bits_make_the_emission_test_one_xor_and_one_compare():
+    """k_points (kernels_cluster.h) keeps one word per tile pixel: representative | class bits (white 0x80000000, black
+    0x40000000; 0 = not in a counted component).  `(a ^ b) > 0xBFFFFFFF` must hold exactly for a counted white and a
+    counted black pixel, whatever their representatives (below 2^30)."""
+    rng = random.Random(15)
+    WHITE, BLACK, REP = 0x80000000, 0x40000000, 0x3FFFFFFF
+    words = []
+    for _ in range(300):
+        r = rng.randrange(1 << 30) if rng.random() < 0.8 else rng.choice([0, 1, REP])
+        words += [("w", WHITE | r), ("b", BLACK | r)]
+    words += [("n", 0)] * 20
+    for ca, a in words:
+        for cb, b in rng.sample(words, 40):
+            want = {ca, cb} == {"w", "b"}
+            assert (((a ^ b) & 0xFFFFFFFF) > 0xBFFFFFFF) == want
+            if ca != "n":
+                assert a & REP == a & ~(WHITE | BLACK) & 0xFFFFFFFF   # the representative comes back with one mask
