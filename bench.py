@@ -323,6 +323,7 @@ def main():
     # below the process group's timeout of 10 minutes (RCCL) / 30 minutes (gloo)); then the other ranks check their own
     # frames side by side, each on its share of the cores.
     gate_ok = True
+    stage_gate = None
     byframe = None
     cpu_rec = None
     gated = 0
@@ -353,6 +354,27 @@ def main():
                 a["id"] == b["id"] and np.array_equal(a["p"], b["p"]) and np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"])
                 for a, b in zip(g, odets))
         gated = len(byframe)
+        # ... and the STAGES of a sample of them: the ten tag detections of a frame say nothing about
+        # the thousands of clusters that end as rejected quads or no quad at all, so for 16 evenly spaced frames of the batch
+        # the library's threshold image, labels, cluster list and QUAD list (count and CRC of the sorted list: key, four float
+        # corners, border direction) of the timed submission shape are compared with the oracle's dump of the same frame.
+        from concurrent.futures import ThreadPoolExecutor
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import parity_util as pu
+        from oracle import pyoracle as po
+        keys = sorted(byframe)
+        sample = [keys[int(round(j))] for j in np.linspace(0, len(keys) - 1, min(16, len(keys)))]
+
+        def odigest(i):
+            fx, fy, cx, cy = intr[i]
+            K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+            return pu.stage_digest_oracle(po.detect(frames_np[i], params=pu.oracle_params(K, args.decimate, tag_size), want_dump=True)[1])
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+            odig = list(ex.map(odigest, sample))
+        stage_bad = [i for i, od in zip(sample, odig) if pu.stage_digest_gpu(det, i) != od]
+        stage_gate = {"frames": len(sample), "mismatches": len(stage_bad), "submission_path": det.last_submission_path(),
+                      "quads_per_frame_mean": round(float(np.mean([d["nquads"] for d in odig])), 1)}
+        gate_ok &= not stage_bad
     gated_all = [gated]
     if world > 1:
         gt = torch.tensor([1.0 if gate_ok else 0.0], dtype=torch.float64, device=coll_dev)
@@ -408,6 +430,8 @@ def main():
             rec["parity_gate"] = "pass" if gate_all else "FAIL"      # AND over all ranks
             rec["parity_gate_frames_rank0"] = len(byframe)
             rec["parity_gate_frames_per_rank"] = gated_all
+            # rank 0's stage-level sample (every rank runs its own; a mismatch anywhere fails parity_gate)
+            rec["parity_gate_stages"] = stage_gate
         print(json.dumps(rec))
         sys.stdout.flush()
     if world > 1:

@@ -27,6 +27,19 @@ int amdAprilTagsGetStageMs(amdAprilTagsHandle handle, float* ms);
 int amdAprilTagsThresholdOnly(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
                               amdAprilTagsStream stream);
 
+/* Which launch set a submission gets.  The library picks it from the submission's size: up to eight 1080p frames' worth of
+ * working pixels take the LATENCY set (k_cc_local<16>, every small cluster in the one-wave class of k_fit_quads, no
+ * k_fit_small, CU-wide prefilter, one select chunk, captured-graph replay, results written to the host by k_reconcile); above
+ * that the THROUGHPUT set (k_cc_local<4>, k_fit_small<2> for clusters up to 128 points, per-wave prefilter, chunked select,
+ * copy commands).  Results never depend on it.  The parity tests pin it so that BOTH sets are compared with the oracle stage
+ * by stage at any frame count (a one-frame submission on the THROUGHPUT set; a 12-frame one on the LATENCY set). */
+#define AMDAT_PATH_AUTO 0
+#define AMDAT_PATH_LATENCY 1
+#define AMDAT_PATH_THROUGHPUT 2
+int amdAprilTagsDebugSetSubmissionPath(amdAprilTagsHandle handle, int path);
+/* AMDAT_PATH_LATENCY or AMDAT_PATH_THROUGHPUT: the set the handle's last submission ran (AMDAT_PATH_AUTO before the first). */
+int amdAprilTagsDebugLastSubmissionPath(amdAprilTagsHandle handle);
+
 /* ---- stage inspection (parity tests) ------------------------------------------------------ */
 typedef enum {
   AMDAT_DBG_GRAY = 0,      /* u8  w*h working gray image */

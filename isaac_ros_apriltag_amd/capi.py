@@ -62,7 +62,8 @@ EXPORTS = ["amdAprilTagsDefaultConfig", "amdCreateAprilTagsDetector", "amdCreate
            "amdAprilTagsSetProfiling", "amdAprilTagsGetStageMs", "amdAprilTagsThresholdOnly",
            "amdAprilTagsDebugCopy", "amdAprilTagsDebugMath", "amdAprilTagsDeviceAlloc", "amdAprilTagsDeviceFree",
            "amdAprilTagsCopyToDevice", "amdAprilTagsResizeMono8", "amdAprilTagsRectifyMono8",
-           "amdAprilTagsGetDeviceBytes"]
+           "amdAprilTagsGetDeviceBytes", "amdAprilTagsDebugSetSubmissionPath", "amdAprilTagsDebugLastSubmissionPath"]
+PATH_AUTO, PATH_LATENCY, PATH_THROUGHPUT = 0, 1, 2
 
 _lib = None
 
@@ -112,6 +113,8 @@ def lib():
     L.amdAprilTagsRectifyMono8.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32,
                                            C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), H]
     L.amdAprilTagsGetDeviceBytes.argtypes = [H, C.POINTER(C.c_size_t)]
+    L.amdAprilTagsDebugSetSubmissionPath.argtypes = [H, C.c_int]
+    L.amdAprilTagsDebugLastSubmissionPath.argtypes = [H]
     L.amdAprilTagsDebugMath.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     for name in EXPORTS:
         fn = getattr(L, name)

@@ -226,6 +226,10 @@ struct amdAprilTagsDetector_st {
   uint64_t graph_clock = 0;
   uint32_t graph_misses = 0;         // consecutive captures that had to evict an entry
   hipEvent_t ev[AMDAT_NUM_STAGES + 1] = {};
+  // which launch set a submission gets: by its size (AMDAT_PATH_AUTO) or pinned by amdAprilTagsDebugSetSubmissionPath, so that
+  // the parity tests can put BOTH launch sets under the oracle at any frame count
+  int path_mode = AMDAT_PATH_AUTO;
+  int last_path = AMDAT_PATH_AUTO;   // the set the last submission ran (amdAprilTagsDebugLastSubmissionPath)
   float stage_ms[AMDAT_NUM_STAGES] = {};
   uint32_t last_n = 0;
 };
@@ -736,6 +740,20 @@ int amdAprilTagsSetProfiling(amdAprilTagsHandle handle, int enable) {
   return AMDAT_SUCCESS;
 }
 
+int amdAprilTagsDebugSetSubmissionPath(amdAprilTagsHandle handle, int path) {
+  if (!handle || path < AMDAT_PATH_AUTO || path > AMDAT_PATH_THROUGHPUT) return AMDAT_INVALID_ARGUMENT;
+  if (path == handle->path_mode) return AMDAT_SUCCESS;
+  DeviceGuard guard(handle->device);
+  if (!guard.ok) return AMDAT_HIP_ERROR;
+  for (auto& g : handle->graphs) if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }   // captured under the other path
+  handle->path_mode = path;
+  return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsDebugLastSubmissionPath(amdAprilTagsHandle handle) {
+  return handle ? handle->last_path : -1;
+}
+
 int amdAprilTagsGetStageMs(amdAprilTagsHandle handle, float* ms) {
   if (!handle || !ms) return AMDAT_INVALID_ARGUMENT;
   memcpy(ms, handle->stage_ms, sizeof(handle->stage_ms));
@@ -800,13 +818,23 @@ __global__ __launch_bounds__(64) void k_prologue(const uint32_t* __restrict__ ho
 
 // Small submissions let k_reconcile write results and counters into the pinned host buffers itself (see there); large
 // ones keep the two copy commands (megabytes over PCIe are the copy engines' job).
-static inline bool direct_results(uint32_t n) { return n <= 8; }
+static inline bool direct_results(const amdAprilTagsDetector_st* D, uint32_t n) { return n <= 8 && D->path_mode != AMDAT_PATH_THROUGHPUT; }
 
 // A small submission (the node's one-frame calls, up to eight 1080p frames) is about latency, not throughput: every cluster
 // is a workgroup's only one, the stage ends with its longest chain, and a launch more costs more than k_fit_small's shorter
 // chain per small cluster saves (measured: 0.54 against 0.47 ms per one-frame call).  Such a submission buckets all clusters
 // up to the one-wave class's bound into that class (work_layout_small) and launches no k_fit_small.
-static inline bool small_submission(const DetParams& P, uint32_t n) { return (uint64_t)n * (uint64_t)P.W * (uint64_t)P.H < (16ull << 20); }
+static inline bool small_submission(const amdAprilTagsDetector_st* D, const DetParams& P, uint32_t n) {
+  if (D->path_mode != AMDAT_PATH_AUTO) return D->path_mode == AMDAT_PATH_LATENCY;
+  return (uint64_t)n * (uint64_t)P.W * (uint64_t)P.H < (16ull << 20);
+}
+// the frame count the launch heuristics see (chunks of k_cluster_select, clusters per pop): a pinned path takes the values of
+// the submissions that path is for, whatever the real count
+static inline uint32_t heuristic_frames(const amdAprilTagsDetector_st* D, uint32_t n) {
+  if (D->path_mode == AMDAT_PATH_THROUGHPUT) return n < 64u ? 64u : n;
+  if (D->path_mode == AMDAT_PATH_LATENCY) return n > 8u ? 8u : n;
+  return n;
+}
 
 static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s, const std::function<void()>& mark) {
   DetParams P = D->P;
@@ -816,7 +844,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
 #ifndef AMDAT_CC_WIDE
 #define AMDAT_CC_WIDE 1
 #endif
-  if (AMDAT_CC_WIDE && small_submission(P, n))   // sixteen waves per tile: a quarter of the rows per lane (latency, not throughput)
+  if (AMDAT_CC_WIDE && small_submission(D, P, n))   // sixteen waves per tile: a quarter of the rows per lane (latency, not throughput)
     hipLaunchKernelGGL((k_cc_local<16>), dim3((P.W + CC_T - 1) / CC_T, (P.H + CC_T - 1) / CC_T, n), dim3(1024), 0, s, D->d_thr,
                      D->d_label, D->d_csize, D->d_roots, D->d_counters, P);
   else
@@ -846,10 +874,10 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
   }
   mark();
   {
-    const int nchunks = n >= 16 ? SEL_CHUNKS : 1;   // (see the kernel)
+    const int nchunks = heuristic_frames(D, n) >= 16 ? SEL_CHUNKS : 1;   // (see the kernel)
     hipLaunchKernelGGL(k_cluster_select, dim3((P.hcap + 1024 * nchunks - 1) / (1024 * nchunks), 1, n), dim3(256), 0, s, D->d_hkeys,
                        D->d_hcnt, D->d_hoff, D->d_clusters, D->d_counters, D->d_work, D->d_workctl,
-                       small_submission(P, n) ? D->work_layout_small : D->work_layout, nchunks, P);
+                       small_submission(D, P, n) ? D->work_layout_small : D->work_layout, nchunks, P);
   }
   mark();
   {
@@ -879,7 +907,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
     // A small submission (the node's one-frame calls) is over when its slowest chain is: there the 256-thread class starts
     // at once beside the small classes (its in-kernel test after the first walk still drops most of its clusters) and
     // only the two largest classes wait for the prefilter -- prefilter, then the survivors' sort, was the longest chain.
-    const bool small = small_submission(P, n);
+    const bool small = small_submission(D, P, n);
     const int pf_first = small ? D->prefilter_class + 1 : D->prefilter_class;
     auto launch_prefilter = [&](hipStream_t sp) {
       if (!prefilter) return;
@@ -908,7 +936,8 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
       const size_t lds = lds_bytes(cl);
       const bool big = c == FQ_NCLS - 1;
       // a small submission spreads its clusters over the workgroups one by one (latency); large ones pop in chunks
-      const int pop = cl.pop < (int)(n / 16u) ? cl.pop : ((int)(n / 16u) < 1 ? 1 : (int)(n / 16u));
+      const int nh16 = (int)(heuristic_frames(D, n) / 16u);
+      const int pop = cl.pop < nh16 ? cl.pop : (nh16 < 1 ? 1 : nh16);
       const bool filtered = prefilter && c >= pf_first;
       if (cl.small_k) {
 #define FS_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work + D->work_layout.off[c], D->d_workctl + c,               \
@@ -997,7 +1026,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
   }
   mark();
   {
-    const bool direct = direct_results(n);
+    const bool direct = direct_results(D, n);
     hipLaunchKernelGGL(k_reconcile, dim3(n), dim3(64), 0, s, D->d_frames, D->d_dets, D->d_out, D->d_counters, D->d_order,
                        direct ? D->h_out : nullptr, ostride, D->h_counters, P);
   }
@@ -1022,7 +1051,7 @@ static int enqueue_submission(amdAprilTagsDetector_st* D, uint32_t n, uint32_t o
     const int rc = issue_pipeline(D, n, ostride, s, mark);
     if (rc) return rc;
   }
-  if (!direct_results(n)) {
+  if (!direct_results(D, n)) {
     HIP_TRY(hipMemcpyAsync(D->h_counters, D->d_counters, n * sizeof(FrameCounters), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpy2DAsync(D->h_out, (size_t)ostride * sizeof(DetRec), D->d_out, (size_t)P.dcap * sizeof(DetRec),
                              (size_t)ostride * sizeof(DetRec), n, hipMemcpyDeviceToHost, s));
@@ -1053,7 +1082,7 @@ static int run_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hi
   // handful of instantiated graphs is kept (a host that alternates batch sizes or streams would otherwise re-capture on
   // every call, far slower than the plain enqueues the graph replaces); after a few consecutive misses with the cache
   // full, or one failed capture, the handle falls back to plain enqueues for good.
-  if (D->graph_max_frames && n <= D->graph_max_frames && !prof) {
+  if (D->graph_max_frames && n <= D->graph_max_frames && !prof && D->path_mode != AMDAT_PATH_THROUGHPUT) {
     amdAprilTagsDetector_st::GraphEntry* hit = nullptr;
     for (auto& g : D->graphs)
       if (g.exec && g.n == n && g.ostride == ostride && g.stream == s) hit = &g;
@@ -1120,6 +1149,7 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
   if (D->unusable) return AMDAT_OUT_OF_MEMORY;   // (never launch on the half-allocated buffers of a failed regrowth)
   fill_frames(D, n, images, intr);   // image pointers, pitches and intrinsics travel through the pinned descriptor block
   D->last_n = n;
+  D->last_path = small_submission(D, D->P, n) ? AMDAT_PATH_LATENCY : AMDAT_PATH_THROUGHPUT;
   if (ostride > D->P.dcap) ostride = D->P.dcap;
   if (D->pending_hash_grow) {   // the pair table of the previous submission was crowded: grow it now (its buffers are dead)
     D->pending_hash_grow = false;

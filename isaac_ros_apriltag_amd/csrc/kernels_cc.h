@@ -306,7 +306,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CC_LOCA
       atomicAdd(lds_at(sl, root[k]), len);
       // a component can only ever merge with another tile's through a pixel on the tile's perimeter: flag it (bit 31).
       // (first or last row of the tile, a run from column 0 -- its length is then the lane + 1 -- or one up to column 63)
-      const bool edge_row = (k == 0 && wv == 0) || (k == ROWS - 1 && wv == NW - 1);
+      const bool edge_row = (k == 0 && wv == 0) || (k == ROWS - CC_LAST_ROW_OFFSET(NW) && wv == NW - 1);   // (tools_hooks.h: 1)
       if (edge_row || len == (uint32_t)(lane + 1) || lane == 63) atomicOr(lds_at(sl, root[k]), 0x80000000u);
     }
   }

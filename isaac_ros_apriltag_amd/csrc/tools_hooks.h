@@ -8,6 +8,9 @@
 //   -DAMDAT_CC_STOP=n       k_cc_local returns after phase n
 //   -DAMDAT_FQ_SKIP=mask    the launch sequence leaves out k_fit_quads classes (bits 0..4) or the prefilter (bit 5)
 //   -DAMDAT_FQ_NO_*         one of the quad fit's sound early exits compiled out (see below)
+//   -DAMDAT_MUTATE=n        a deliberately WRONG build for tools/mutation_check.sh, which shows that the GPU suite fails on it:
+//                           1 = the launch sequence leaves out k_fit_small (the throughput set's small-cluster fit);
+//                           2 = k_cc_local<4> flags the perimeter on the wrong last row (one row constant off in the 4-wave instance only)
 // The stop builds key on P.max_nmaxima == 10 (always true) so that the compiler cannot fold the early exit at compile time
 // into dead-code elimination of the phases before it.
 #pragma once
@@ -24,6 +27,12 @@
 #define CC_STOP_AT(n) if (AMDAT_CC_STOP == (n) && P.max_nmaxima == 10) return;
 #else
 #define CC_STOP_AT(n)
+#endif
+
+#if defined(AMDAT_MUTATE) && AMDAT_MUTATE == 2
+#define CC_LAST_ROW_OFFSET(NW) ((NW) == 4 ? 2 : 1)
+#else
+#define CC_LAST_ROW_OFFSET(NW) 1
 #endif
 
 // ---- k_points -----------------------------------------------------------------------------------------------------------
@@ -122,7 +131,10 @@
 #endif
 
 // ---- launch sequence (detector.hip) ---------------------------------------------------------------------------------------
-#ifdef AMDAT_FQ_SKIP
+#if defined(AMDAT_MUTATE) && AMDAT_MUTATE == 1
+#define FQ_SKIP_PREFILTER() 0
+#define FQ_SKIP_CLASS(c) ((c) < FQ_C0)
+#elif defined(AMDAT_FQ_SKIP)
 #define FQ_SKIP_PREFILTER() (((AMDAT_FQ_SKIP) >> 5) & 1)
 #define FQ_SKIP_CLASS(c) ((c) >= FQ_C0 && (((AMDAT_FQ_SKIP) >> ((c) - FQ_C0)) & 1))
 #else

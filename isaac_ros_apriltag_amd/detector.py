@@ -154,6 +154,15 @@ class AprilTagDetector:
         """True/1: HIP events per stage; 2: plus cycle counters inside the quad-fit kernel."""
         capi._check("amdAprilTagsSetProfiling", self._L.amdAprilTagsSetProfiling(self._h, int(enable)))
 
+    def set_submission_path(self, path):
+        """'auto' (by submission size), 'latency' or 'throughput': pins the launch set (parity tests; results never depend on it)."""
+        code = {"auto": capi.PATH_AUTO, "latency": capi.PATH_LATENCY, "throughput": capi.PATH_THROUGHPUT}[path] if isinstance(path, str) else int(path)
+        capi._check("amdAprilTagsDebugSetSubmissionPath", self._L.amdAprilTagsDebugSetSubmissionPath(self._h, code))
+
+    def last_submission_path(self):
+        return {capi.PATH_AUTO: "none", capi.PATH_LATENCY: "latency", capi.PATH_THROUGHPUT: "throughput"}[
+            self._L.amdAprilTagsDebugLastSubmissionPath(self._h)]
+
     def stage_ms(self):
         ms = (C.c_float * capi.NUM_STAGES)()
         capi._check("amdAprilTagsGetStageMs", self._L.amdAprilTagsGetStageMs(self._h, ms))

@@ -8,6 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# tools/mutation_check.sh runs parts of the GPU suite against deliberately wrong builds (libapriltag_amd_<tag>.so) to show that the
+# suite fails on them; nothing else sets this variable
+if os.environ.get("AMDAT_LIB"):
+    from isaac_ros_apriltag_amd import capi as _capi
+    _capi.LIB_PATH = os.path.join(ROOT, "isaac_ros_apriltag_amd", "libapriltag_amd_%s.so" % os.environ["AMDAT_LIB"])
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

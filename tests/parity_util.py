@@ -80,3 +80,37 @@ def compare_detections(gdets, odets, exact=True):
             elif not np.allclose(g[k], o[k], rtol=0, atol=1e-9):
                 errs.append("det id %d field %s differs by %.3e" % (o["id"], k, np.abs(g[k] - o[k]).max()))
     return errs
+
+
+def _quad_crc(keys, ps, rbs):
+    import zlib
+    order = np.argsort(np.asarray(keys, dtype=np.uint64), kind="stable")
+    crc = 0
+    for i in order:
+        crc = zlib.crc32(np.uint64(keys[i]).tobytes() + np.asarray(ps[i], dtype="<f4").tobytes() + np.int32(rbs[i]).tobytes(), crc)
+    return crc
+
+
+def stage_digest_oracle(dump):
+    """Per-stage digest of an oracle dump: threshold / label CRCs, cluster and point counts, CRC of the sorted cluster list,
+    number of quads and CRC of the sorted quad list (key, four float corners, border direction)."""
+    import zlib
+    cl = dump["clusters"]
+    ck = np.array([c[0] for c in cl], dtype=np.uint64)
+    cc = np.array([c[2] for c in cl], dtype=np.uint32)
+    q = dump["quads"]
+    return {"thr": zlib.crc32(dump["thr"].tobytes()), "label": zlib.crc32(dump["label"].tobytes()), "nclusters": len(cl),
+            "npoints": int(cc.sum()), "clusters": zlib.crc32(ck.tobytes() + cc.tobytes()), "nquads": len(q),
+            "quads": _quad_crc([o["key"] for o in q], [o["p"] for o in q], [o["reversed_border"] for o in q])}
+
+
+def stage_digest_gpu(det, frame_idx):
+    """The same digest from the library's stage buffers of frame `frame_idx` of the last submission."""
+    import zlib
+    cl = det.debug(frame_idx, capi.DBG_CLUSTERS)
+    order = np.argsort(cl["key"], kind="stable")
+    q = det.debug(frame_idx, capi.DBG_QUADS)
+    return {"thr": zlib.crc32(det.debug(frame_idx, capi.DBG_THRESH).tobytes()),
+            "label": zlib.crc32(det.debug(frame_idx, capi.DBG_LABEL).tobytes()), "nclusters": len(cl),
+            "npoints": int(cl["count"].sum()), "clusters": zlib.crc32(cl["key"][order].tobytes() + cl["count"][order].tobytes()),
+            "nquads": len(q), "quads": _quad_crc(q["key"], q["p"], q["reversed_border"])}

@@ -25,13 +25,29 @@ from isaac_ros_apriltag_amd import capi as capi_mod  # noqa: E402
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.json")))
 
 
+@pytest.fixture(autouse=True)
+def _registry_left_clean():
+    """The family registry is process-wide: whatever a test registers (slots 3..8) is gone when the next one starts."""
+    yield
+    for slot in range(capi.SLOT_TAG36H10, 9):
+        capi.unregister_family(slot)
+
+
 def _k4(K):
     return (K[0, 0], K[1, 1], K[0, 2], K[1, 2])
 
 
-def _run(img, K, families=("tag36h11",), decimate=1, **kw):
+# The library has two launch sets (include/apriltag_amd_debug.h): submissions of up to eight 1080p frames' worth of pixels
+# take the LATENCY set, larger ones the THROUGHPUT set (k_cc_local<4>, k_fit_small<2>, the per-wave prefilter, chunked select).
+# The stage-level tests below pin each set in turn, so that both meet the oracle on every case whatever its size.
+PATHS = ("latency", "throughput")
+
+
+def _run(img, K, families=("tag36h11",), decimate=1, path=None, **kw):
     h, w = img.shape
     det = AprilTagDetector(w, h, families=families, decimate=decimate, intrinsics=_k4(K), max_batch=1, **kw)
+    if path is not None:
+        det.set_submission_path(path)
     g = det.detect_batch_ex(torch.from_numpy(np.ascontiguousarray(img)).cuda(), max_dets=256)[0]
     return det, g
 
@@ -70,15 +86,87 @@ def test_device_arithmetic_is_ieee(built):
     ("c2_dec2", lambda: synth.scene_c2(seed=1301), ("tag36h11",), 2),
     ("c5", lambda: synth.scene_c5(), ("tag36h11", "tag25h9"), 1),
 ])
-def test_stage_and_detection_parity(built, name, scene, families, decimate):
+@pytest.mark.parametrize("path", PATHS)
+def test_stage_and_detection_parity(built, name, scene, families, decimate, path):
     r = scene()
     img, K = r[0], r[1]
-    det, g = _run(img, K, families, decimate)
+    det, g = _run(img, K, families, decimate, path=path)
+    assert det.last_submission_path() == path
     errs, odets = pu.compare_stages(det, 0, img, families, K, decimate)
     errs += pu.compare_detections(g, odets, exact=True)
     det.close()
     assert not errs, errs[:5]
     assert len(g) == len(odets)
+
+
+def _content_frames(w=1920, h=1080):
+    """Non-tag content at full size: uniform noise, two-level noise, stripes, a flat frame, an 11-px checkerboard (8 500 clusters of
+    about 90 points -- every one a quad, all of them through the small-cluster fit of the throughput set), a big noisy-edged
+    rectangle (clusters of thousands of points: the large size classes and their prefilter) and rings."""
+    rng = np.random.default_rng(77)
+    yy, xx = np.mgrid[0:h, 0:w]
+    out = [rng.integers(0, 256, size=(h, w), dtype=np.uint8),
+           ((rng.random((h, w)) < 0.45) * 255).astype(np.uint8),
+           (((xx + 3) % 7 < 3) * 220 + 10).astype(np.uint8),
+           np.full((h, w), 99, dtype=np.uint8),
+           ((((yy // 11) + (xx // 11)) & 1) * 200 + 20).astype(np.uint8)]
+    rect = np.full((h, w), 40.0)
+    rect[h // 6: 5 * h // 6, w // 6: 5 * w // 6] = 220
+    out.append(np.clip(np.rint(rect + rng.normal(0, 18.0, (h, w))), 0, 255).astype(np.uint8))
+    r = np.sqrt((xx - w / 2.0) ** 2 + (yy - h / 2.0) ** 2)
+    out.append((((r / 9.0).astype(np.int64) & 1) * 240 + 8).astype(np.uint8))
+    return out
+
+
+def _check_every_frame(det, res, frames, families, K, decimate=1):
+    for i, img in enumerate(frames):
+        errs, odets = pu.compare_stages(det, i, img, families, K, decimate)
+        errs += pu.compare_detections(res[i], odets)
+        assert not errs, (i, errs[:4])
+
+
+def test_throughput_set_every_stage_of_every_frame(built):
+    """FOURTEEN distinct 1080p frames in ONE call -- 14 x 2.07 Mpx is beyond the sixteen Mi pixels up
+    to which a submission takes the latency set, so the library itself (path AUTO) picks what the bench runs: k_cc_local<4>,
+    the normal work-list bucketing, k_fit_small<2> for clusters up to 128 points, k_fit_prefilter<64>, chunked select, copy
+    commands.  Labels, component sizes, clusters, points, quads and detections of EVERY frame equal the oracle's."""
+    frames = [synth.scene_c2(seed=1234 + 7 * i)[0] for i in range(6)] + [synth.scene_c2(seed=1300, sigma=0.0)[0]] + _content_frames()
+    assert len(frames) == 14
+    K = synth.default_K(1920, 1080)
+    det = AprilTagDetector(1920, 1080, intrinsics=_k4(K), max_batch=len(frames))
+    res = det.detect_batch_ex(torch.from_numpy(np.stack(frames)).cuda(), max_dets=64)
+    assert det.last_submission_path() == "throughput"
+    assert det.frame_flags(len(frames)) == [0] * len(frames)
+    _check_every_frame(det, res, frames, ("tag36h11",), K)
+    # the checkerboard's quads all come from clusters of at most 128 points: k_fit_small's output is under the comparison
+    cl = det.debug(11, capi.DBG_CLUSTERS)
+    nq = len(det.debug(11, capi.DBG_QUADS))
+    assert nq > 8000 and np.percentile(cl["count"], 90) <= 128
+    # ... and the same frames through the latency set give the same bytes (both equal the oracle's)
+    det.set_submission_path("latency")
+    res2 = det.detect_batch_ex(torch.from_numpy(np.stack(frames)).cuda(), max_dets=64)
+    assert det.last_submission_path() == "latency"
+    _check_every_frame(det, res2, frames, ("tag36h11",), K)
+    det.close()
+
+
+@pytest.mark.parametrize("families,decimate,scene", [
+    (("tag36h11",), 2, lambda i: synth.scene_c2(seed=1301 + 5 * i)[0]),
+    (("tag36h11", "tag25h9"), 1, lambda i: synth.scene_c5(seed=4321 + 3 * i)[0]),
+])
+def test_throughput_set_decimate2_and_two_families(built, families, decimate, scene):
+    """The same for twelve frames at decimate 2 (pinned: twelve half-resolution working images are a small submission by size)
+    and for config 5's two families at decimate 1 (picked by size)."""
+    frames = [scene(i) for i in range(10)] + _content_frames()[:2]
+    K = synth.default_K(1920, 1080)
+    det = AprilTagDetector(1920, 1080, families=families, decimate=decimate, intrinsics=_k4(K), max_batch=len(frames))
+    if decimate > 1:
+        det.set_submission_path("throughput")
+    res = det.detect_batch_ex(torch.from_numpy(np.stack(frames)).cuda(), max_dets=64)
+    assert det.last_submission_path() == "throughput"
+    _check_every_frame(det, res, frames, families, K, decimate)
+    assert sum(len(r) for r in res[:10]) >= 90   # (ten tags per scene; a steeply tilted one may be missed by oracle and library alike)
+    det.close()
 
 
 def test_c3_4k_board_decimate2(built):
@@ -94,7 +182,8 @@ def test_c3_4k_board_decimate2(built):
 
 
 @pytest.mark.parametrize("shape,pitch", [((480, 644), 644), ((477, 635), 640), ((203, 301), 301), ((64, 64), 64), ((33, 70), 83)])
-def test_integer_stages_on_noise_ragged_sizes(built, shape, pitch):
+@pytest.mark.parametrize("path", PATHS)
+def test_integer_stages_on_noise_ragged_sizes(built, shape, pitch, path):
     """Uniform random bytes (every tile high-contrast, salt-and-pepper components), odd sizes, odd pitch
     (exercises the unaligned loader and the leftover strips)."""
     rng = np.random.default_rng(shape[0] * 1000 + shape[1])
@@ -102,6 +191,7 @@ def test_integer_stages_on_noise_ragged_sizes(built, shape, pitch):
     img = buf[:, :shape[1]]
     K = synth.default_K(shape[1], shape[0])
     det = AprilTagDetector(shape[1], shape[0], intrinsics=_k4(K), max_batch=1)
+    det.set_submission_path(path)
     t = torch.from_numpy(buf).cuda()
     g = det.detect_batch_ex([(t.data_ptr(), pitch)], max_dets=64)[0]
     errs, odets = pu.compare_stages(det, 0, np.ascontiguousarray(img), ("tag36h11",), K, 1)
@@ -123,12 +213,13 @@ def test_three_valued_blocks_cc(built):
 
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-5] for p in GOLD])
-def test_against_committed_golden_vectors(built, path):
+@pytest.mark.parametrize("subpath", PATHS)
+def test_against_committed_golden_vectors(built, path, subpath):
     rec = json.load(open(path))
     r = getattr(synth, rec["scene"])(**rec["kwargs"])
     img, K = r[0], r[1]
     assert zlib.crc32(img.tobytes()) == rec["image_crc32"]
-    det, g = _run(img, K, tuple(rec["families"]), rec["decimate"])
+    det, g = _run(img, K, tuple(rec["families"]), rec["decimate"], path=subpath)
     h, w = (1 + (img.shape[0] - 1) // rec["decimate"]), (1 + (img.shape[1] - 1) // rec["decimate"])
     assert zlib.crc32(det.debug(0, capi.DBG_THRESH).tobytes()) == rec["thr_crc32"]
     assert zlib.crc32(det.debug(0, capi.DBG_LABEL).tobytes()) == rec["label_crc32"]
@@ -544,7 +635,8 @@ def test_random_scene_sweep(built):
     assert total >= 30   # the sweep does exercise real detections
 
 
-def test_adversarial_content_fuzz(built):
+@pytest.mark.parametrize("path", PATHS)
+def test_adversarial_content_fuzz(built, path):
     """300 seeded cases from tools/fuzz_gpu.py: checkerboards, stripes, gradients, rings, impulses, two-level
     noise, rectangles and tag scenes at ragged sizes (4..300 px), odd pitches, decimate 1-4, one to three
     families: every stage and every detection bit-identical to the oracle."""
@@ -553,7 +645,7 @@ def test_adversarial_content_fuzz(built):
         "fuzz_gpu", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_gpu.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
-    done, fails = fz.run_cases(300, seed=20260928, maxdim=300, out=lambda m: None)
+    done, fails = fz.run_cases(300, seed=20260928, maxdim=300, out=lambda m: None, path=path)
     assert done == 300 and not fails, fails[:3]
 
 
@@ -643,8 +735,38 @@ def test_bench_two_ranks_on_one_gpu(built):
     assert cfg["frames_per_step_per_gpu"] == 32
     assert rec["parity_gate"] == "pass"
     assert rec["parity_gate_frames_per_rank"] == [32, 32]        # every rank gated on every frame of its batch
+    assert rec["parity_gate_stages"]["frames"] == 16 and rec["parity_gate_stages"]["mismatches"] == 0
+    assert rec["parity_gate_stages"]["submission_path"] == "throughput"
     assert len(cfg["per_rank_fps"]["ranks"]) == 2 and cfg["per_rank_fps"]["min"] > 0
     assert rec["value"] > 0 and abs(rec["value"] - 2 * 32 / (rec["ms_per_step"] * 1e-3)) < 0.01 * rec["value"]
+
+
+def test_bench_eight_ranks_on_one_gpu(built):
+    """BASELINE config 4 AS SPECIFIED -- eight streams, ONE per rank -- on the one GPU this box has:
+    bench.py --gpus 8 starts eight ranks, gloo carries the broadcast, all share cuda:0.  This is the layout the driver's 8-GPU
+    run uses (streams_per_gpu == 1, per-stream batch = the whole batch, the gate's thread share cpu_count // 7): sixteen frames
+    per rank, so that every rank's submission takes the throughput launch set, every rank gates on all of its frames, and the
+    stage-level sample of rank 0 reports the set it ran."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--shared-gpu", "--steps", "2",
+           "--warmup", "1", "--batch", "16", "--distinct", "16", "--no-extra", "--no-roofline"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=root, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "weak"
+    cfg = rec["config"]
+    assert cfg["world_size_seen_by_gloo"] == 8 and cfg["streams"] == 8 and cfg["streams_per_gpu"] == 1
+    assert cfg["frames_per_step_per_gpu"] == 16
+    assert rec["parity_gate"] == "pass"
+    assert rec["parity_gate_frames_per_rank"] == [16] * 8
+    assert rec["parity_gate_stages"]["mismatches"] == 0 and rec["parity_gate_stages"]["submission_path"] == "throughput"
+    assert len(cfg["per_rank_fps"]["ranks"]) == 8 and cfg["per_rank_fps"]["min"] > 0
+    assert rec["value"] > 0 and abs(rec["value"] - 8 * 16 / (rec["ms_per_step"] * 1e-3)) < 0.01 * rec["value"]
 
 
 def test_c99_example_runs(built, tmp_path):
@@ -678,18 +800,21 @@ def test_tag36h11_registered_in_apriltag3_encoding(built):
     at3 = [fl.reencode(c, 6, bx, by) for c in codes]
     assert at3[:len(fl.AT3_TAG36H11_HEAD)] == fl.AT3_TAG36H11_HEAD
     capi.register_family_ex(6, "tag36h11_at3", bx, by, 8, 10, False, at3)
-    ofam = po.custom_family("tag36h11_at3", bx, by, 8, 10, False, at3)
-    img, K = synth.scene_c2_ids(ids=[0, 7, 100, 137, 298, 333, 402, 511, 560, 586], seed=1302, sigma=2.0)[:2]
-    t = torch.from_numpy(img).cuda()
-    res = {}
-    for name, ofm in (("tag36h11", "tag36h11"), ("tag36h11_at3", ofam)):
-        det = AprilTagDetector(1920, 1080, families=(name,), intrinsics=_k4(K), max_batch=1)
-        g = det.detect_batch_ex(t, max_dets=64)[0]
-        errs, odets = pu.compare_stages(det, 0, img, (ofm,), K, 1)
-        errs += pu.compare_detections(g, odets)
-        assert not errs, (name, errs[:4])
-        det.close()
-        res[name] = g
+    try:
+        ofam = po.custom_family("tag36h11_at3", bx, by, 8, 10, False, at3)
+        img, K = synth.scene_c2_ids(ids=[0, 7, 100, 137, 298, 333, 402, 511, 560, 586], seed=1302, sigma=2.0)[:2]
+        t = torch.from_numpy(img).cuda()
+        res = {}
+        for name, ofm in (("tag36h11", "tag36h11"), ("tag36h11_at3", ofam)):
+            det = AprilTagDetector(1920, 1080, families=(name,), intrinsics=_k4(K), max_batch=1)
+            g = det.detect_batch_ex(t, max_dets=64)[0]
+            errs, odets = pu.compare_stages(det, 0, img, (ofm,), K, 1)
+            errs += pu.compare_detections(g, odets)
+            assert not errs, (name, errs[:4])
+            det.close()
+            res[name] = g
+    finally:
+        capi.unregister_family(6)   # the registry is process-wide: leave the slot as the other tests expect it
     a, b = res["tag36h11"], res["tag36h11_at3"]
     assert sorted(d["id"] for d in a) == [0, 7, 100, 137, 298, 333, 402, 511, 560, 586]
     assert len(a) == len(b)

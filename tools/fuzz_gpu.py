@@ -88,8 +88,9 @@ def tag_scene(rng, h, w, fams):
     return img
 
 
-def run_cases(cases, seed, maxdim=420, budget=1e9, out=print):
-    """Returns (cases run, list of failure strings)."""
+def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None):
+    """Returns (cases run, list of failure strings).  path: None (the library picks the launch set by size: the latency set at these
+    sizes), "latency", "throughput", or "alternate" (even cases latency, odd cases throughput)."""
     rng = np.random.default_rng(seed)
     t0 = time.time()
     fails = []
@@ -124,6 +125,8 @@ def run_cases(cases, seed, maxdim=420, budget=1e9, out=print):
             fails.append("case %d: create failed for %dx%d dec %d: %s" % (case, w, h, dec, e))
             out(fails[-1])
             continue
+        if path is not None:
+            det.set_submission_path(("latency", "throughput")[case & 1] if path == "alternate" else path)
         t = torch.from_numpy(buf).cuda()
         g = det.detect_batch_ex([(t.data_ptr(), pitch)], max_dets=256)[0]
         errs, odets = pu.compare_stages(det, 0, np.ascontiguousarray(img), fams, K, dec)
@@ -143,9 +146,10 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--maxdim", type=int, default=420)
     ap.add_argument("--budget", type=float, default=1e9, help="seconds")
+    ap.add_argument("--path", default="alternate", help="launch set: latency | throughput | alternate | auto")
     a = ap.parse_args()
     t0 = time.time()
-    done, fails = run_cases(a.cases, a.seed, a.maxdim, a.budget, out=lambda m: print(m, flush=True))
+    done, fails = run_cases(a.cases, a.seed, a.maxdim, a.budget, out=lambda m: print(m, flush=True), path=None if a.path == "auto" else a.path)
     print("fuzz: %d cases, %d failed, %.1f s" % (done, len(fails), time.time() - t0))
     sys.exit(1 if fails else 0)
 

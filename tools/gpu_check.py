@@ -42,6 +42,12 @@ def run_scene(name, img, K, families=("tag36h11",), decimate=1):
     dt = time.time() - t0
     errs, odets = pu.compare_stages(det, 0, img, families, K, decimate, verbose=True)
     errs += pu.compare_detections(g, odets)
+    # the same frame through the throughput launch set (k_cc_local<4>, k_fit_small, per-wave prefilter, chunked select)
+    det.set_submission_path("throughput")
+    g2 = det.detect_batch_ex(t, max_dets=256)[0]
+    e2, _ = pu.compare_stages(det, 0, img, families, K, decimate)
+    errs += ["throughput set: " + e for e in e2 + pu.compare_detections(g2, odets)]
+    det.set_submission_path("auto")
     print("%-28s dec %d: gpu dets %d, first-call %.1f ms, %s" % (name, decimate, len(g), dt * 1e3, "PARITY OK" if not errs else "MISMATCH"))
     for e in errs[:8]:
         print("      ", e)
