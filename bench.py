@@ -480,9 +480,10 @@ def extra_measurements(det, batch, frames_np, intr, args, torch, dev, tag_size, 
     nsteps = 6
     t = time.perf_counter()
     for k in range(nsteps):
+        det.submit_prepared(preps[k & 1])                         # amdAprilTagsSubmitBatch: this step's frames, returns at once
         with torch.cuda.stream(side):
-            bufs[(k + 1) & 1].copy_(host, non_blocking=True)     # next step's frames
-        det.run_prepared(preps[k & 1])                            # blocking call on this step's frames
+            bufs[(k + 1) & 1].copy_(host, non_blocking=True)     # next step's frames over PCIe meanwhile
+        det.wait_prepared(preps[k & 1])                           # amdAprilTagsWaitBatchEx
         side.synchronize()
     ex["fps_h2d_included_double_buffered"] = round(nsteps * B / (time.perf_counter() - t), 1)
     t = time.perf_counter()

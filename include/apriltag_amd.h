@@ -118,8 +118,13 @@ typedef struct {
 } amdAprilTagsDetectionEx_t;
 
 typedef struct {
+  uint32_t struct_size;        /* sizeof(amdAprilTagsConfig_t) of the header the caller was built against: set by
+                                * amdAprilTagsDefaultConfig -- every configuration must start from that call.  The struct only ever
+                                * grows at its end: a caller built against an older, shorter header passes its smaller size and
+                                * the fields it does not know keep their defaults; 0, or a size beyond the library's own, is
+                                * AMDAT_INVALID_ARGUMENT (a struct that did not come from amdAprilTagsDefaultConfig). */
   uint32_t width, height;      /* input image size (fixed for the handle, as in the reference) */
-  uint32_t tile_size;          /* 4 (src/apriltag_node.cpp:566); other values: AMDAT_UNSUPPORTED */
+  uint32_t tile_size;          /* 4 (src/apriltag_node.cpp:566) or 8; other values: AMDAT_UNSUPPORTED */
   uint32_t decimate;           /* quad_decimate, integer >= 1 (1 = cuAprilTags behaviour) */
   uint32_t num_families;       /* 1..4 */
   amdAprilTagsFamily families[4];
@@ -173,6 +178,24 @@ int amdAprilTagsDetectBatchEx(amdAprilTagsHandle handle, uint32_t n, const amdAp
                               const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics,
                               amdAprilTagsDetectionEx_t* dets_out, uint32_t* num_dets, uint32_t max_dets,
                               amdAprilTagsStream stream);
+
+/* The batched call in two halves, for hosts that overlap the NEXT batch's host-to-device copy (on a stream of their own) with
+ * this batch's detection: amdAprilTagsSubmitBatch enqueues the submission and returns; amdAprilTagsWaitBatch[Ex] blocks until
+ * it is done and hands out the records (layout as amdAprilTagsDetectBatch[Ex] with the max_tags given at submit).  One
+ * submission per handle at a time: a second Submit, or any other call that runs or inspects a submission, returns
+ * AMDAT_INVALID_ARGUMENT until the wait has returned, and so does a wait with nothing in flight.  Images and their device
+ * buffers must stay valid until the wait returns.  The blocking calls are exactly Submit followed by Wait. */
+int amdAprilTagsSubmitBatch(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
+                            const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics, uint32_t max_tags,
+                            amdAprilTagsStream stream);
+int amdAprilTagsWaitBatch(amdAprilTagsHandle handle, amdAprilTagsID_t* tags_out, uint32_t* num_tags);
+int amdAprilTagsWaitBatchEx(amdAprilTagsHandle handle, amdAprilTagsDetectionEx_t* dets_out, uint32_t* num_dets);
+
+/* Per-frame skew K[0][1] for the batch slots 0 .. n-1 of the submissions that follow (frames beyond n, and every frame after
+ * n = 0, take the handle's amdAprilTagsConfig_t.skew).  The VPI path of the reference passes every camera's own skew with its
+ * 2x3 intrinsics (src/apriltag_node.cpp:215-225); a batching front end that serves several cameras with one handle sets them
+ * here next to the per-frame fx, fy, cx, cy of amdAprilTagsDetectBatch.  Only the pose depends on it. */
+int amdAprilTagsSetFrameSkews(amdAprilTagsHandle handle, uint32_t n, const float* skews);
 
 /* Device memory the handle owns, in bytes. */
 int amdAprilTagsGetDeviceBytes(amdAprilTagsHandle handle, size_t* bytes);

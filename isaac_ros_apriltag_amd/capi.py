@@ -45,7 +45,7 @@ class DetectionEx(C.Structure):
 
 
 class Config(C.Structure):
-    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("tile_size", C.c_uint32), ("decimate", C.c_uint32),
+    _fields_ = [("struct_size", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("tile_size", C.c_uint32), ("decimate", C.c_uint32),
                 ("num_families", C.c_uint32), ("families", C.c_int * 4), ("intrinsics", Intrinsics),
                 ("tag_size", C.c_float), ("max_batch", C.c_uint32), ("refine_edges", C.c_uint32),
                 ("max_hamming", C.c_uint32), ("decode_sharpening", C.c_float), ("max_points", C.c_uint32),
@@ -56,6 +56,7 @@ class Config(C.Structure):
 # every symbol include/apriltag_amd.h declares
 EXPORTS = ["amdAprilTagsDefaultConfig", "amdCreateAprilTagsDetector", "amdCreateAprilTagsDetectorEx",
            "amdAprilTagsDestroy", "amdAprilTagsDetect", "amdAprilTagsDetectBatch", "amdAprilTagsDetectBatchEx",
+           "amdAprilTagsSubmitBatch", "amdAprilTagsWaitBatch", "amdAprilTagsWaitBatchEx", "amdAprilTagsSetFrameSkews",
            "amdAprilTagsGetFrameFlags", "amdAprilTagsConvertToMono8", "amdAprilTagsRegisterFamily",
            "amdAprilTagsRegisterFamilyEx", "amdAprilTagsUnregisterFamily",
            "amdAprilTagsFamilyInfo", "amdAprilTagsFamilyFromName", "amdAprilTagsStageName",
@@ -89,6 +90,10 @@ def lib():
                                           C.POINTER(TagID), C.POINTER(C.c_uint32), C.c_uint32, H]
     L.amdAprilTagsDetectBatchEx.argtypes = [H, C.c_uint32, C.POINTER(ImageInput), C.POINTER(Intrinsics),
                                             C.POINTER(DetectionEx), C.POINTER(C.c_uint32), C.c_uint32, H]
+    L.amdAprilTagsSubmitBatch.argtypes = [H, C.c_uint32, C.POINTER(ImageInput), C.POINTER(Intrinsics), C.c_uint32, H]
+    L.amdAprilTagsWaitBatch.argtypes = [H, C.POINTER(TagID), C.POINTER(C.c_uint32)]
+    L.amdAprilTagsWaitBatchEx.argtypes = [H, C.POINTER(DetectionEx), C.POINTER(C.c_uint32)]
+    L.amdAprilTagsSetFrameSkews.argtypes = [H, C.c_uint32, C.POINTER(C.c_float)]
     L.amdAprilTagsGetFrameFlags.argtypes = [H, C.POINTER(C.c_uint32), C.c_uint32]
     L.amdAprilTagsConvertToMono8.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                              C.c_size_t, H]

@@ -90,7 +90,8 @@ struct DetParams {
   int W, H;          // working (decimated) size
   int WS;            // pitch of the working u8 images (multiple of 16)
   int decimate;
-  int tw, th;        // full 4x4 tiles
+  int tw, th;        // full tiles of the threshold (tile x tile pixels)
+  int tile;          // threshold tile edge: 4 (the one-pass kernel) or 8 (the two-pass statement)
   int min_white_black_diff;
   int min_component_size;
   int min_cluster_points;

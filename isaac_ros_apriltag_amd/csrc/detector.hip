@@ -170,6 +170,8 @@ struct amdAprilTagsDetector_st {
   // device buffers
   uint8_t* d_gray = nullptr;
   uint8_t* d_thr = nullptr;
+  uint8_t* d_tmin = nullptr;         // per-tile min / max of the two-pass threshold (tile_size != 4 only)
+  uint8_t* d_tmax = nullptr;
   uint32_t* d_label = nullptr;
   uint32_t* d_csize = nullptr;
   uint32_t* d_roots = nullptr;
@@ -228,6 +230,9 @@ struct amdAprilTagsDetector_st {
   hipEvent_t ev[AMDAT_NUM_STAGES + 1] = {};
   // which launch set a submission gets: by its size (AMDAT_PATH_AUTO) or pinned by amdAprilTagsDebugSetSubmissionPath, so that
   // the parity tests can put BOTH launch sets under the oracle at any frame count
+  bool events_recorded = false;      // the submission in flight recorded the stage events (profiling on, no graph replay)
+  struct { bool active = false; uint32_t n = 0, ostride = 0, max_out = 0; hipStream_t stream = nullptr; } inflight;   // amdAprilTagsSubmitBatch .. WaitBatch
+  std::vector<float> frame_skew;     // per batch slot, amdAprilTagsSetFrameSkews; empty: cfg.skew for every frame
   int path_mode = AMDAT_PATH_AUTO;
   int last_path = AMDAT_PATH_AUTO;   // the set the last submission ran (amdAprilTagsDebugLastSubmissionPath)
   float stage_ms[AMDAT_NUM_STAGES] = {};
@@ -271,6 +276,7 @@ extern "C" {
 
 void amdAprilTagsDefaultConfig(amdAprilTagsConfig_t* cfg, uint32_t width, uint32_t height) {
   memset(cfg, 0, sizeof(*cfg));
+  cfg->struct_size = (uint32_t)sizeof(*cfg);
   cfg->width = width;
   cfg->height = height;
   cfg->tile_size = 4;
@@ -383,7 +389,7 @@ const char* amdAprilTagsStageName(uint32_t stage) { return stage < AMDAT_NUM_STA
 
 static void free_all(amdAprilTagsDetector_st* D) {
   for (auto& g : D->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
-  hipFree(D->d_gray); hipFree(D->d_thr); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_roots); hipFree(D->d_hkeys);
+  hipFree(D->d_gray); hipFree(D->d_thr); hipFree(D->d_tmin); hipFree(D->d_tmax); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_roots); hipFree(D->d_hkeys);
   hipFree(D->d_hcnt); hipFree(D->d_hoff); hipFree(D->d_stage); hipFree(D->d_bhdr); hipFree(D->d_btab); hipFree(D->d_long); hipFree(D->d_pts); hipFree(D->d_clusters);
   hipFree(D->d_work); hipFree(D->d_work2); hipFree(D->d_workctl); hipFree(D->d_keys_scr); hipFree(D->d_quads);
   for (auto& c : D->cls) { hipFree(c.d_lf); hipFree(c.d_errs); }
@@ -480,23 +486,40 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   std::call_once(g_fam_once, init_families);
   if (!handle || !cfg_in) return AMDAT_INVALID_ARGUMENT;
   *handle = nullptr;
-  amdAprilTagsConfig_t cfg = *cfg_in;
+  // the caller's struct may be an older, shorter one (include/apriltag_amd.h: struct_size): only its own bytes are read, the
+  // fields beyond them keep the defaults
+  constexpr uint32_t kMinConfig = (uint32_t)offsetof(amdAprilTagsConfig_t, skew);   // the first published layout ended before `skew`
+  if (cfg_in->struct_size < kMinConfig || cfg_in->struct_size > sizeof(amdAprilTagsConfig_t)) return AMDAT_INVALID_ARGUMENT;
+  amdAprilTagsConfig_t cfg;
+  amdAprilTagsDefaultConfig(&cfg, 0, 0);
+  memcpy(&cfg, cfg_in, cfg_in->struct_size);
+  cfg.struct_size = (uint32_t)sizeof(cfg);
   if (cfg.width == 0 || cfg.height == 0 || cfg.max_batch == 0 || cfg.decimate == 0) return AMDAT_INVALID_ARGUMENT;
   if (cfg.max_batch > 65535) return AMDAT_BATCH_TOO_LARGE;   // a work item carries the batch slot in 16 bits
-  if (cfg.tile_size != 4) return AMDAT_UNSUPPORTED;
+  if (cfg.tile_size != 4 && cfg.tile_size != 8) return AMDAT_UNSUPPORTED;   // (the reference's default and twice it)
   if (cfg.decimate > 4) return AMDAT_UNSUPPORTED;     // the threshold loader is instantiated for 1..4
   if (cfg.max_hamming > 3) return AMDAT_INVALID_ARGUMENT;  // AprilRobotics' own limit for the code search
   if (cfg.corner_convention > AMDAT_CORNERS_ROTATED_180) return AMDAT_INVALID_ARGUMENT;
   if (cfg.num_families < 1 || cfg.num_families > AT_MAX_FAMILIES) return AMDAT_INVALID_ARGUMENT;
-  // the family tables are read (and copied to the device) under the registry's lock: a concurrent
-  // amdAprilTagsRegisterFamily[Ex] cannot swap a table out from under the copy
-  std::lock_guard<std::mutex> fam_lock(g_fam_mutex);
-  for (uint32_t i = 0; i < cfg.num_families; i++) {
-    if ((int)cfg.families[i] < 0 || cfg.families[i] >= AMDAT_ENUM_SIZE || !g_families[cfg.families[i]].codes)
-      return AMDAT_UNSUPPORTED;
+  // the family tables are copied under the registry's lock: a concurrent amdAprilTagsRegisterFamily[Ex] cannot swap a table
+  // out from under the copy
+  // (only for the copy: creation itself -- allocations, uploads, a device-wide wait -- runs without the registry's lock, so hosts
+  // that create their per-GPU handles in parallel, or register families meanwhile, are not serialised behind it)
+  struct FamilyCopy { FamilyHost layout; std::vector<uint64_t> codes; };
+  std::vector<FamilyCopy> fams(cfg.num_families);
+  {
+    std::lock_guard<std::mutex> fam_lock(g_fam_mutex);
+    for (uint32_t i = 0; i < cfg.num_families; i++) {
+      if ((int)cfg.families[i] < 0 || cfg.families[i] >= AMDAT_ENUM_SIZE || !g_families[cfg.families[i]].codes)
+        return AMDAT_UNSUPPORTED;
+      const FamilyHost& g = g_families[cfg.families[i]];
+      fams[i].codes.assign(g.codes, g.codes + g.ncodes);
+      fams[i].layout = g;
+      fams[i].layout.owned.clear(); fams[i].layout.codes = nullptr; fams[i].layout.name = nullptr;
+    }
   }
   const int W = 1 + ((int)cfg.width - 1) / (int)cfg.decimate, H = 1 + ((int)cfg.height - 1) / (int)cfg.decimate;
-  if (W / 4 < 1 || H / 4 < 1 || 2 * W + 1 >= (1 << 14) || 2 * H + 1 >= (1 << 14)) return AMDAT_UNSUPPORTED;
+  if (W / (int)cfg.tile_size < 1 || H / (int)cfg.tile_size < 1 || 2 * W + 1 >= (1 << 14) || 2 * H + 1 >= (1 << 14)) return AMDAT_UNSUPPORTED;
 
   auto* D = new (std::nothrow) amdAprilTagsDetector_st();
   if (!D) return AMDAT_OUT_OF_MEMORY;
@@ -516,7 +539,8 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   P.W0 = (int)cfg.width; P.H0 = (int)cfg.height; P.W = W; P.H = H;
   P.WS = (W + 15) & ~15;
   P.decimate = (int)cfg.decimate;
-  P.tw = W / 4; P.th = H / 4;
+  P.tile = (int)cfg.tile_size;
+  P.tw = W / P.tile; P.th = H / P.tile;
   P.min_white_black_diff = 5;
   P.min_component_size = 25;
   P.min_cluster_points = 24;
@@ -533,7 +557,7 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   P.tag_size = (double)cfg.tag_size;
   int min_tag_width = 1000000;
   for (int i = 0; i < P.nfam; i++) {
-    const FamilyHost& f = g_families[cfg.families[i]];
+    const FamilyHost& f = fams[i].layout;
     P.fam[i].d = f.d; P.fam[i].nbits = f.nbits; P.fam[i].width_at_border = f.width_at_border; P.fam[i].total_width = f.total_width;
     P.fam[i].reversed_border = f.reversed_border; P.fam[i].ncodes = f.ncodes;
     memcpy(P.fam[i].bit_x, f.bit_x, 64); memcpy(P.fam[i].bit_y, f.bit_y, 64); memcpy(P.fam[i].rot_src, f.rot_src, 64);
@@ -630,6 +654,7 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   };
   if (P.decimate > 1) alloc((void**)&D->d_gray, B * (size_t)H * P.WS);
   alloc((void**)&D->d_thr, B * (size_t)H * P.WS);
+  if (P.tile != 4) { alloc((void**)&D->d_tmin, B * (size_t)P.tw * P.th); alloc((void**)&D->d_tmax, B * (size_t)P.tw * P.th); }
   alloc((void**)&D->d_label, B * (size_t)npx * 4);
   alloc((void**)&D->d_csize, B * (size_t)npx * 4);
   // tile-local roots that go to the list touch their 64 x 64 tile's perimeter, and components are disjoint: at most
@@ -670,9 +695,9 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   alloc((void**)&D->d_fqprof, (64 + 8) * 8);
   D->d_ptprof = D->d_fqprof + 64;   // k_points' phase counters follow the quad fit's
   for (int i = 0; ok && i < P.nfam; i++) {
-    const FamilyHost& f = g_families[cfg.families[i]];
-    alloc((void**)&D->d_codes[i], (size_t)f.ncodes * 8);
-    if (ok && hipMemcpy(D->d_codes[i], f.codes, (size_t)f.ncodes * 8, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+    const std::vector<uint64_t>& codes = fams[i].codes;
+    alloc((void**)&D->d_codes[i], codes.size() * 8);
+    if (ok && hipMemcpy(D->d_codes[i], codes.data(), codes.size() * 8, hipMemcpyHostToDevice) != hipSuccess) ok = false;
     P.fam[i].codes = D->d_codes[i];
   }
   if (ok && hipHostMalloc((void**)&D->h_frames, B * sizeof(FrameDesc)) != hipSuccess) ok = false;
@@ -781,11 +806,25 @@ static void fill_frames(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTa
     D->h_frames[i].pad = 0;
     D->h_frames[i].fx = (double)k.fx; D->h_frames[i].fy = (double)k.fy;
     D->h_frames[i].cx = (double)k.cx; D->h_frames[i].cy = (double)k.cy;
-    D->h_frames[i].skew = (double)D->cfg.skew;
+    D->h_frames[i].skew = (double)(i < D->frame_skew.size() ? D->frame_skew[i] : D->cfg.skew);
   }
 }
 
 static void launch_threshold(amdAprilTagsDetector_st* D, const DetParams& P, uint32_t n, hipStream_t s) {
+  if (P.tile != 4) {   // the two-pass statement (kernels_threshold.h); 4 keeps the one-pass kernel below
+    const dim3 g1((unsigned)((P.tw * P.th + 255) / 256), 1, n), g2((unsigned)((P.W + 255) / 256), (unsigned)P.H, n);
+#define TH_ANY(DEC)                                                                                                      \
+    hipLaunchKernelGGL(k_tile_minmax<DEC>, g1, dim3(256), 0, s, D->d_frames, D->d_tmin, D->d_tmax, P.tile, P);           \
+    hipLaunchKernelGGL(k_threshold_any_tile<DEC>, g2, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, D->d_tmin, D->d_tmax, P.tile, P);
+    switch (P.decimate) {
+      case 1: TH_ANY(1) break;
+      case 2: TH_ANY(2) break;
+      case 3: TH_ANY(3) break;
+      default: TH_ANY(4) break;
+    }
+#undef TH_ANY
+    return;
+  }
   const int gx = ((P.W + 3) / 4 + TH_BTX - 1) / TH_BTX, gy = ((P.H + 3) / 4 + TH_BTY - 1) / TH_BTY;
   const unsigned ntiles = (unsigned)gx * gy * n;
   dim3 grid(8u * ((ntiles + 7u) / 8u));
@@ -1061,8 +1100,10 @@ static int enqueue_submission(amdAprilTagsDetector_st* D, uint32_t n, uint32_t o
 }
 
 // One pass of a submission over the device: captured-graph replay for small submissions, plain enqueues otherwise.
-static int run_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s) {
+// launch_once enqueues it and returns; finish_once waits for it (and reads the stage events when profiling is on).
+static int launch_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s) {
   const bool prof = D->profiling;
+  D->events_recorded = false;
   int evi = 0;
   // profiling: one HIP event per stage boundary, and a roctx range per stage (it spans the stage's enqueues; rocprofv3
   // --marker-trace shows them beside the kernels they launched)
@@ -1117,7 +1158,6 @@ static int run_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hi
     }
     if (hit) {
       HIP_TRY(hipGraphLaunch(hit->exec, s));
-      HIP_TRY(hipStreamSynchronize(s));
       return AMDAT_SUCCESS;
     }
   }
@@ -1125,9 +1165,14 @@ static int run_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hi
     const int rc = enqueue_submission(D, n, ostride, s, mark);
     if (rc) return rc;
   }
+  D->events_recorded = prof;
   HIP_TRY(hipGetLastError());
+  return AMDAT_SUCCESS;
+}
+
+static int finish_once(amdAprilTagsDetector_st* D, hipStream_t s) {
   HIP_TRY(hipStreamSynchronize(s));
-  if (prof) {
+  if (D->events_recorded) {
     for (int i = 0; i < AMDAT_NUM_STAGES; i++) {
       float ms = 0;
       hipEventElapsedTime(&ms, D->ev[i], D->ev[i + 1]);
@@ -1142,8 +1187,11 @@ static void drop_graphs(amdAprilTagsDetector_st* D) {
 }
 
 // One batched submission; results land in h_out / h_counters with `ostride` records per frame.
-static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images,
-                     const amdAprilTagsCameraIntrinsics_t* intr, uint32_t ostride, hipStream_t s) {
+// begin_batch fills the descriptor block and enqueues the submission; end_batch waits for it, and where a frame overflowed a
+// capacity the handle may grow, grows it and runs the submission again (the descriptors are still in the pinned block).
+static int begin_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images,
+                       const amdAprilTagsCameraIntrinsics_t* intr, uint32_t ostride, hipStream_t s) {
+  if (D->inflight.active) return AMDAT_INVALID_ARGUMENT;   // one submission per handle at a time (amdAprilTagsWaitBatch first)
   DeviceGuard guard(D->device);
   if (!guard.ok) return AMDAT_HIP_ERROR;
   if (D->unusable) return AMDAT_OUT_OF_MEMORY;   // (never launch on the half-allocated buffers of a failed regrowth)
@@ -1165,10 +1213,23 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
       }
     }
   }
+  if (D->tables_dirty) { const int crc = clear_hash_tables(D); if (crc) return crc; }
+  D->tables_dirty = true;
+  const int rc = launch_once(D, n, ostride, s);
+  if (rc) return rc;
+  D->inflight.active = true; D->inflight.n = n; D->inflight.ostride = ostride; D->inflight.stream = s;
+  return AMDAT_SUCCESS;
+}
+
+static int end_batch(amdAprilTagsDetector_st* D) {
+  if (!D->inflight.active) return AMDAT_INVALID_ARGUMENT;
+  DeviceGuard guard(D->device);
+  if (!guard.ok) return AMDAT_HIP_ERROR;
+  const uint32_t n = D->inflight.n, ostride = D->inflight.ostride;
+  const hipStream_t s = D->inflight.stream;
+  D->inflight.active = false;
   for (;;) {
-    if (D->tables_dirty) { const int crc = clear_hash_tables(D); if (crc) return crc; }
-    D->tables_dirty = true;
-    const int rc = run_once(D, n, ostride, s);
+    const int rc = finish_once(D, s);
     if (rc) return rc;
     D->tables_dirty = false;   // ran to its end: k_cluster_select left the pair table empty
     // A frame whose boundary points did not fit yields no clusters at all (flag 0x1), one whose component pairs did not fit
@@ -1182,6 +1243,7 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
     }
     bool cands_over = false;
     for (uint32_t f = 0; f < n; f++) cands_over |= (D->h_counters[f].flags & AT_FLAG_CANDS) != 0;
+    bool again = false;
     if (cands_over) {
       if (D->P.cand_cap < D->P.ccap) {   // grow the candidate list and repeat
         drop_graphs(D);
@@ -1196,33 +1258,57 @@ static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsI
           D->cands_bytes = nbytes;
           D->P.cand_cap = ncap;
           D->grown++;
-          continue;
+          again = true;
         }
       }
       // cannot grow: report it as what it is for the caller, a quad-list overflow
-      for (uint32_t f = 0; f < n; f++)
-        if (D->h_counters[f].flags & AT_FLAG_CANDS) D->h_counters[f].flags = (D->h_counters[f].flags & ~AT_FLAG_CANDS) | 0x8u;
+      if (!again)
+        for (uint32_t f = 0; f < n; f++)
+          if (D->h_counters[f].flags & AT_FLAG_CANDS) D->h_counters[f].flags = (D->h_counters[f].flags & ~AT_FLAG_CANDS) | 0x8u;
     }
-    const bool can_pts = D->grow_points && D->P.pcap < D->pcap_hard;
-    const bool can_hash = D->grow_hash && D->P.hcap < D->hcap_hard;
-    const bool redo = (pts_over && can_pts) || (hash_over && can_hash);
-    if (!redo) {   // (a crowded table grows before the next submission: this one's buffers may still be inspected)
-      if (hash_crowded && can_hash) D->pending_hash_grow = true;
-      return AMDAT_SUCCESS;
+    if (!again) {
+      const bool can_pts = D->grow_points && D->P.pcap < D->pcap_hard;
+      const bool can_hash = D->grow_hash && D->P.hcap < D->hcap_hard;
+      const bool redo = (pts_over && can_pts) || (hash_over && can_hash);
+      if (!redo) {   // (a crowded table grows before the next submission: this one's buffers may still be inspected)
+        if (hash_crowded && can_hash) D->pending_hash_grow = true;
+        return AMDAT_SUCCESS;
+      }
+      drop_graphs(D);   // captured launches carry the old pointers and capacities
+      const uint32_t pcap_before = D->P.pcap, hcap_before = D->P.hcap;
+      if (pts_over && can_pts) { const uint64_t want = (uint64_t)D->P.pcap * 2; D->P.pcap = want > D->pcap_hard ? D->pcap_hard : (uint32_t)want; }
+      if (hash_over && can_hash) D->P.hcap = D->P.hcap * 2 > D->hcap_hard ? D->hcap_hard : D->P.hcap * 2;
+      int grc = alloc_hash_buffers(D);
+      if (grc == AMDAT_SUCCESS) grc = alloc_point_buffers(D);   // (also when only the staging format changed)
+      if (grc != AMDAT_SUCCESS) {   // not enough memory to grow: keep reporting the overflow with the old capacities
+        D->P.pcap = pcap_before; D->P.hcap = hcap_before;
+        D->grow_points = false; D->grow_hash = false;
+        if (alloc_hash_buffers(D) != AMDAT_SUCCESS || alloc_point_buffers(D) != AMDAT_SUCCESS) { D->unusable = true; return AMDAT_OUT_OF_MEMORY; }
+        return AMDAT_SUCCESS;
+      }
+      D->grown++;
     }
-    drop_graphs(D);   // captured launches carry the old pointers and capacities
-    const uint32_t pcap_before = D->P.pcap, hcap_before = D->P.hcap;
-    if (pts_over && can_pts) { const uint64_t want = (uint64_t)D->P.pcap * 2; D->P.pcap = want > D->pcap_hard ? D->pcap_hard : (uint32_t)want; }
-    if (hash_over && can_hash) D->P.hcap = D->P.hcap * 2 > D->hcap_hard ? D->hcap_hard : D->P.hcap * 2;
-    int grc = alloc_hash_buffers(D);
-    if (grc == AMDAT_SUCCESS) grc = alloc_point_buffers(D);   // (also when only the staging format changed)
-    if (grc != AMDAT_SUCCESS) {   // not enough memory to grow: keep reporting the overflow with the old capacities
-      D->P.pcap = pcap_before; D->P.hcap = hcap_before;
-      D->grow_points = false; D->grow_hash = false;
-      if (alloc_hash_buffers(D) != AMDAT_SUCCESS || alloc_point_buffers(D) != AMDAT_SUCCESS) { D->unusable = true; return AMDAT_OUT_OF_MEMORY; }
-      return AMDAT_SUCCESS;
-    }
-    D->grown++;
+    // run the submission again on the grown buffers
+    if (D->tables_dirty) { const int crc = clear_hash_tables(D); if (crc) return crc; }
+    D->tables_dirty = true;
+    const int lrc = launch_once(D, n, ostride, s);
+    if (lrc) return lrc;
+  }
+}
+
+static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images,
+                     const amdAprilTagsCameraIntrinsics_t* intr, uint32_t ostride, hipStream_t s) {
+  const int rc = begin_batch(D, n, images, intr, ostride, s);
+  return rc ? rc : end_batch(D);
+}
+
+// copies the finished submission's records out of the pinned buffers
+static void copy_out_ex(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, uint32_t max_dets, amdAprilTagsDetectionEx_t* dets_out, uint32_t* num_dets) {
+  for (uint32_t f = 0; f < n; f++) {
+    uint32_t k = D->h_counters[f].nout;
+    if (k > ostride) k = ostride;
+    num_dets[f] = k;
+    memcpy(dets_out + (size_t)f * max_dets, D->h_out + (size_t)f * ostride, (size_t)k * sizeof(DetRec));
   }
 }
 
@@ -1236,12 +1322,7 @@ int amdAprilTagsDetectBatchEx(amdAprilTagsHandle handle, uint32_t n, const amdAp
   uint32_t ostride = max_dets < handle->P.dcap ? max_dets : handle->P.dcap;
   rc = run_batch(handle, n, images, per_frame_intrinsics, ostride, s);
   if (rc) return rc;
-  for (uint32_t f = 0; f < n; f++) {
-    uint32_t k = handle->h_counters[f].nout;
-    if (k > ostride) k = ostride;
-    num_dets[f] = k;
-    memcpy(dets_out + (size_t)f * max_dets, handle->h_out + (size_t)f * ostride, (size_t)k * sizeof(DetRec));
-  }
+  copy_out_ex(handle, n, ostride, max_dets, dets_out, num_dets);
   return AMDAT_SUCCESS;
 }
 
@@ -1263,6 +1344,18 @@ static void to_public(const DetRec& d, uint16_t family_enum, uint32_t corner_con
   o->center.y = (float)d.c[1];
 }
 
+static void copy_out_public(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, uint32_t max_tags, amdAprilTagsID_t* tags_out, uint32_t* num_tags) {
+  for (uint32_t f = 0; f < n; f++) {
+    uint32_t k = D->h_counters[f].nout;
+    if (k > ostride) k = ostride;
+    num_tags[f] = k;
+    for (uint32_t i = 0; i < k; i++) {
+      const DetRec& d = D->h_out[(size_t)f * ostride + i];
+      to_public(d, (uint16_t)D->cfg.families[d.family], D->cfg.corner_convention, &tags_out[(size_t)f * max_tags + i]);
+    }
+  }
+}
+
 int amdAprilTagsDetectBatch(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
                             const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics, amdAprilTagsID_t* tags_out,
                             uint32_t* num_tags, uint32_t max_tags, amdAprilTagsStream stream) {
@@ -1273,15 +1366,43 @@ int amdAprilTagsDetectBatch(amdAprilTagsHandle handle, uint32_t n, const amdApri
   uint32_t ostride = max_tags < handle->P.dcap ? max_tags : handle->P.dcap;
   rc = run_batch(handle, n, images, per_frame_intrinsics, ostride, s);
   if (rc) return rc;
-  for (uint32_t f = 0; f < n; f++) {
-    uint32_t k = handle->h_counters[f].nout;
-    if (k > ostride) k = ostride;
-    num_tags[f] = k;
-    for (uint32_t i = 0; i < k; i++) {
-      const DetRec& d = handle->h_out[(size_t)f * ostride + i];
-      to_public(d, (uint16_t)handle->cfg.families[d.family], handle->cfg.corner_convention, &tags_out[(size_t)f * max_tags + i]);
-    }
-  }
+  copy_out_public(handle, n, ostride, max_tags, tags_out, num_tags);
+  return AMDAT_SUCCESS;
+}
+
+// ---- the same submission in two halves: enqueue, then wait -------------------------------------------------------------
+// amdAprilTagsSubmitBatch returns as soon as the submission is enqueued on the stream; the host is free -- to copy the NEXT
+// batch's frames to the device on a stream of its own, to serve other handles -- until amdAprilTagsWaitBatch[Ex] blocks for
+// the results.  One submission per handle may be in flight; the images (and their device buffers) must stay valid until the
+// wait returns.  Submit + Wait gives exactly what the blocking call gives (the blocking call IS the two, back to back).
+int amdAprilTagsSubmitBatch(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
+                            const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics, uint32_t max_tags, amdAprilTagsStream stream) {
+  if (!handle || max_tags == 0) return AMDAT_INVALID_ARGUMENT;
+  int rc = check_images(handle, n, images);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : handle->own_stream;
+  const uint32_t ostride = max_tags < handle->P.dcap ? max_tags : handle->P.dcap;
+  rc = begin_batch(handle, n, images, per_frame_intrinsics, ostride, s);
+  if (rc) return rc;
+  handle->inflight.max_out = max_tags;
+  return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsWaitBatch(amdAprilTagsHandle handle, amdAprilTagsID_t* tags_out, uint32_t* num_tags) {
+  if (!handle || !tags_out || !num_tags || !handle->inflight.active) return AMDAT_INVALID_ARGUMENT;
+  const uint32_t n = handle->inflight.n, ostride = handle->inflight.ostride, max_tags = handle->inflight.max_out;
+  const int rc = end_batch(handle);
+  if (rc) return rc;
+  copy_out_public(handle, n, ostride, max_tags, tags_out, num_tags);
+  return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsWaitBatchEx(amdAprilTagsHandle handle, amdAprilTagsDetectionEx_t* dets_out, uint32_t* num_dets) {
+  if (!handle || !dets_out || !num_dets || !handle->inflight.active) return AMDAT_INVALID_ARGUMENT;
+  const uint32_t n = handle->inflight.n, ostride = handle->inflight.ostride, max_dets = handle->inflight.max_out;
+  const int rc = end_batch(handle);
+  if (rc) return rc;
+  copy_out_ex(handle, n, ostride, max_dets, dets_out, num_dets);
   return AMDAT_SUCCESS;
 }
 
@@ -1290,15 +1411,21 @@ int amdAprilTagsDetect(amdAprilTagsHandle handle, const amdAprilTagsImageInput_t
   return amdAprilTagsDetectBatch(handle, 1, img_input, nullptr, tags_out, num_tags, max_tags, stream);
 }
 
+int amdAprilTagsSetFrameSkews(amdAprilTagsHandle handle, uint32_t n, const float* skews) {
+  if (!handle || n > handle->cfg.max_batch || (n && !skews) || handle->inflight.active) return AMDAT_INVALID_ARGUMENT;
+  handle->frame_skew.assign(skews, skews + n);
+  return AMDAT_SUCCESS;
+}
+
 int amdAprilTagsGetFrameFlags(amdAprilTagsHandle handle, uint32_t* flags, uint32_t n) {
-  if (!handle || !flags || n > handle->last_n) return AMDAT_INVALID_ARGUMENT;
+  if (!handle || !flags || n > handle->last_n || handle->inflight.active) return AMDAT_INVALID_ARGUMENT;
   for (uint32_t i = 0; i < n; i++) flags[i] = handle->h_counters[i].flags;
   return AMDAT_SUCCESS;
 }
 
 int amdAprilTagsThresholdOnly(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
                               amdAprilTagsStream stream) {
-  if (!handle) return AMDAT_INVALID_ARGUMENT;
+  if (!handle || handle->inflight.active) return AMDAT_INVALID_ARGUMENT;
   int rc = check_images(handle, n, images);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : handle->own_stream;
@@ -1385,7 +1512,7 @@ int amdAprilTagsCopyToDevice(void* dst_dev, const void* src_host, size_t bytes, 
 
 int amdAprilTagsDebugCopy(amdAprilTagsHandle handle, uint32_t frame, amdAprilTagsDebugBuffer what, void* host_dst,
                           size_t capacity, size_t* bytes) {
-  if (!handle || !bytes || frame >= handle->last_n) return AMDAT_INVALID_ARGUMENT;
+  if (!handle || !bytes || frame >= handle->last_n || handle->inflight.active) return AMDAT_INVALID_ARGUMENT;
   const DetParams& P = handle->P;
   DeviceGuard guard(handle->device);
   if (!guard.ok) return AMDAT_HIP_ERROR;

@@ -281,3 +281,53 @@ __global__ __launch_bounds__(256) void k_threshold_leftover(const FrameDesc* __r
   thr_all[(size_t)frame * P.H * P.WS + (size_t)y * P.WS + x] = v > thresh ? 255 : 0;
   if (DEC > 1) gray_all[(size_t)frame * P.H * P.WS + (size_t)y * P.WS + x] = (uint8_t)v;
 }
+
+// ---- tile sizes other than 4 (the reference's settable `tile_size`, src/apriltag_node.cpp:566, handed to the library at
+// :451).  4 is the reference's default and the path every measurement is quoted on: it keeps the one-pass kernel above.  Any other
+// accepted size takes the plain statement of SURVEY.md A.2 in two passes -- per-tile min / max to two small global arrays
+// (tw x th bytes per frame), then per pixel the 3 x 3 tile neighbourhood, the low-contrast rule inside the full tiles and the
+// nearest tile's threshold right of / below them.  Same bytes as the oracle's ato_threshold(.., tile, ..); not a tuned kernel.
+template <int DEC>
+__global__ __launch_bounds__(256) void k_tile_minmax(const FrameDesc* __restrict__ frames, uint8_t* __restrict__ tmin_all,
+                                                     uint8_t* __restrict__ tmax_all, int ts, DetParams P) {
+  const int frame = (int)blockIdx.z + P.frame0;
+  const FrameDesc fd = frames[frame];
+  const int t = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (t >= P.tw * P.th) return;
+  const int tx = t % P.tw, ty = t / P.tw;
+  uint32_t mn = 255, mx = 0;
+  for (int r = 0; r < ts; r++)
+    for (int c = 0; c < ts; c++) {
+      const uint32_t v = th_px<DEC>((th_gimg_t)fd.img, fd.pitch, P.W0, P.H0, tx * ts + c, ty * ts + r);
+      mn = min(mn, v);
+      mx = max(mx, v);
+    }
+  tmin_all[(size_t)frame * P.tw * P.th + t] = (uint8_t)mn;
+  tmax_all[(size_t)frame * P.tw * P.th + t] = (uint8_t)mx;
+}
+
+template <int DEC>
+__global__ __launch_bounds__(256) void k_threshold_any_tile(const FrameDesc* __restrict__ frames, uint8_t* __restrict__ gray_all,
+                                                            uint8_t* __restrict__ thr_all, const uint8_t* __restrict__ tmin_all,
+                                                            const uint8_t* __restrict__ tmax_all, int ts, DetParams P) {
+  const int frame = (int)blockIdx.z + P.frame0;
+  const FrameDesc fd = frames[frame];
+  const int x = (int)(blockIdx.x * 256 + threadIdx.x), y = (int)blockIdx.y;
+  if (x >= P.W) return;
+  const uint8_t* tmin = tmin_all + (size_t)frame * P.tw * P.th;
+  const uint8_t* tmax = tmax_all + (size_t)frame * P.tw * P.th;
+  const int tX = min(x / ts, P.tw - 1), tY = min(y / ts, P.th - 1);
+  uint32_t mn = 255, mx = 0;
+  for (int ty = max(tY - 1, 0); ty <= min(tY + 1, P.th - 1); ty++)
+    for (int tx = max(tX - 1, 0); tx <= min(tX + 1, P.tw - 1); tx++) {
+      mn = min(mn, (uint32_t)tmin[ty * P.tw + tx]);
+      mx = max(mx, (uint32_t)tmax[ty * P.tw + tx]);
+    }
+  const uint32_t v = th_px<DEC>((th_gimg_t)fd.img, fd.pitch, P.W0, P.H0, x, y);
+  const bool in_full_tile = x < P.tw * ts && y < P.th * ts;   // (no low-contrast rule right of / below the last full tile)
+  uint8_t o;
+  if (in_full_tile && (int)(mx - mn) < P.min_white_black_diff) o = 127;
+  else o = v > mn + (mx - mn) / 2 ? 255 : 0;
+  thr_all[(size_t)frame * P.H * P.WS + (size_t)y * P.WS + x] = o;
+  if (DEC > 1) gray_all[(size_t)frame * P.H * P.WS + (size_t)y * P.WS + x] = (uint8_t)v;
+}

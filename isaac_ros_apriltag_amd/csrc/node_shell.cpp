@@ -35,6 +35,7 @@ struct DetectorApi {
   decltype(&amdAprilTagsDeviceAlloc) dev_alloc = nullptr;
   decltype(&amdAprilTagsDeviceFree) dev_free = nullptr;
   decltype(&amdAprilTagsCopyToDevice) copy_to_device = nullptr;
+  decltype(&amdAprilTagsSetFrameSkews) set_frame_skews = nullptr;
 };
 
 DetectorApi& api() {
@@ -62,6 +63,7 @@ DetectorApi& api() {
   BIND(dev_alloc, "amdAprilTagsDeviceAlloc")
   BIND(dev_free, "amdAprilTagsDeviceFree")
   BIND(copy_to_device, "amdAprilTagsCopyToDevice")
+  BIND(set_frame_skews, "amdAprilTagsSetFrameSkews")
 #undef BIND
   return a;
 }
@@ -351,7 +353,6 @@ struct AprilTagMultiCameraNode::Impl {
   struct Slot { bool pending = false; Header info_header; std::array<double, 9> k{}; };
   std::vector<Slot> slots;
 
-  float handle_skew = 0.0f;        // K[1] the handle was created with (VPI mode; the batch ABI carries fx, fy, cx, cy per frame, no skew)
 
   void Initialize(const CameraInfo& info) {
     if (opt.max_tags <= 0) throw std::runtime_error("'max_tags' must be positive");
@@ -368,8 +369,8 @@ struct AprilTagMultiCameraNode::Impl {
     cfg.intrinsics.fy = static_cast<float>(info.k[4]);
     cfg.intrinsics.cx = static_cast<float>(info.k[2]);
     cfg.intrinsics.cy = static_cast<float>(info.k[5]);
-    // one skew per handle -- the first stream's; a stream whose K[1] differs is refused frame by frame (CameraImageCallback)
-    cfg.skew = handle_skew = cuapriltags_mode ? 0.0f : static_cast<float>(info.k[1]);
+    // (VPI mode passes every camera's own skew K[1], src/apriltag_node.cpp:215-225: set per frame at every flush)
+    cfg.skew = cuapriltags_mode ? 0.0f : static_cast<float>(info.k[1]);
     cfg.tag_size = static_cast<float>(opt.size);
     cfg.max_batch = S;
     const int error = api().create_ex(&detector, &cfg);
@@ -446,12 +447,6 @@ bool AprilTagMultiCameraNode::CameraImageCallback(uint32_t stream, const Image& 
   if (image.header.stamp.sec != camera_info.header.stamp.sec || image.header.stamp.nanosec != camera_info.header.stamp.nanosec)
     return false;  // ExactTime synchroniser would not fire
   if (!impl_->initialized) impl_->Initialize(camera_info);
-  if (!impl_->cuapriltags_mode && static_cast<float>(camera_info.k[1]) != impl_->handle_skew) {
-    // S independent nodes would each pass their own skew (src/apriltag_node.cpp:215-225); one batched handle has one
-    std::fprintf(stderr, "[apriltag_node] stream %u: camera skew K[1] = %g differs from the handle's %g: frame dropped\n", stream,
-                 camera_info.k[1], static_cast<double>(impl_->handle_skew));
-    return false;
-  }
   Impl::Slot& sl = impl_->slots[stream];
   // the slot's device image is about to be overwritten: a frame staged earlier and not yet submitted is gone either way,
   // and a failed staging must not leave it pending under its old header
@@ -486,6 +481,11 @@ uint32_t AprilTagMultiCameraNode::Flush() {
   const uint32_t max_tags = static_cast<uint32_t>(I.opt.max_tags);
   std::vector<amdAprilTagsID_t> tags(static_cast<size_t>(n) * max_tags);
   std::vector<uint32_t> counts(n, 0);
+  if (!I.cuapriltags_mode) {   // every stream's own K[1], as S independent VPI-mode nodes would pass it
+    std::vector<float> skews(n);
+    for (uint32_t i = 0; i < n; i++) skews[i] = static_cast<float>(I.slots[who[i]].k[1]);
+    api().set_frame_skews(I.detector, n, skews.data());
+  }
   const int error = api().detect_batch(I.detector, n, imgs.data(), intr.data(), tags.data(), counts.data(), max_tags, nullptr);
   for (uint32_t s : who) I.slots[s].pending = false;
   if (error != 0) {

@@ -117,6 +117,14 @@ class AprilTagDetector:
                     self._L.amdAprilTagsDetectBatchEx(self._h, prep["n"], prep["imgs"], prep.get("intr"), prep["out"],
                                                       prep["cnt"], prep["max_dets"], stream))
 
+    def submit_prepared(self, prep, stream=None):
+        """amdAprilTagsSubmitBatch: enqueues and returns; wait_prepared() collects (results in prep['out'] / prep['cnt'])."""
+        capi._check("amdAprilTagsSubmitBatch",
+                    self._L.amdAprilTagsSubmitBatch(self._h, prep["n"], prep["imgs"], prep.get("intr"), prep["max_dets"], stream))
+
+    def wait_prepared(self, prep):
+        capi._check("amdAprilTagsWaitBatchEx", self._L.amdAprilTagsWaitBatchEx(self._h, prep["out"], prep["cnt"]))
+
     def unpack(self, prep):
         res = []
         out, cnt, max_dets = prep["out"], prep["cnt"], prep["max_dets"]

@@ -5,17 +5,17 @@ from isaac_ros_apriltag_amd import capi
 from oracle import pyoracle as po
 
 
-def oracle_params(K, decimate=1, tag_size=0.22):
+def oracle_params(K, decimate=1, tag_size=0.22, tile_size=4):
     # the C ABI carries float intrinsics (like cuAprilTagsCameraIntrinsics_t); give the oracle the same values
     f32 = lambda v: float(np.float32(v))
     return po.default_params(fx=f32(K[0, 0]), fy=f32(K[1, 1]), cx=f32(K[0, 2]), cy=f32(K[1, 2]), decimate=decimate,
-                             tag_size=f32(tag_size))
+                             tag_size=f32(tag_size), tile_size=tile_size)
 
 
-def compare_stages(det, frame_idx, img, families, K, decimate=1, tag_size=0.22, verbose=False):
+def compare_stages(det, frame_idx, img, families, K, decimate=1, tag_size=0.22, verbose=False, tile_size=4):
     """Returns a list of mismatch strings (empty = bit-exact parity on every stage)."""
     errs = []
-    odets, dump = po.detect(img, families=families, params=oracle_params(K, decimate, tag_size), want_dump=True)
+    odets, dump = po.detect(img, families=families, params=oracle_params(K, decimate, tag_size, tile_size), want_dump=True)
     w, h = dump["w"], dump["h"]
     gray = det.debug(frame_idx, capi.DBG_GRAY).reshape(h, w)
     if not np.array_equal(gray, dump["gray"]):

@@ -91,11 +91,37 @@ def test_create_argument_validation():
     h = C.c_void_p()
     cam = capi.Intrinsics(1000, 1000, 960, 540)
     # unsupported tile size / family -> AMDAT_UNSUPPORTED (the node throws on non-zero, apriltag_node.cpp:453-457)
-    assert L.amdCreateAprilTagsDetector(C.byref(h), 1920, 1080, 8, 0, C.byref(cam), 0.22) == 2
+    assert L.amdCreateAprilTagsDetector(C.byref(h), 1920, 1080, 5, 0, C.byref(cam), 0.22) == 2     # (4 and 8 exist)
     assert L.amdCreateAprilTagsDetector(C.byref(h), 1920, 1080, 4, 5, C.byref(cam), 0.22) == 2
     assert L.amdCreateAprilTagsDetector(C.byref(h), 0, 1080, 4, 0, C.byref(cam), 0.22) == 1
     assert L.amdCreateAprilTagsDetector(C.byref(h), 1920, 1080, 4, 0, None, 0.22) == 1
     assert L.amdAprilTagsDestroy(None) == 1
+    assert not h
+    # the two halves of the batched call: no handle, or nothing in flight
+    assert L.amdAprilTagsSubmitBatch(None, 1, None, None, 64, None) == 1
+    assert L.amdAprilTagsWaitBatch(None, None, None) == 1 and L.amdAprilTagsWaitBatchEx(None, None, None) == 1
+
+
+def test_config_struct_size():
+    """amdAprilTagsConfig_t carries its own size.  amdAprilTagsDefaultConfig sets it; a struct that did not come
+    from there (size 0), or one larger than the library's, is refused before anything else is looked at; a SHORTER struct -- a
+    caller built against the header before `skew` and `corner_convention` were appended -- is accepted and its missing tail
+    fields take the defaults (checked up to the first validation that fails without a device: a bad decimate still reports
+    AMDAT_UNSUPPORTED, i.e. the shorter struct was read, not rejected)."""
+    _need_lib()
+    L = capi.lib()
+    h = C.c_void_p()
+    cfg = capi.Config()
+    L.amdAprilTagsDefaultConfig(C.byref(cfg), 640, 480)
+    assert cfg.struct_size == C.sizeof(capi.Config)
+    cfg.decimate = 9                                   # -> AMDAT_UNSUPPORTED once the struct itself is accepted
+    assert L.amdCreateAprilTagsDetectorEx(C.byref(h), C.byref(cfg)) == 2
+    for bad in (0, 8, C.sizeof(capi.Config) + 4):
+        cfg.struct_size = bad
+        assert L.amdCreateAprilTagsDetectorEx(C.byref(h), C.byref(cfg)) == 1
+    cfg.struct_size = capi.Config.skew.offset          # the first published layout
+    cfg.corner_convention = 77                         # garbage beyond the caller's struct: never read
+    assert L.amdCreateAprilTagsDetectorEx(C.byref(h), C.byref(cfg)) == 2
     assert not h
 
 

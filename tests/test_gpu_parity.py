@@ -169,6 +169,57 @@ def test_throughput_set_decimate2_and_two_families(built, families, decimate, sc
     det.close()
 
 
+@pytest.mark.parametrize("name,scene,decimate", [
+    ("c1", lambda: synth.scene_c1(), 1),
+    ("c1_dec2", lambda: synth.scene_c1(), 2),
+    ("c2", lambda: synth.scene_c2(), 1),
+    ("noise_ragged", lambda: (np.random.default_rng(8).integers(0, 256, size=(477, 635), dtype=np.uint8), synth.default_K(635, 477)), 1),
+    ("noise_ragged_dec3", lambda: (np.random.default_rng(9).integers(0, 256, size=(203, 301), dtype=np.uint8), synth.default_K(301, 203)), 3),
+])
+def test_tile_size_8(built, name, scene, decimate):
+    """`tile_size` as the reference declares it (apriltag_node.cpp:566, handed to the library at :451): 8 constructs and detects,
+    threshold image and every later stage bit-exact against the oracle run with tile 8 -- config 1, config 2, ragged noise (the
+    pixels right of / below the last full 8 x 8 tile) -- and anything but 4 or 8 is still refused."""
+    r = scene()
+    img, K = np.ascontiguousarray(r[0]), r[1]
+    h, w = img.shape
+    det = AprilTagDetector(w, h, decimate=decimate, intrinsics=_k4(K), max_batch=1, tile_size=8)
+    g = det.detect_batch_ex(torch.from_numpy(img).cuda(), max_dets=64)[0]
+    errs, odets = pu.compare_stages(det, 0, img, ("tag36h11",), K, decimate, tile_size=8)
+    errs += pu.compare_detections(g, odets)
+    # the threshold does depend on the tile: the same frame with tile 4 gives another image
+    thr8 = det.debug(0, capi.DBG_THRESH).copy()
+    det.close()
+    det4, _ = _run(img, K, decimate=decimate)
+    thr4 = det4.debug(0, capi.DBG_THRESH)
+    det4.close()
+    assert not errs, errs[:4]
+    assert not np.array_equal(thr4, thr8)
+    if name.startswith("c"):
+        assert len(g) >= 1
+    for bad in (0, 2, 5, 16):
+        with pytest.raises(capi.AprilTagsError) as e:
+            AprilTagDetector(w, h, intrinsics=_k4(K), tile_size=bad)
+        assert e.value.code == 2
+
+
+def test_tile_size_8_through_the_node_shell(built):
+    """tile_size:=8 on the node (the reference's parameter): constructs at the first frame and publishes the golden tag."""
+    from isaac_ros_apriltag_amd import node as nd
+    img, K, _ = synth.scene_pol_golden()
+    K9 = [K[0, 0], 0, K[0, 2], 0, K[1, 1], K[1, 2], 0, 0, 1]
+    n = nd.AprilTagNode(max_tags=64, size=0.22, tile_size=8)
+    dets, _ = n.on_frame(img.ctypes.data, False, "mono8", 1920, 1080, 1920, K9)
+    n.close()
+    assert [d["id"] for d in dets] == [0]
+    o, _ = po.detect(img, params=pu.oracle_params(K, 1, 0.22, tile_size=8))
+    assert len(o) == 1 and np.abs(np.array(dets[0]["corners"]) - o[0]["p"][::-1]).max() < 1e-3
+    n5 = nd.AprilTagNode(tile_size=5)
+    with pytest.raises(RuntimeError):
+        n5.on_frame(img.ctypes.data, False, "mono8", 1920, 1080, 1920, K9)
+    n5.close()
+
+
 def test_c3_4k_board_decimate2(built):
     img, K, truth, size = synth.scene_c3()
     h, w = img.shape
@@ -680,9 +731,12 @@ def test_cpp_multi_stream_host(built, tmp_path):
     path = str(tmp_path / "streams.bin")
     S, F = 8, 2
     block = dump_streams.dump(path, S, F, 0.0, 1, tag_sizes=[0.22, 0.16])
-    out = subprocess.run([exe, path, "1", "2"], capture_output=True, text=True, timeout=600)
+    # --host-frames adds the double-buffered, PCIe-inclusive loop (amdAprilTagsSubmitBatch / copy stream / amdAprilTagsWaitBatch):
+    # its records are the ones checked below (the last thing each handle ran)
+    out = subprocess.run([exe, path, "1", "2", "--host-frames"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["fps_host_frames"] > 0
     assert rec["gpus"] == 1 and rec["streams"] == S and len(rec["streams_out"]) == S
     assert len(rec["per_gpu_seconds"]) == 1 and rec["per_gpu_seconds"][0] > 0
 
@@ -767,6 +821,63 @@ def test_bench_eight_ranks_on_one_gpu(built):
     assert rec["parity_gate_stages"]["mismatches"] == 0 and rec["parity_gate_stages"]["submission_path"] == "throughput"
     assert len(cfg["per_rank_fps"]["ranks"]) == 8 and cfg["per_rank_fps"]["min"] > 0
     assert rec["value"] > 0 and abs(rec["value"] - 8 * 16 / (rec["ms_per_step"] * 1e-3)) < 0.01 * rec["value"]
+
+
+def test_submit_wait_is_the_blocking_call_in_two_halves(built):
+    """amdAprilTagsSubmitBatch / amdAprilTagsWaitBatch[Ex]: the same records as the blocking call, for a
+    one-frame (graph replay) and a twelve-frame (throughput set) submission, while the host copies the next frames on a stream of
+    its own between the halves; one submission per handle at a time; a capacity overflow met at the wait still grows the buffers
+    and repeats the submission."""
+    frames = np.stack([synth.scene_c2(seed=1234 + i)[0] for i in range(12)])
+    K = synth.default_K(1920, 1080)
+    dev = torch.from_numpy(frames).cuda()
+    det = AprilTagDetector(1920, 1080, intrinsics=_k4(K), max_batch=12)
+    L = capi.lib()
+    for nfr in (1, 12):
+        ref = det.detect_batch_ex(dev[:nfr], max_dets=64)
+        prep = det.prepare(dev[:nfr], max_dets=64)
+        side = torch.cuda.Stream()
+        nxt = torch.empty_like(dev)
+        host = torch.from_numpy(frames).pin_memory()
+        det.submit_prepared(prep)
+        # in flight: everything that runs or inspects a submission is refused, the handle's results are not touched
+        assert L.amdAprilTagsSubmitBatch(det._h, prep["n"], prep["imgs"], None, 64, None) == 1
+        assert L.amdAprilTagsDetectBatchEx(det._h, prep["n"], prep["imgs"], None, prep["out"], prep["cnt"], 64, None) == 1
+        nb = C.c_size_t()
+        assert L.amdAprilTagsDebugCopy(det._h, 0, capi.DBG_COUNTS, None, 0, C.byref(nb)) == 1
+        with torch.cuda.stream(side):
+            nxt.copy_(host, non_blocking=True)           # the next batch's H2D copy, overlapped with the detection
+        det.wait_prepared(prep)
+        side.synchronize()
+        got = det.unpack(prep)
+        assert len(got) == nfr
+        for a, b in zip(got, ref):
+            assert not pu.compare_detections(a, b)
+        assert torch.equal(nxt, dev)
+        assert L.amdAprilTagsWaitBatchEx(det._h, prep["out"], prep["cnt"]) == 1    # nothing in flight
+        # the cuAprilTagsID_t-shaped wait
+        det.submit_prepared(prep)
+        tags = (capi.TagID * (nfr * 64))()
+        cnt = (C.c_uint32 * nfr)()
+        assert L.amdAprilTagsWaitBatch(det._h, tags, cnt) == 0
+        rtags, rcnt = det.detect_batch_raw(dev[:nfr], max_tags=64)
+        assert list(cnt) == rcnt and bytes(tags) == bytes(rtags)
+    det.close()
+    # growth at the wait: one-pixel stripes have ~2 boundary points per pixel, the default capacity is 1
+    w, h = 640, 480
+    yy = np.mgrid[0:h, 0:w][0]
+    img = np.where(yy % 2 == 0, 40, 215).astype(np.uint8)
+    K2 = synth.default_K(w, h)
+    d2 = AprilTagDetector(w, h, intrinsics=_k4(K2), max_batch=1)
+    t = torch.from_numpy(np.ascontiguousarray(img)).cuda()
+    before = d2.device_bytes()
+    p2 = d2.prepare(t, max_dets=64)
+    d2.submit_prepared(p2)
+    d2.wait_prepared(p2)
+    assert d2.frame_flags(1) == [0] and d2.device_bytes() > before
+    errs, _ = pu.compare_stages(d2, 0, img, ("tag36h11",), K2, 1)
+    d2.close()
+    assert not errs, errs[:3]
 
 
 def test_c99_example_runs(built, tmp_path):
@@ -1005,16 +1116,22 @@ def test_multi_camera_node(built):
               % (t_single * 1e3, S / t_single, t_multi * 1e3, S / t_multi))
         assert multi.last(3)[0] == want[3]
         assert t_multi < t_single
-        # VPI mode passes the skew K[1] (apriltag_node.cpp:215-225) and one batched handle has one skew: a stream whose
-        # K[1] differs from the handle's is refused, and a refused frame leaves nothing pending under an older header
+        # VPI mode passes the skew K[1] (apriltag_node.cpp:215-225): every stream keeps ITS OWN in the batched node (ADVICE round 4:
+        # a stream whose K[1] differed from the first stream's used to be refused frame by frame) -- same messages as two
+        # independent VPI-mode nodes with those CameraInfos
         vpi = node.AprilTagMultiCameraNode(2, backends="CPU", auto_flush=False)
         try:
             Ksk = list(Ks[0]); Ksk[1] = 2.5
-            assert vpi.on_frame(0, frames[0].ctypes.data, False, "mono8", 1920, 1080, 1920, Ksk, "cam0", (40, 0))
-            assert vpi.on_frame(1, frames[1].ctypes.data, False, "mono8", 1920, 1080, 1920, Ksk, "cam1", (40, 1))
             Kother = list(Ks[1]); Kother[1] = 0.5
-            assert not vpi.on_frame(1, frames[1].ctypes.data, False, "mono8", 1920, 1080, 1920, Kother, "cam1", (41, 1))
+            assert vpi.on_frame(0, frames[0].ctypes.data, False, "mono8", 1920, 1080, 1920, Ksk, "cam0", (40, 0))
+            assert vpi.on_frame(1, frames[1].ctypes.data, False, "mono8", 1920, 1080, 1920, Kother, "cam1", (40, 1))
             assert vpi.flush() == 2 and vpi.last(1)[2] == (40, 1) and len(vpi.last(0)[0]) == 10
+            for s_, Kv in ((0, Ksk), (1, Kother)):
+                one = node.AprilTagNode(backends="CPU")
+                want_v, _ = one.on_frame(frames[s_].ctypes.data, False, "mono8", 1920, 1080, 1920, Kv, "cam%d" % s_, (40, s_))
+                one.close()
+                assert vpi.last(s_)[0] == want_v, s_
+                assert [d["position"] for d in want_v] != [d["position"] for d in want[s_]]     # the skew does change the pose
             # a frame that fails staging (wrong size) drops what the slot held
             assert vpi.on_frame(0, frames[0].ctypes.data, False, "mono8", 1920, 1080, 1920, Ksk, "cam0", (42, 0))
             assert not vpi.on_frame(0, frames[0].ctypes.data, False, "mono8", 1280, 720, 1280, Ksk, "cam0", (43, 0))
