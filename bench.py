@@ -127,7 +127,35 @@ def cpu_baseline(frames, intr, decimate, tag_size, budget_s=15.0):
                      "frame-parallel; single thread %.2f frames/s; CPU restatement of AprilRobotics apriltag_detect "
                      "(AprilRobotics' binary is not part of the reference)" % (n, len(byframe), flags, cores, 1.0 / t1),
            "single_thread_fps": round(1.0 / t1, 3)}
-    # optional second row: a real libapriltag.so, if this host has one (never required)
+    # Second row: a CPU path that is trying -- the same restatement with upstream's own cheaper forms
+    # (sequential double moment sums instead of the checker's 128-bit exact ones, float border dot) through cheaper code (radix
+    # sort of the slope keys, AprilRobotics' quick_decode table instead of a scan over 587 x 4 codes): ATO_VAR_SEQ_MOMENTS |
+    # ATO_VAR_FLOAT_DOT | ATO_VAR_FAST_PATHS.  Detections are compared with the checker's on the same frames.
+    fast_var = po.VAR_SEQ_MOMENTS | po.VAR_FLOAT_DOT | po.VAR_FAST_PATHS
+
+    def run_fast(i):
+        fx, fy, cx, cy = intr[i]
+        K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+        prm = pu.oracle_params(K, decimate, tag_size)
+        prm.variant = fast_var
+        return po.detect(frames[i], params=prm)[0]
+    run_fast(0)                                   # (builds the decode table once)
+    t0 = time.perf_counter()
+    run_fast(0)
+    t1f = time.perf_counter() - t0
+    nf = int(max(cores, min(len(frames) * 4, 0.6 * budget_s * cores / max(t1f, 1e-3))))
+    idxf = [i % len(frames) for i in range(nf)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        resf = list(ex.map(run_fast, idxf))
+    dtf = time.perf_counter() - t0
+    same = all(len(a) == len(byframe[i]) and all(x["id"] == y["id"] and x["hamming"] == y["hamming"] and np.abs(x["p"] - y["p"]).max() < 1e-6
+                                                  for x, y in zip(a, byframe[i])) for i, a in zip(idxf, resf))
+    rec["upstream_forms"] = {"value": round(nf / dtf, 2), "unit": "frames/s", "cores": cores, "single_thread_fps": round(1.0 / t1f, 3),
+                             "kind": "port", "sample": "%d frames; sequential double moment sums + float border dot (upstream's statements, "
+                             "ATO_VAR_SEQ_MOMENTS | ATO_VAR_FLOAT_DOT), radix-sorted slope keys, quick_decode hash table (ATO_VAR_FAST_PATHS)" % nf,
+                             "detections_equal_checker_ids_hamming_corners_1e-6": bool(same)}
+    # optional third row: a real libapriltag.so, if this host has one (never required)
     try:
         from oracle import aprilrobotics_xcheck as ax
         real = ax.time_and_compare(frames[:min(len(frames), 8)], byframe, decimate)

@@ -12,6 +12,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <pthread.h>
 #include <string.h>
 
 #include "../include/apriltag_amd_families.h"
@@ -506,6 +507,29 @@ static int u64_cmp(const void* a, const void* b) {
   return (x > y) - (x < y);
 }
 
+/* ATO_VAR_FAST_PATHS: the same ascending order of the 64-bit keys as qsort(u64_cmp), by a byte-wise LSD radix sort (keys are
+ * unique up to exact duplicates, so stability does not matter).  Small arrays: insertion sort. */
+static void sort_keys_fast(uint64_t* k, int n) {
+  if (n <= 48) {
+    for (int i = 1; i < n; i++) { uint64_t v = k[i]; int j = i - 1; while (j >= 0 && k[j] > v) { k[j + 1] = k[j]; j--; } k[j + 1] = v; }
+    return;
+  }
+  uint64_t* tmp = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
+  uint64_t* a = k; uint64_t* b = tmp;
+  for (int pass = 0; pass < 8; pass++) {
+    const int sh = pass * 8;
+    uint32_t cnt[257];
+    memset(cnt, 0, sizeof(cnt));
+    for (int i = 0; i < n; i++) cnt[((a[i] >> sh) & 0xFF) + 1]++;
+    if (cnt[((a[0] >> sh) & 0xFF) + 1] == (uint32_t)n) continue;   /* every key has the same byte here */
+    for (int j = 0; j < 256; j++) cnt[j + 1] += cnt[j];
+    for (int i = 0; i < n; i++) b[cnt[(a[i] >> sh) & 0xFF]++] = a[i];
+    uint64_t* t = a; a = b; b = t;
+  }
+  if (a != k) memcpy(k, a, sizeof(uint64_t) * (size_t)n);
+  free(tmp);
+}
+
 /* exact fixed-point view of a double >= 1: value * 2^52 as a 128-bit integer (terms < 2^36 fit easily) */
 static unsigned __int128 exact_to_fixed(double t) {
   uint64_t bits;
@@ -584,7 +608,8 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
     /* CANONICAL total order: (slope, y, x, gx, gy) */
     keys[i] = ((uint64_t)float_sortable(slope) << 32) | ((uint64_t)y << 18) | ((uint64_t)x << 4) | (pts[i] & 15u);
   }
-  qsort(keys, sz, sizeof(uint64_t), u64_cmp);
+  if (prm->variant & ATO_VAR_FAST_PATHS) sort_keys_fast(keys, sz);
+  else qsort(keys, sz, sizeof(uint64_t), u64_cmp);
   double diag_sector[3] = {0, 0, 0};
   if (ato_diag_cap > 0) {
     /* angular-sector variant of the relaxed feasibility test, computable BEFORE the sort: sectors are intervals of the
@@ -688,6 +713,9 @@ static int fit_quad(const ato_params_t* prm, const uint8_t* gray, int w, int h, 
     }
     double t[6] = {W * x, W * y, W * x * x, W * x * y, W * y * y, W};
     double r[6];
+    if ((prm->variant & (ATO_VAR_FAST_PATHS | ATO_VAR_SEQ_MOMENTS)) == (ATO_VAR_FAST_PATHS | ATO_VAR_SEQ_MOMENTS)) {
+      for (int j = 0; j < 6; j++) { seq[j] += t[j]; r[j] = seq[j]; }   /* upstream's compute_lfps, nothing else */
+    } else
     for (int j = 0; j < 6; j++) {
       acc[j] += exact_to_fixed(t[j]); r[j] = exact_from_fixed(acc[j]);
       seq[j] += t[j];
@@ -999,7 +1027,64 @@ static uint64_t rotate90(const ato_family_t* f, uint64_t w) {
 
 /* quick_decode_codeword semantics: first rotation r in 0..3 for which some code is within
  * max_hamming bits (unique by the family's minimum distance). */
-static int decode_codeword(const ato_family_t* fam, uint64_t rcode, int max_hamming, int* id, int* hamming, int* rotation) {
+/* ATO_VAR_FAST_PATHS: AprilRobotics' quick_decode -- an open-addressing table of every code word and every word within one or two
+ * bit errors of one ({code, id, hamming}); a lookup per rotation instead of a scan over the family.  Built once per family
+ * (keyed by the code table's address and size), kept for the life of the process; families whose table would not fit the
+ * published layout's assumptions (more than 2 correctable bits asked for) fall back to the scan. */
+typedef struct { uint64_t code; uint16_t id; uint8_t hamming, used; } qd_entry_t;
+typedef struct { const uint64_t* codes; uint32_t ncodes, nbits; size_t cap; qd_entry_t* tab; } qd_table_t;
+static qd_table_t g_qd[8];
+static int g_qd_n;
+static pthread_mutex_t g_qd_lock = PTHREAD_MUTEX_INITIALIZER;
+static void qd_add(qd_table_t* t, uint64_t code, uint32_t id, int hamming) {
+  size_t h = (size_t)((code * 0x9E3779B97F4A7C15ULL) >> 24) & (t->cap - 1);
+  while (t->tab[h].used) {
+    if (t->tab[h].code == code) { if (hamming < t->tab[h].hamming) { t->tab[h].id = (uint16_t)id; t->tab[h].hamming = (uint8_t)hamming; } return; }
+    h = (h + 1) & (t->cap - 1);
+  }
+  t->tab[h].code = code; t->tab[h].id = (uint16_t)id; t->tab[h].hamming = (uint8_t)hamming; t->tab[h].used = 1;
+}
+static const qd_table_t* qd_get(const ato_family_t* fam) {
+  pthread_mutex_lock(&g_qd_lock);
+  for (int i = 0; i < g_qd_n; i++)
+    if (g_qd[i].codes == fam->codes && g_qd[i].ncodes == fam->ncodes && g_qd[i].nbits == fam->nbits) { pthread_mutex_unlock(&g_qd_lock); return &g_qd[i]; }
+  if (g_qd_n == 8 || fam->ncodes > 65535) { pthread_mutex_unlock(&g_qd_lock); return NULL; }
+  qd_table_t* t = &g_qd[g_qd_n];
+  const size_t entries = (size_t)fam->ncodes * (1 + fam->nbits + (size_t)fam->nbits * (fam->nbits - 1) / 2);
+  t->cap = 1024;
+  while (t->cap < entries * 3) t->cap <<= 1;
+  t->tab = (qd_entry_t*)calloc(t->cap, sizeof(qd_entry_t));
+  t->codes = fam->codes; t->ncodes = fam->ncodes; t->nbits = fam->nbits;
+  for (uint32_t i = 0; i < fam->ncodes; i++) {
+    const uint64_t c = fam->codes[i];
+    qd_add(t, c, i, 0);
+    for (uint32_t a = 0; a < fam->nbits; a++) {
+      qd_add(t, c ^ (1ULL << a), i, 1);
+      for (uint32_t b = 0; b < a; b++) qd_add(t, c ^ (1ULL << a) ^ (1ULL << b), i, 2);
+    }
+  }
+  g_qd_n++;
+  pthread_mutex_unlock(&g_qd_lock);
+  return t;
+}
+static int decode_codeword_scan(const ato_family_t* fam, uint64_t rcode, int max_hamming, int* id, int* hamming, int* rotation);
+static int decode_codeword_fast(const ato_family_t* fam, uint64_t rcode, int max_hamming, int* id, int* hamming, int* rotation) {
+  const qd_table_t* t = max_hamming <= 2 ? qd_get(fam) : NULL;
+  if (!t) return decode_codeword_scan(fam, rcode, max_hamming, id, hamming, rotation);
+  for (int r = 0; r < 4; r++) {
+    size_t h = (size_t)((rcode * 0x9E3779B97F4A7C15ULL) >> 24) & (t->cap - 1);
+    while (t->tab[h].used) {
+      if (t->tab[h].code == rcode) {
+        if (t->tab[h].hamming <= max_hamming) { *id = t->tab[h].id; *hamming = t->tab[h].hamming; *rotation = r; return 1; }
+        break;
+      }
+      h = (h + 1) & (t->cap - 1);
+    }
+    rcode = rotate90(fam, rcode);
+  }
+  return 0;
+}
+static int decode_codeword_scan(const ato_family_t* fam, uint64_t rcode, int max_hamming, int* id, int* hamming, int* rotation) {
   for (int r = 0; r < 4; r++) {
     int best = 1 << 30, bid = -1;
     for (uint32_t i = 0; i < fam->ncodes; i++) {
@@ -1117,7 +1202,8 @@ static float quad_decode(const ato_params_t* prm, const ato_family_t* fam, const
     if (v > 0) { white_score = (float)((double)white_score + v); white_count++; rcode |= 1; }
     else { black_score = (float)((double)black_score - v); black_count++; }
   }
-  *found = decode_codeword(fam, rcode, prm->max_hamming, id, hamming, rotation);
+  *found = (prm->variant & ATO_VAR_FAST_PATHS) ? decode_codeword_fast(fam, rcode, prm->max_hamming, id, hamming, rotation)
+                                              : decode_codeword_scan(fam, rcode, prm->max_hamming, id, hamming, rotation);
   float a = white_score / white_count, b = black_score / black_count;
   return a < b ? a : b;
 }

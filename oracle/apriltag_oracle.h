@@ -72,6 +72,12 @@ typedef struct {
 /* (16 was FLOAT_COS: upstream's float cos_critical_rad is the definition now) */
 #define ATO_VAR_AT3_BIT_ORDER 32 /* quad_decode: white/black scores (floats) accumulated in AprilTag 3's bit order (four
                                 * rotated quadrant triangles, centre bit last) instead of row-major */
+#define ATO_VAR_FAST_PATHS 128   /* NOT a change of definition: the same statements through cheaper code, for bench.py's second CPU row
+                                  * ("a CPU baseline that is trying").  With ATO_VAR_SEQ_MOMENTS the 128-bit exact sums are not
+                                  * formed at all (without this flag both are, so that the checker can compare them); the slope keys
+                                  * are sorted by an LSD radix sort instead of qsort with a comparator (same total order); codes are
+                                  * looked up in a hash table of every code word within two bit errors -- AprilRobotics' quick_decode --
+                                  * instead of a scan over the family per rotation (same result for max_hamming <= 2). */
 /* (64 was TRIG_RZ: H * Rz with libm's cos / sin values and the full 3x3 product is the definition now) */
 
 typedef struct {

@@ -190,6 +190,7 @@ def rectify_mono8(img, K, D, Knew):
 
 VAR_SEQ_MOMENTS, VAR_ATAN_NORMAL, VAR_SVD_POLAR, VAR_FLOAT_DOT = 1, 2, 4, 8
 VAR_AT3_BIT_ORDER = 32   # (16 and 64 were FLOAT_COS and TRIG_RZ: upstream's forms are the definition now)
+VAR_FAST_PATHS = 128     # same statements through cheaper code (radix sort of the keys, quick_decode table, no exact sums beside SEQ_MOMENTS)
 
 
 def pose_from_homography(H, fx, fy, cx, cy, tag_size, skew=0.0, variant=0):

@@ -110,3 +110,32 @@ def test_skew_pose_recovers_truth(built):
         R0, t0 = po.pose_from_homography(H, fx, fy, cx, cy, size, skew=0.0)
         assert np.abs(R2 - R).max() < 1e-4 and np.abs(t2 - t).max() < 1e-4
         assert max(np.abs(R0 - R).max(), np.abs(t0 - t).max()) > 1e-4   # ignoring the skew is measurably wrong
+
+
+def test_fast_paths_change_nothing():
+    """ATO_VAR_FAST_PATHS (bench.py's second CPU row) is cheaper CODE, not another definition: radix-sorted slope keys and the
+    quick_decode table give the same quads and detections bit for bit, on clean and noisy frames, two families, and tags whose
+    code words carry one or two flipped bits (the table's Hamming entries); with ATO_VAR_SEQ_MOMENTS beside it the result is the
+    SEQ_MOMENTS variant's, bit for bit."""
+    cases = list(_scenes())
+    codes, _ = synth.family_codes("tag36h11")
+    for nflip in (1, 2, 3):   # (three flipped bits: beyond what is corrected -- no detection either way)
+        tags = []
+        for k in range(6):
+            code = codes[40 + k]
+            for b in range(nflip):
+                code ^= 1 << ((7 * k + 13 * b + 3) % 36)
+            H = np.array([[60.0, 0, 110.0 + 190.0 * (k % 3)], [0, 60.0, 130.0 + 210.0 * (k // 3)], [0, 0, 1.0]])
+            tags.append({"family": "tag36h11", "id": 40 + k, "H": H, "code": code})
+        img = synth.render(640, 480, tags, background=160, sigma=1.0, seed=77 + nflip)
+        cases.append(("vga_%d_flipped_bits" % nflip, (img, synth.default_K(640, 480)), ("tag36h11",), 1))
+    for name, r, fams, dec in cases:
+        img, K = r[0], r[1]
+        for base in (0, po.VAR_SEQ_MOMENTS | po.VAR_FLOAT_DOT):
+            prm = pu.oracle_params(K, dec, 0.22)
+            prm.variant = base
+            a, da = po.detect(img, families=fams, params=prm, want_dump=True)
+            prm.variant = base | po.VAR_FAST_PATHS
+            b, db = po.detect(img, families=fams, params=prm, want_dump=True)
+            assert not pu.compare_detections(b, a), (name, base)
+            assert pu.stage_digest_oracle(da) == pu.stage_digest_oracle(db), (name, base)
