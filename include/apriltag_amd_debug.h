@@ -40,11 +40,6 @@ int amdAprilTagsDebugSetSubmissionPath(amdAprilTagsHandle handle, int path);
 /* AMDAT_PATH_LATENCY or AMDAT_PATH_THROUGHPUT: the set the handle's last submission ran (AMDAT_PATH_AUTO before the first). */
 int amdAprilTagsDebugLastSubmissionPath(amdAprilTagsHandle handle);
 
-/* Launch-order knobs for A/B measurements inside one process (tools/): knob 0 = what starts beside the quad fit's prefilter on
- * throughput-sized submissions (0 nothing, 1 k_fit_small, 2 the one-wave class, 3 every class below the prefilter's).  Results
- * never depend on a knob. */
-int amdAprilTagsDebugSetTuning(amdAprilTagsHandle handle, int knob, int value);
-
 /* ---- stage inspection (parity tests) ------------------------------------------------------ */
 typedef enum {
   AMDAT_DBG_GRAY = 0,      /* u8  w*h working gray image */

@@ -146,11 +146,6 @@ uint32_t next_pow2(uint32_t v) {
 // streams + the submission stream) crashed inside hipGraphLaunch (hip::Graph::UpdateStreams, ROCm 7.2) in about one of seven
 // 300-case fuzz runs; with four branches it never has.  Classes that launch share the streams round-robin.
 #define FQ_NAUX 3
-// What starts at t = 0 beside the prefilter (throughput path): 0 nothing (the prefilter runs first and alone), 1 k_fit_small,
-// 2 the one-wave class of k_fit_quads, 3 every class below the prefilter's.  The prefilter then runs on a highest-priority stream.
-#ifndef AMDAT_FQ_START_DEFAULT
-#define AMDAT_FQ_START_DEFAULT 0
-#endif
 struct FqClass {
   int nt, sort_cap, lo, hi;
   unsigned grid;
@@ -171,9 +166,7 @@ struct amdAprilTagsDetector_st {
   hipStream_t own_stream = nullptr;
   // the size classes of the quad fit fork to auxiliary streams and join before decode
   hipStream_t aux_stream[FQ_NAUX] = {};
-  hipStream_t hp_stream = nullptr;   // highest priority: the prefilter when it starts beside a small class (fq_start)
-  hipEvent_t ev_fork = nullptr, ev_join[FQ_NAUX] = {}, ev_pf = nullptr;
-  int fq_start = AMDAT_FQ_START_DEFAULT;   // amdAprilTagsDebugSetTuning(0, ..): what starts beside the prefilter on throughput-sized submissions
+  hipEvent_t ev_fork = nullptr, ev_join[FQ_NAUX] = {};
   // device buffers
   uint8_t* d_gray = nullptr;
   uint8_t* d_thr = nullptr;
@@ -409,8 +402,6 @@ static void free_all(amdAprilTagsDetector_st* D) {
   for (auto& e : D->ev) if (e) hipEventDestroy(e);
   if (D->own_stream) hipStreamDestroy(D->own_stream);
   for (auto& a : D->aux_stream) if (a) hipStreamDestroy(a);
-  if (D->hp_stream) hipStreamDestroy(D->hp_stream);
-  if (D->ev_pf) hipEventDestroy(D->ev_pf);
   if (D->ev_fork) hipEventDestroy(D->ev_fork);
   for (auto& e : D->ev_join) if (e) hipEventDestroy(e);
 }
@@ -716,12 +707,6 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   for (auto& e : D->ev) if (ok && hipEventCreate(&e) != hipSuccess) ok = false;
   for (auto& a : D->aux_stream) if (ok && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) ok = false;
   if (ok && hipEventCreateWithFlags(&D->ev_fork, hipEventDisableTiming) != hipSuccess) ok = false;
-  if (ok && hipEventCreateWithFlags(&D->ev_pf, hipEventDisableTiming) != hipSuccess) ok = false;
-  if (ok) {
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
-    if (hipStreamCreateWithPriority(&D->hp_stream, hipStreamNonBlocking, greatest) != hipSuccess) ok = false;
-  }
   for (auto& e : D->ev_join) if (ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
   // dynamic LDS beyond 64 KB has to be allowed per kernel (once per device; not allowed while a stream is being captured)
   if (ok) {
@@ -788,12 +773,6 @@ int amdAprilTagsDebugSetSubmissionPath(amdAprilTagsHandle handle, int path) {
   for (auto& g : handle->graphs) if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }   // captured under the other path
   handle->path_mode = path;
   return AMDAT_SUCCESS;
-}
-
-int amdAprilTagsDebugSetTuning(amdAprilTagsHandle handle, int knob, int value) {
-  if (!handle || handle->inflight.active) return AMDAT_INVALID_ARGUMENT;
-  if (knob == 0 && value >= 0 && value <= 3) { handle->fq_start = value; return AMDAT_SUCCESS; }
-  return AMDAT_INVALID_ARGUMENT;
 }
 
 int amdAprilTagsDebugLastSubmissionPath(amdAprilTagsHandle handle) {
@@ -1039,23 +1018,6 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
       // (the longest chain) first.
       // A small submission leaves most of the chip empty either way: its classes below the prefilter start at once on the
       // side streams, beside the prefilter.
-      if (!small && D->fq_start != 0) {
-        // the prefilter on the highest-priority stream with one or all of the classes below it starting beside it: its waves are
-        // placed first, the other kernel's workgroups take what it leaves -- above all its tail
-        HIP_TRY(hipEventRecord(D->ev_fork, s));
-        HIP_TRY(hipStreamWaitEvent(D->hp_stream, D->ev_fork, 0));
-        for (int a = 0; a < FQ_NAUX; a++) HIP_TRY(hipStreamWaitEvent(aux[a], D->ev_fork, 0));
-        launch_prefilter(D->hp_stream);
-        HIP_TRY(hipEventRecord(D->ev_pf, D->hp_stream));
-        // stream of a class: <128> aux[0], <64> aux[1], k_fit_small aux[2] (the empty K = 4 class takes none)
-        auto stream_of = [&](int c) { return c == FQ_C0 + 1 ? aux[0] : c == FQ_C0 ? aux[1] : aux[2]; };
-        auto early = [&](int c) { return D->fq_start == 3 || (D->fq_start == 1 && c < FQ_C0) || (D->fq_start == 2 && c == FQ_C0); };
-        for (int c = pf_first - 1; c >= 0; c--) if (early(c)) launch_class(c, stream_of(c));
-        HIP_TRY(hipStreamWaitEvent(s, D->ev_pf, 0));
-        for (int c = pf_first; c < FQ_NCLS; c++) launch_class(c, s);
-        for (int c = pf_first - 1; c >= 0; c--)
-          if (!early(c)) { HIP_TRY(hipStreamWaitEvent(stream_of(c), D->ev_pf, 0)); launch_class(c, stream_of(c)); }
-      } else {
       if (!small) launch_prefilter(s);
       HIP_TRY(hipEventRecord(D->ev_fork, s));
       for (int a = 0; a < FQ_NAUX; a++) HIP_TRY(hipStreamWaitEvent(aux[a], D->ev_fork, 0));
@@ -1065,7 +1027,6 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
       int a = 0;
       for (int c = pf_first - 1; c >= 0; c--)
         if (launch_class(c, aux[a % FQ_NAUX])) a++;
-      }
     } else {
     if (large_first) {
       launch_class(FQ_C0 + 3, s);

@@ -1397,12 +1397,37 @@ __device__ __forceinline__ void fit_quads_body(const FrameDesc* __restrict__ fra
     double* ea = in_lds ? reinterpret_cast<double*>(skeys) : gerrs_a;
     // (indices wrap with compare/subtract: integer division by a run-time value costs ~40 instructions)
     // (two interleaved fits per trip for instruction-level parallelism measured no gain)
-    for (int i = tid; i < szd; i += NT) {
-      double e;
-      const int i0 = (i >= ksz) ? i - ksz : i - ksz + szd;
-      const int i1 = (i + ksz < szd) ? i + ksz : i + ksz - szd;
-      fit_line_dev(lf, szd, i0, i1, nullptr, &e, nullptr);
-      ea[i] = e;
+    {
+      // The window of point i is rows (i - ksz - 1, i + ksz] of the cumulative moments, around the end for the first and last ksz
+      // points.  fit_line_dev's three cases are one statement once the row before the window reads as zero where the window starts at
+      // point 0 (b - 0.0 is b, bit for bit: every moment is positive) -- inside: b - a; around the end: (total - a) + b -- so a trip
+      // is two row loads whose addresses depend on nothing but i, and the total row is loaded once per cluster instead of once per
+      // wrap-around trip (9.71 -> 9.66 ms for the stage per 256 frames).  Holding the rows of trip k + 1 in registers under the fit of
+      // trip k was measured too: 24 more live doubles took the 64- and 128-thread instances from 17 / 26 to 41 / 58 spilled registers
+      // and the stage to 10.28 ms.
+      double tot[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) tot[j] = lf[(size_t)(szd - 1) * 6 + j];
+      for (int i = tid; i < szd; i += NT) {
+        const int i0 = (i >= ksz) ? i - ksz : i - ksz + szd;
+        const int i1 = (i + ksz < szd) ? i + ksz : i + ksz - szd;
+        const double2* pb = reinterpret_cast<const double2*>(lf + (size_t)i1 * 6);
+        const double2 b0 = pb[0], b1 = pb[1], b2 = pb[2];
+        const double b[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
+        double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (i0 > 0) {
+          const double2* pa = reinterpret_cast<const double2*>(lf + (size_t)(i0 - 1) * 6);
+          const double2 a0 = pa[0], a1 = pa[1], a2 = pa[2];
+          a[0] = a0.x; a[1] = a0.y; a[2] = a1.x; a[3] = a1.y; a[4] = a2.x; a[5] = a2.y;
+        }
+        const bool around = (i < ksz) || (i + ksz >= szd);
+        double m[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) m[j] = around ? (tot[j] - a[j]) + b[j] : b[j] - a[j];
+        double e;
+        fit_line_moments(m[0], m[1], m[2], m[3], m[4], m[5], 2 * ksz + 1, nullptr, &e, nullptr);
+        ea[i] = e;
+      }
     }
     if (tid == 0) { s_ncand = 0; s_nkept = 0; }
     __syncthreads();

@@ -167,9 +167,6 @@ class AprilTagDetector:
         code = {"auto": capi.PATH_AUTO, "latency": capi.PATH_LATENCY, "throughput": capi.PATH_THROUGHPUT}[path] if isinstance(path, str) else int(path)
         capi._check("amdAprilTagsDebugSetSubmissionPath", self._L.amdAprilTagsDebugSetSubmissionPath(self._h, code))
 
-    def set_tuning(self, knob, value):
-        capi._check("amdAprilTagsDebugSetTuning", self._L.amdAprilTagsDebugSetTuning(self._h, int(knob), int(value)))
-
     def last_submission_path(self):
         return {capi.PATH_AUTO: "none", capi.PATH_LATENCY: "latency", capi.PATH_THROUGHPUT: "throughput"}[
             self._L.amdAprilTagsDebugLastSubmissionPath(self._h)]
