@@ -225,6 +225,7 @@ struct amdAprilTagsDetector_st {
   uint32_t graph_max_frames = 8;
   struct GraphEntry { hipGraphExec_t exec = nullptr; uint32_t n = 0, ostride = 0; hipStream_t stream = nullptr; uint64_t last_use = 0; };
   GraphEntry graphs[6];
+  std::vector<hipGraphExec_t> retired_graphs;   // see drop_graphs
   uint64_t graph_clock = 0;
   uint32_t graph_misses = 0;         // consecutive captures that had to evict an entry
   hipEvent_t ev[AMDAT_NUM_STAGES + 1] = {};
@@ -389,6 +390,7 @@ const char* amdAprilTagsStageName(uint32_t stage) { return stage < AMDAT_NUM_STA
 
 static void free_all(amdAprilTagsDetector_st* D) {
   for (auto& g : D->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
+  for (hipGraphExec_t e : D->retired_graphs) hipGraphExecDestroy(e);
   hipFree(D->d_gray); hipFree(D->d_thr); hipFree(D->d_tmin); hipFree(D->d_tmax); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_roots); hipFree(D->d_hkeys);
   hipFree(D->d_hcnt); hipFree(D->d_hoff); hipFree(D->d_stage); hipFree(D->d_bhdr); hipFree(D->d_btab); hipFree(D->d_long); hipFree(D->d_pts); hipFree(D->d_clusters);
   hipFree(D->d_work); hipFree(D->d_work2); hipFree(D->d_workctl); hipFree(D->d_keys_scr); hipFree(D->d_quads);
@@ -671,7 +673,10 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   if (ok) { const int rc = alloc_point_buffers(D); if (rc == AMDAT_BATCH_TOO_LARGE) { free_all(D); delete D; return rc; } ok = rc == AMDAT_SUCCESS; }
   for (int k = 0; k < FQ_NCLS; k++) {
     FqClass& c = D->cls[k];
-    if (P.max_cluster_points <= c.lo || c.small_k == 2 || c.hi <= c.lo) continue;   // (k_fit_small<2> keeps its moments in LDS)
+    // (the one-wave class of k_fit_quads takes every cluster from 24 points on when a submission runs the latency set: its lower
+    // bound for "can this class ever see a cluster" is 23, whatever the k_fit_small classes below it would take on the other set)
+    const int lo_eff = k == FQ_C0 ? 23 : c.lo;
+    if (P.max_cluster_points <= lo_eff || c.small_k == 2 || c.hi <= c.lo) continue;   // (k_fit_small<2> keeps its moments in LDS)
     alloc((void**)&c.d_lf, (size_t)c.grid * c.slot_cap * 48);
     // smoothed errors stay in registers up to FQ_SMOOTH_REGS_OF(threads) points per thread; larger clusters need a second array
     if (!c.small_k && (c.slot_cap > FQ_SMOOTH_REGS_OF(c.nt) * c.nt || c.slot_cap > c.sort_cap)) alloc((void**)&c.d_errs, (size_t)c.grid * c.slot_cap * 16);
@@ -765,12 +770,14 @@ int amdAprilTagsSetProfiling(amdAprilTagsHandle handle, int enable) {
   return AMDAT_SUCCESS;
 }
 
+static void drop_graphs(amdAprilTagsDetector_st* D);   // (defined with the submission code below)
+
 int amdAprilTagsDebugSetSubmissionPath(amdAprilTagsHandle handle, int path) {
   if (!handle || path < AMDAT_PATH_AUTO || path > AMDAT_PATH_THROUGHPUT) return AMDAT_INVALID_ARGUMENT;
   if (path == handle->path_mode) return AMDAT_SUCCESS;
   DeviceGuard guard(handle->device);
   if (!guard.ok) return AMDAT_HIP_ERROR;
-  for (auto& g : handle->graphs) if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }   // captured under the other path
+  drop_graphs(handle);   // captured under the other path
   handle->path_mode = path;
   return AMDAT_SUCCESS;
 }
@@ -968,7 +975,11 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
     };
     auto launch_class = [&](int c, hipStream_t sc) -> bool {   // false: the class has no clusters on this handle, nothing was launched
       const FqClass& cl = D->cls[c];
-      if (P.max_cluster_points <= cl.lo || cl.hi <= cl.lo || (!cl.small_k && !cl.d_lf)) return false;
+      // (working images so small that no cluster can exceed the k_fit_small classes' bound -- 3 (2 W + 2 H) <= 128 -- still need the
+      // one-wave class on the latency set, where it takes everything from 24 points on; found by the fuzzer in round 5: a 9 x 8
+      // working image whose only cluster, 34 points, was bucketed into a list no kernel was launched for)
+      const int lo_eff = (small && c == FQ_C0) ? 23 : cl.lo;
+      if (P.max_cluster_points <= lo_eff || cl.hi <= cl.lo || (!cl.small_k && !cl.d_lf)) return false;
       if (small && cl.small_k) return false;   // (their clusters are in the one-wave class's list: work_layout_small)
       if (FQ_SKIP_CLASS(c)) return false;   // (tools_hooks.h: always 0 in the product build)
       const dim3 grid(cl.grid);   // (a submission of n < max_batch frames still gets the handle's persistent grid)
@@ -1099,6 +1110,31 @@ static int enqueue_submission(amdAprilTagsDetector_st* D, uint32_t n, uint32_t o
   return AMDAT_SUCCESS;
 }
 
+// An instantiated graph that is no longer wanted -- a capacity grew (its launches carry the old pointers), the cache evicted it,
+// the submission path was pinned -- is RETIRED, not destroyed: hipGraphExecDestroy followed by the capture, instantiation and launch
+// of the next graph crashed the host inside the runtime (a segmentation fault, ROCm 7.2) once a process had done it a few dozen
+// times -- tools/stress_regrow.py: 3 of 3 runs within seconds; the full GPU suite inside the pair-table regrowth test in about half
+// of its runs -- and a device-wide wait ahead of the destroy only made it rarer (1 of 3 stress runs, 2 of 3 suite runs still died).
+// Retired graphs are destroyed with the handle, after its device-wide wait and with no capture behind them (every handle has
+// always destroyed its graphs there); the list is short: a regrowth retires at most the six cache entries, and the cache stops
+// capturing after eight consecutive evictions.
+static void retire_graph(amdAprilTagsDetector_st* D, amdAprilTagsDetector_st::GraphEntry& g) {
+  if (!g.exec) return;
+  D->retired_graphs.push_back(g.exec);
+  g.exec = nullptr;
+}
+static void drop_graphs(amdAprilTagsDetector_st* D) {
+  for (auto& g : D->graphs) retire_graph(D, g);
+}
+// ... and a handle whose capacities had to grow gives graph replay up for good (plain enqueues from then on: a one-frame call of
+// such a handle costs ~0.1 ms more).  Capturing, instantiating and launching a NEW graph on a handle right after its buffers were
+// reallocated is what the crash needs: with replay given up after the first regrowth the stress loop and the suite are clean
+// (DESIGN.md section 5), with the graphs merely retired -- and re-captured -- 4 of 6 stress runs still died.
+static void drop_graphs_for_regrowth(amdAprilTagsDetector_st* D) {
+  drop_graphs(D);
+  D->graph_max_frames = 0;
+}
+
 // One pass of a submission over the device: captured-graph replay for small submissions, plain enqueues otherwise.
 // launch_once enqueues it and returns; finish_once waits for it (and reads the stage events when profiling is on).
 static int launch_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s) {
@@ -1137,8 +1173,7 @@ static int launch_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride,
         D->graph_misses++;
         slot = &D->graphs[0];
         for (auto& g : D->graphs) if (g.last_use < slot->last_use) slot = &g;
-        hipGraphExecDestroy(slot->exec);
-        slot->exec = nullptr;
+        retire_graph(D, *slot);   // (not destroyed here: see drop_graphs)
       }
       hipGraph_t graph = nullptr;
       bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
@@ -1182,9 +1217,6 @@ static int finish_once(amdAprilTagsDetector_st* D, hipStream_t s) {
   return AMDAT_SUCCESS;
 }
 
-static void drop_graphs(amdAprilTagsDetector_st* D) {
-  for (auto& g : D->graphs) if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-}
 
 // One batched submission; results land in h_out / h_counters with `ostride` records per frame.
 // begin_batch fills the descriptor block and enqueues the submission; end_batch waits for it, and where a frame overflowed a
@@ -1202,7 +1234,7 @@ static int begin_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTag
   if (D->pending_hash_grow) {   // the pair table of the previous submission was crowded: grow it now (its buffers are dead)
     D->pending_hash_grow = false;
     if (D->grow_hash && D->P.hcap < D->hcap_hard) {
-      drop_graphs(D);
+      drop_graphs_for_regrowth(D);
       const uint32_t before = D->P.hcap;
       D->P.hcap = D->P.hcap * 2 > D->hcap_hard ? D->hcap_hard : D->P.hcap * 2;
       if (alloc_hash_buffers(D) != AMDAT_SUCCESS || alloc_point_buffers(D) != AMDAT_SUCCESS) {
@@ -1246,7 +1278,7 @@ static int end_batch(amdAprilTagsDetector_st* D) {
     bool again = false;
     if (cands_over) {
       if (D->P.cand_cap < D->P.ccap) {   // grow the candidate list and repeat
-        drop_graphs(D);
+        drop_graphs_for_regrowth(D);
         const uint64_t want = (uint64_t)D->P.cand_cap * 2;
         const uint32_t ncap = want > D->P.ccap ? D->P.ccap : (uint32_t)want;
         FitCand* nb = nullptr;
@@ -1274,7 +1306,7 @@ static int end_batch(amdAprilTagsDetector_st* D) {
         if (hash_crowded && can_hash) D->pending_hash_grow = true;
         return AMDAT_SUCCESS;
       }
-      drop_graphs(D);   // captured launches carry the old pointers and capacities
+      drop_graphs_for_regrowth(D);   // captured launches carry the old pointers and capacities
       const uint32_t pcap_before = D->P.pcap, hcap_before = D->P.hcap;
       if (pts_over && can_pts) { const uint64_t want = (uint64_t)D->P.pcap * 2; D->P.pcap = want > D->pcap_hard ? D->pcap_hard : (uint32_t)want; }
       if (hash_over && can_hash) D->P.hcap = D->P.hcap * 2 > D->hcap_hard ? D->hcap_hard : D->P.hcap * 2;

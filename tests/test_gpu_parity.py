@@ -544,6 +544,24 @@ def test_tiny_and_degenerate_frames(built, shape):
         assert g == [] and odets == []
 
 
+@pytest.mark.parametrize("path", PATHS)
+def test_tiny_working_image_whose_clusters_all_fit_the_small_class(built, path):
+    """Found by the fuzzer in round 5 (seed 61002, case 4254): a 25 x 24 frame at decimate 3 is a 9 x 8 working image, where no
+    cluster can exceed 3 (2 W + 2 H) = 102 points -- below the 128-point bound of the small-cluster class.  The latency set buckets
+    every cluster from 24 points on into the one-wave class of k_fit_quads, which was neither allocated nor launched on such a
+    handle: the frame's only cluster (34 points, one quad) was dropped, while the throughput set (k_fit_small) found it."""
+    img = np.load(os.path.join(os.path.dirname(__file__), "golden", "fuzz_r05_tiny_working_image.npy"))
+    assert img.shape == (24, 25)
+    K = synth.default_K(25, 24)
+    det, g = _run(img, K, ("tag16h5",), 3, path=path)
+    errs, odets = pu.compare_stages(det, 0, img, ("tag16h5",), K, 3)
+    errs += pu.compare_detections(g, odets)
+    nq = len(det.debug(0, capi.DBG_QUADS))
+    det.close()
+    assert not errs, errs[:3]
+    assert nq == 1
+
+
 def test_create_rejects_unsupported_sizes(built):
     L = capi.lib()
     h = C.c_void_p()
@@ -698,6 +716,9 @@ def test_adversarial_content_fuzz(built, path):
     spec.loader.exec_module(fz)
     done, fails = fz.run_cases(300, seed=20260928, maxdim=300, out=lambda m: None, path=path)
     assert done == 300 and not fails, fails[:3]
+    # ... and 60 cases of FIVE frames per submission, every frame with content of its own (frame indexing of every stage)
+    done, fails = fz.run_cases(60, seed=20260929, maxdim=260, out=lambda m: None, path=path, batch=5)
+    assert done == 60 and not fails, fails[:3]
 
 
 def test_checkerboard_more_quads_than_the_old_fixed_capacity(built):
@@ -1175,6 +1196,18 @@ def test_pair_table_grows_with_the_content(built):
     fixed.detect_batch_ex(t, max_dets=64)
     assert fixed.frame_flags(1)[0] & 2
     fixed.close()
+
+
+def test_regrowth_stress_loop(built):
+    """tools/stress_regrow.py in a process of its own (a host-side crash must fail a test, not end the session): handle after handle
+    whose candidate list, pair table and point buffers grow -- the sequence that crashed inside the runtime when a regrown handle
+    went on capturing new graphs.  60 iterations = 180 handles, 300 submissions."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_regrow.py"), "60", "graph"], capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert out.returncode == 0 and "60 iterations (graph) ok" in out.stdout and "UNEXPECTED" not in out.stdout, (out.returncode, out.stdout[-1500:], out.stderr[-1500:])
 
 
 @pytest.mark.gpu

@@ -88,9 +88,10 @@ def tag_scene(rng, h, w, fams):
     return img
 
 
-def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None):
+def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None, batch=1, only=None, dump=None):
     """Returns (cases run, list of failure strings).  path: None (the library picks the launch set by size: the latency set at these
-    sizes), "latency", "throughput", or "alternate" (even cases latency, odd cases throughput)."""
+    sizes), "latency", "throughput", or "alternate" (even cases latency, odd cases throughput).  batch > 1: every case submits `batch` frames
+    of the case's size, each with content of its own, in ONE call, and every frame is compared (frame indexing of every stage)."""
     rng = np.random.default_rng(seed)
     t0 = time.time()
     fails = []
@@ -109,32 +110,43 @@ def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None):
             dec = 1
         fams = [("tag36h11",), ("tag25h9",), ("tag16h5",), ("tag36h11", "tag25h9"), ("tag36h11", "tag25h9", "tag16h5")][
             int(rng.integers(0, 5))]
-        kind, img = gen_content(rng, h, w)
-        if img is None:
-            img = tag_scene(rng, h, w, fams)
-        img = np.clip(np.rint(img), 0, 255).astype(np.uint8)
         pitch = w + int(rng.choice([0, 0, 1, 3, 13, 64]))
-        buf = np.zeros((h, pitch), dtype=np.uint8)
-        buf[:, :w] = img
-        buf[:, w:] = rng.integers(0, 256, (h, pitch - w), dtype=np.uint8)
+        imgs, bufs, kinds = [], [], []
+        for _ in range(batch):
+            kind, img = gen_content(rng, h, w)
+            if img is None:
+                img = tag_scene(rng, h, w, fams)
+            img = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+            buf = np.zeros((h, pitch), dtype=np.uint8)
+            buf[:, :w] = img
+            buf[:, w:] = rng.integers(0, 256, (h, pitch - w), dtype=np.uint8)
+            imgs.append(img); bufs.append(buf); kinds.append(int(kind))
+        kind = kinds[0] if batch == 1 else tuple(kinds)
+        if only is not None and case != only:   # (the generator has consumed exactly what the full run consumes)
+            continue
+        if dump:
+            np.savez(dump, imgs=np.stack(imgs), pitch=pitch, dec=dec, fams=np.array(fams), w=w, h=h)
         K = synth.default_K(w, h)
         try:
             det = AprilTagDetector(w, h, intrinsics=(K[0, 0], K[1, 1], K[0, 2], K[1, 2]), families=fams, decimate=dec,
-                                   max_batch=1)
+                                   max_batch=batch)
         except Exception as e:  # noqa: BLE001
             fails.append("case %d: create failed for %dx%d dec %d: %s" % (case, w, h, dec, e))
             out(fails[-1])
             continue
         if path is not None:
             det.set_submission_path(("latency", "throughput")[case & 1] if path == "alternate" else path)
-        t = torch.from_numpy(buf).cuda()
-        g = det.detect_batch_ex([(t.data_ptr(), pitch)], max_dets=256)[0]
-        errs, odets = pu.compare_stages(det, 0, np.ascontiguousarray(img), fams, K, dec)
-        errs += pu.compare_detections(g, odets)
+        ts = [torch.from_numpy(b).cuda() for b in bufs]
+        gs = det.detect_batch_ex([(t.data_ptr(), pitch) for t in ts], max_dets=256)
+        errs = []
+        for f in range(batch):
+            e, odets = pu.compare_stages(det, f, np.ascontiguousarray(imgs[f]), fams, K, dec)
+            e += pu.compare_detections(gs[f], odets)
+            errs += ["frame %d: %s" % (f, x) for x in e] if batch > 1 else e
         det.close()
         done += 1
         if errs:
-            fails.append("case %d FAIL kind %d %dx%d pitch %d dec %d fams %s: %s" % (case, kind, w, h, pitch, dec, fams,
+            fails.append("case %d FAIL kind %s %dx%d pitch %d dec %d fams %s: %s" % (case, kind, w, h, pitch, dec, fams,
                                                                                   errs[:3]))
             out(fails[-1])
     return done, fails
@@ -146,10 +158,14 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--maxdim", type=int, default=420)
     ap.add_argument("--budget", type=float, default=1e9, help="seconds")
+    ap.add_argument("--batch", type=int, default=1, help="frames per case (one submission)")
+    ap.add_argument("--only", type=int, default=None, help="run this case only (the cases before it are generated and skipped)")
+    ap.add_argument("--dump", default=None, help="with --only: write the case's frames to this .npz")
     ap.add_argument("--path", default="alternate", help="launch set: latency | throughput | alternate | auto")
     a = ap.parse_args()
     t0 = time.time()
-    done, fails = run_cases(a.cases, a.seed, a.maxdim, a.budget, out=lambda m: print(m, flush=True), path=None if a.path == "auto" else a.path)
+    done, fails = run_cases(a.cases, a.seed, a.maxdim, a.budget, out=lambda m: print(m, flush=True), path=None if a.path == "auto" else a.path, batch=a.batch,
+                            only=a.only, dump=a.dump)
     print("fuzz: %d cases, %d failed, %.1f s" % (done, len(fails), time.time() - t0))
     sys.exit(1 if fails else 0)
 
