@@ -39,6 +39,9 @@ int amdAprilTagsThresholdOnly(amdAprilTagsHandle handle, uint32_t n, const amdAp
 int amdAprilTagsDebugSetSubmissionPath(amdAprilTagsHandle handle, int path);
 /* AMDAT_PATH_LATENCY or AMDAT_PATH_THROUGHPUT: the set the handle's last submission ran (AMDAT_PATH_AUTO before the first). */
 int amdAprilTagsDebugLastSubmissionPath(amdAprilTagsHandle handle);
+/* Launches of this handle whose stream wait returned before their results were there (every launch's counters carry its sequence
+ * number; the library then waits for the whole device and checks again): 0 on a healthy runtime. */
+int amdAprilTagsDebugLateWaits(amdAprilTagsHandle handle);
 
 /* ---- stage inspection (parity tests) ------------------------------------------------------ */
 typedef enum {

@@ -63,7 +63,7 @@ EXPORTS = ["amdAprilTagsDefaultConfig", "amdCreateAprilTagsDetector", "amdCreate
            "amdAprilTagsSetProfiling", "amdAprilTagsGetStageMs", "amdAprilTagsThresholdOnly",
            "amdAprilTagsDebugCopy", "amdAprilTagsDebugMath", "amdAprilTagsDeviceAlloc", "amdAprilTagsDeviceFree",
            "amdAprilTagsCopyToDevice", "amdAprilTagsResizeMono8", "amdAprilTagsRectifyMono8",
-           "amdAprilTagsGetDeviceBytes", "amdAprilTagsDebugSetSubmissionPath", "amdAprilTagsDebugLastSubmissionPath"]
+           "amdAprilTagsGetDeviceBytes", "amdAprilTagsDebugSetSubmissionPath", "amdAprilTagsDebugLastSubmissionPath", "amdAprilTagsDebugLateWaits"]
 PATH_AUTO, PATH_LATENCY, PATH_THROUGHPUT = 0, 1, 2
 
 _lib = None
@@ -120,6 +120,7 @@ def lib():
     L.amdAprilTagsGetDeviceBytes.argtypes = [H, C.POINTER(C.c_size_t)]
     L.amdAprilTagsDebugSetSubmissionPath.argtypes = [H, C.c_int]
     L.amdAprilTagsDebugLastSubmissionPath.argtypes = [H]
+    L.amdAprilTagsDebugLateWaits.argtypes = [H]
     L.amdAprilTagsDebugMath.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     for name in EXPORTS:
         fn = getattr(L, name)

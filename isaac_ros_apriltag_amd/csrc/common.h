@@ -19,7 +19,7 @@
 struct FrameDesc {
   const uint8_t* img;  // mono8, full resolution
   uint32_t pitch;
-  uint32_t pad;
+  uint32_t seq;        // number of the launch this descriptor was written for (the handle's counter): comes back in FrameCounters::seq
   double fx, fy, cx, cy;
   double skew;
 };
@@ -36,6 +36,8 @@ struct FrameCounters {
   uint32_t nroots;        // tile-local component roots (CC root list)
   uint32_t ncand;         // quad candidates (four fitted lines) awaiting k_quad_finish
   uint32_t nlong;         // long staging records (k_points -> k_scatter)
+  uint32_t seq;           // FrameDesc::seq of the launch that produced these counters, written last (k_reconcile): the host checks it
+                          // after its stream wait, so results of an EARLIER launch can never be taken for this one's
 };
 
 struct ClusterRec {

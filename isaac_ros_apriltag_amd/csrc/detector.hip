@@ -234,6 +234,9 @@ struct amdAprilTagsDetector_st {
   bool events_recorded = false;      // the submission in flight recorded the stage events (profiling on, no graph replay)
   struct { bool active = false; uint32_t n = 0, ostride = 0, max_out = 0; hipStream_t stream = nullptr; } inflight;   // amdAprilTagsSubmitBatch .. WaitBatch
   std::vector<float> frame_skew;     // per batch slot, amdAprilTagsSetFrameSkews; empty: cfg.skew for every frame
+  uint32_t launched_n = 0;
+  uint32_t seq = 0;                  // launch counter: travels through the descriptor block and comes back with the counters
+  uint32_t late_waits = 0;           // launches whose stream wait returned before their results (finish_once); amdAprilTagsDebugLateWaits
   int path_mode = AMDAT_PATH_AUTO;
   int last_path = AMDAT_PATH_AUTO;   // the set the last submission ran (amdAprilTagsDebugLastSubmissionPath)
   float stage_ms[AMDAT_NUM_STAGES] = {};
@@ -782,6 +785,8 @@ int amdAprilTagsDebugSetSubmissionPath(amdAprilTagsHandle handle, int path) {
   return AMDAT_SUCCESS;
 }
 
+int amdAprilTagsDebugLateWaits(amdAprilTagsHandle handle) { return handle ? (int)handle->late_waits : -1; }
+
 int amdAprilTagsDebugLastSubmissionPath(amdAprilTagsHandle handle) {
   return handle ? handle->last_path : -1;
 }
@@ -810,7 +815,7 @@ static void fill_frames(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTa
     const amdAprilTagsCameraIntrinsics_t& k = intr ? intr[i] : D->cfg.intrinsics;
     D->h_frames[i].img = images[i].dev_ptr;
     D->h_frames[i].pitch = (uint32_t)images[i].pitch;
-    D->h_frames[i].pad = 0;
+    D->h_frames[i].seq = D->seq;
     D->h_frames[i].fx = (double)k.fx; D->h_frames[i].fy = (double)k.fy;
     D->h_frames[i].cx = (double)k.cx; D->h_frames[i].cy = (double)k.cy;
     D->h_frames[i].skew = (double)(i < D->frame_skew.size() ? D->frame_skew[i] : D->cfg.skew);
@@ -1138,6 +1143,9 @@ static void drop_graphs_for_regrowth(amdAprilTagsDetector_st* D) {
 // One pass of a submission over the device: captured-graph replay for small submissions, plain enqueues otherwise.
 // launch_once enqueues it and returns; finish_once waits for it (and reads the stage events when profiling is on).
 static int launch_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s) {
+  D->seq++;
+  for (uint32_t i = 0; i < n; i++) D->h_frames[i].seq = D->seq;   // (k_prologue reads the pinned block when the launch executes)
+  D->launched_n = n;
   const bool prof = D->profiling;
   D->events_recorded = false;
   int evi = 0;
@@ -1207,6 +1215,23 @@ static int launch_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride,
 
 static int finish_once(amdAprilTagsDetector_st* D, hipStream_t s) {
   HIP_TRY(hipStreamSynchronize(s));
+  // The counters the host is about to act on must be THIS launch's: k_reconcile stamps them with the descriptor's sequence number
+  // as its last store.  (The regrowth stress loop once ended with a handle that had not grown -- counters read before they were
+  // final, under graph replay on ROCm 7.2.)  A mismatch waits for the whole device and looks again; if the results still are not
+  // there the call fails instead of handing out an earlier launch's records.
+  auto stamped = [&]() {
+    for (uint32_t f = 0; f < D->launched_n; f++)
+      if (reinterpret_cast<volatile FrameCounters*>(D->h_counters)[f].seq != D->seq) return false;
+    return true;
+  };
+  if (!stamped()) {
+    D->late_waits++;
+    HIP_TRY(hipDeviceSynchronize());
+    if (!stamped()) {
+      fprintf(stderr, "[apriltag_amd] launch %u: results missing after a device-wide wait\n", D->seq);
+      return AMDAT_HIP_ERROR;
+    }
+  }
   if (D->events_recorded) {
     for (int i = 0; i < AMDAT_NUM_STAGES; i++) {
       float ms = 0;

@@ -201,5 +201,8 @@ __global__ __launch_bounds__(64) void k_reconcile(const FrameDesc* __restrict__ 
     if (!host_out) out[i] = d;
     else if (i < host_stride) host_out[(size_t)frame * host_stride + i] = d;
   }
-  if (host_out && threadIdx.x == 0) host_counters[frame] = counters[frame];   // (this block wrote the last field, nout, itself)
+  if (threadIdx.x == 0) {
+    counters[frame].seq = fd.seq;
+    if (host_out) host_counters[frame] = counters[frame];   // (this block wrote the last fields, nout and seq, itself)
+  }
 }

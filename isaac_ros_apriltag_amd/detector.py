@@ -167,6 +167,9 @@ class AprilTagDetector:
         code = {"auto": capi.PATH_AUTO, "latency": capi.PATH_LATENCY, "throughput": capi.PATH_THROUGHPUT}[path] if isinstance(path, str) else int(path)
         capi._check("amdAprilTagsDebugSetSubmissionPath", self._L.amdAprilTagsDebugSetSubmissionPath(self._h, code))
 
+    def late_waits(self):
+        return int(self._L.amdAprilTagsDebugLateWaits(self._h))
+
     def last_submission_path(self):
         return {capi.PATH_AUTO: "none", capi.PATH_LATENCY: "latency", capi.PATH_THROUGHPUT: "throughput"}[
             self._L.amdAprilTagsDebugLastSubmissionPath(self._h)]

@@ -22,6 +22,7 @@ t = torch.from_numpy(img).cuda()
 ts = torch.from_numpy(np.ascontiguousarray(stripes)).cuda()
 other = torch.from_numpy(synth.scene_c1()[0]).cuda()
 ref = None
+late = 0
 for it in range(iters):
     det = AprilTagDetector(w, h, intrinsics=(K[0, 0], K[1, 1], K[0, 2], K[1, 2]), max_batch=1)
     if mode == "nograph":
@@ -47,6 +48,7 @@ for it in range(iters):
         ref = cnt
     if cnt != ref:
         print("UNEXPECTED it %d: counts %s vs %s" % (it, cnt, ref), flush=True)
+    late += det.late_waits()
     det.close()
     d2 = AprilTagDetector(640, 480, max_batch=1)     # point buffers grow, submission repeated
     if mode == "nograph":
@@ -55,9 +57,11 @@ for it in range(iters):
     d2.detect_batch_ex(ts, max_dets=64)
     if d2.frame_flags(1) != [0]:
         print("UNEXPECTED it %d: stripes flags %s" % (it, d2.frame_flags(1)), flush=True)
+    late += d2.late_waits()
     d2.close()
     d3 = AprilTagDetector(640, 480, decimate=2, max_batch=1)   # an ordinary handle in between
     step("plain")
     d3.detect_batch_ex(other, max_dets=64)
+    late += d3.late_waits()
     d3.close()
-print("stress_regrow: %d iterations (%s) ok, counts %s" % (iters, mode, ref))
+print("stress_regrow: %d iterations (%s) ok, counts %s, late stream waits %d" % (iters, mode, ref, late))
