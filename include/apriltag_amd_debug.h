@@ -29,10 +29,10 @@ int amdAprilTagsThresholdOnly(amdAprilTagsHandle handle, uint32_t n, const amdAp
 
 /* Which launch set a submission gets.  The library picks it from the submission's size: up to eight 1080p frames' worth of
  * working pixels take the LATENCY set (k_cc_local<16>, every small cluster in the one-wave class of k_fit_quads, no
- * k_fit_small, CU-wide prefilter, one select chunk, captured-graph replay, results written to the host by k_reconcile); above
- * that the THROUGHPUT set (k_cc_local<4>, k_fit_small<2> for clusters up to 128 points, per-wave prefilter, chunked select,
- * copy commands).  Results never depend on it.  The parity tests pin it so that BOTH sets are compared with the oracle stage
- * by stage at any frame count (a one-frame submission on the THROUGHPUT set; a 12-frame one on the LATENCY set). */
+ * k_fit_small, CU-wide prefilter, one select chunk, captured-graph replay); above that the THROUGHPUT set (k_cc_local<4>,
+ * k_fit_small<2> for clusters up to 128 points, per-wave prefilter, chunked select).  Results never depend on it.  The parity
+ * tests pin it so that BOTH sets are compared with the oracle stage by stage at any frame count (a one-frame submission on the
+ * THROUGHPUT set; a 12-frame one on the LATENCY set). */
 #define AMDAT_PATH_AUTO 0
 #define AMDAT_PATH_LATENCY 1
 #define AMDAT_PATH_THROUGHPUT 2

@@ -191,7 +191,6 @@ struct amdAprilTagsDetector_st {
   unsigned long long* d_keys_scr = nullptr;  // only when a cluster can exceed the LDS key array (large images)
   QuadRec* d_quads = nullptr;
   DetRec* d_dets = nullptr;
-  DetRec* d_out = nullptr;
   uint16_t* d_order = nullptr;
   FitCand* d_cands = nullptr;        // quad candidates of k_fit_quads (four lines each), consumed by k_quad_finish
   FrameCounters* d_counters = nullptr;
@@ -399,7 +398,7 @@ static void free_all(amdAprilTagsDetector_st* D) {
   hipFree(D->d_work); hipFree(D->d_work2); hipFree(D->d_workctl); hipFree(D->d_keys_scr); hipFree(D->d_quads);
   for (auto& c : D->cls) { hipFree(c.d_lf); hipFree(c.d_errs); }
   hipFree(D->d_fqprof);
-  hipFree(D->d_cands); hipFree(D->d_dets); hipFree(D->d_out); hipFree(D->d_order); hipFree(D->d_frames);   // (d_counters lives behind d_workctl)
+  hipFree(D->d_cands); hipFree(D->d_dets); hipFree(D->d_order); hipFree(D->d_frames);   // (d_counters lives behind d_workctl)
   for (int i = 0; i < AT_MAX_FAMILIES; i++) hipFree(D->d_codes[i]);
   if (D->h_frames) hipHostFree(D->h_frames);
   if (D->h_counters) hipHostFree(D->h_counters);
@@ -694,7 +693,6 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   alloc((void**)&D->d_cands, B * (size_t)P.cand_cap * sizeof(FitCand));
   D->cands_bytes = B * (size_t)P.cand_cap * sizeof(FitCand);
   alloc((void**)&D->d_dets, B * (size_t)P.dcap * sizeof(DetRec));
-  alloc((void**)&D->d_out, B * (size_t)P.dcap * sizeof(DetRec));
   alloc((void**)&D->d_order, B * (size_t)P.dcap * 2);
   // work-list control words and frame counters share one allocation, cleared by ONE fill per submission
   alloc((void**)&D->d_workctl, 32 * 4 + B * sizeof(FrameCounters));
@@ -867,9 +865,9 @@ __global__ __launch_bounds__(64) void k_prologue(const uint32_t* __restrict__ ho
   if (frame == 0 && t < 32) workctl[t] = 0u;
 }
 
-// Small submissions let k_reconcile write results and counters into the pinned host buffers itself (see there); large
-// ones keep the two copy commands (megabytes over PCIe are the copy engines' job).
-static inline bool direct_results(const amdAprilTagsDetector_st* D, uint32_t n) { return n <= 8 && D->path_mode != AMDAT_PATH_THROUGHPUT; }
+// k_reconcile writes every frame's records and counters straight into the pinned host buffers the API call reads: no copy commands
+// after the last kernel (about 10 us of a one-frame call; at 256 frames the strided 3.8 MB copy of mostly empty record slots cost
+// 0.08 ms per step against the ~0.6 MB of real records the kernel writes: 17.85 -> 17.77 ms).
 
 // A small submission (the node's one-frame calls, up to eight 1080p frames) is about latency, not throughput: every cluster
 // is a workgroup's only one, the stage ends with its longest chain, and a launch more costs more than k_fit_small's shorter
@@ -1081,9 +1079,8 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
   }
   mark();
   {
-    const bool direct = direct_results(D, n);
-    hipLaunchKernelGGL(k_reconcile, dim3(n), dim3(64), 0, s, D->d_frames, D->d_dets, D->d_out, D->d_counters, D->d_order,
-                       direct ? D->h_out : nullptr, ostride, D->h_counters, P);
+    hipLaunchKernelGGL(k_reconcile, dim3(n), dim3(64), 0, s, D->d_frames, D->d_dets, D->d_counters, D->d_order, D->h_out, ostride,
+                       D->h_counters, P);
   }
   mark();
   return AMDAT_SUCCESS;
@@ -1092,7 +1089,6 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
 // Everything one submission enqueues on stream s (and the auxiliary streams forked from it): descriptor upload, clears,
 // the stage sequence, result download.  No host synchronisation inside, so the sequence can be stream-captured.
 static int enqueue_submission(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s, const std::function<void()>& mark) {
-  const DetParams& P = D->P;
   mark();
   // descriptor upload + clears in one small kernel (it reads the pinned descriptor block over the bus itself): a copy
   // command and a fill command ahead of the first kernel cost a one-frame call about 15 us, this launch 4
@@ -1105,11 +1101,6 @@ static int enqueue_submission(amdAprilTagsDetector_st* D, uint32_t n, uint32_t o
   {
     const int rc = issue_pipeline(D, n, ostride, s, mark);
     if (rc) return rc;
-  }
-  if (!direct_results(D, n)) {
-    HIP_TRY(hipMemcpyAsync(D->h_counters, D->d_counters, n * sizeof(FrameCounters), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpy2DAsync(D->h_out, (size_t)ostride * sizeof(DetRec), D->d_out, (size_t)P.dcap * sizeof(DetRec),
-                             (size_t)ostride * sizeof(DetRec), n, hipMemcpyDeviceToHost, s));
   }
   mark();
   return AMDAT_SUCCESS;

@@ -150,17 +150,15 @@ __device__ void pose_from_homography_dev(const double* H, double fx_in, double f
 
 // one 64-thread block per frame; lane 0 orders and reconciles (tens of records), all lanes copy
 __global__ __launch_bounds__(64) void k_reconcile(const FrameDesc* __restrict__ frames, const DetRec* __restrict__ dets_all,
-                                                  DetRec* __restrict__ out_all, FrameCounters* __restrict__ counters,
+                                                  FrameCounters* __restrict__ counters,
                                                   uint16_t* __restrict__ order_all, DetRec* __restrict__ host_out,
                                                   uint32_t host_stride, FrameCounters* __restrict__ host_counters, DetParams P) {
-  // host_out != nullptr (small submissions): the kept records and the frame's counters go straight to the pinned host
-  // buffers the API call reads -- `host_stride` records per frame -- instead of to device buffers that two copy commands
-  // would move afterwards (about 10 us of a one-frame call)
+  // the kept records and the frame's counters go straight to the pinned host buffers the API call reads -- `host_stride` records
+  // per frame -- instead of to device buffers that two copy commands would move afterwards
   const int frame = (int)blockIdx.x + P.frame0;
   uint32_t nd = counters[frame].ndets;
   if (nd > P.dcap) nd = P.dcap;
   const DetRec* dets = dets_all + (size_t)frame * P.dcap;
-  DetRec* out = out_all + (size_t)frame * P.dcap;
   uint16_t* order = order_all + (size_t)frame * P.dcap;
   __shared__ uint32_t s_nout;
   // rank sort by the canonical preference order: every lane counts the records that precede its own
@@ -198,11 +196,10 @@ __global__ __launch_bounds__(64) void k_reconcile(const FrameDesc* __restrict__ 
   for (uint32_t i = threadIdx.x; i < nk; i += 64) {
     DetRec d = dets[order[i]];
     pose_from_homography_dev(d.H, fd.fx, fd.fy, fd.cx, fd.cy, fd.skew, P.tag_size, d.R, d.t);
-    if (!host_out) out[i] = d;
-    else if (i < host_stride) host_out[(size_t)frame * host_stride + i] = d;
+    if (i < host_stride) host_out[(size_t)frame * host_stride + i] = d;
   }
   if (threadIdx.x == 0) {
     counters[frame].seq = fd.seq;
-    if (host_out) host_counters[frame] = counters[frame];   // (this block wrote the last fields, nout and seq, itself)
+    host_counters[frame] = counters[frame];   // (this block wrote the last fields, nout and seq, itself)
   }
 }
