@@ -16,8 +16,12 @@
  *     first with amdAprilTagsConvertToMono8 (stands in for vpiSubmitConvertImageFormat,
  *     src/apriltag_node.cpp:275-282; accepted encodings = the table at :76-82);
  *   - a batched entry point (amdAprilTagsDetectBatch) processes independent frames in one
- *     submission; a HIP stream replaces the CUDA stream;
- *   - more than one tag family can be enabled (amdCreateAprilTagsDetectorEx).
+ *     submission -- also in two halves, amdAprilTagsSubmitBatch / amdAprilTagsWaitBatch, so that a host
+ *     overlaps its next host-to-device copy with the detection; a HIP stream replaces the CUDA stream;
+ *   - more than one tag family can be enabled (amdCreateAprilTagsDetectorEx); tile_size is the
+ *     reference's parameter (src/apriltag_node.cpp:566, handed over at :451): 4 or 8;
+ *   - the skew K[0][1] of the reference's VPI path (src/apriltag_node.cpp:215-225) is a field of the
+ *     configuration and, per frame of a batch, amdAprilTagsSetFrameSkews.
  * Ownership and threading follow the reference's use: the caller owns the input buffers and the
  * output arrays (host memory); the library owns everything behind the handle; one thread per handle;
  * every Detect call is host-synchronous (results valid on return).  All functions return 0 on
