@@ -488,6 +488,57 @@ def extra_measurements(det, batch, frames_np, intr, args, torch, dev, tag_size, 
         sweep[str(b)] = {"fps_median": round(b / float(np.median(ts)), 1), "ms_median": round(float(np.median(ts)) * 1e3, 3),
                          "ms_min": round(float(np.min(ts)) * 1e3, 3)}
     ex["batch_sweep"] = sweep
+    # the reference's own input format (its cuAprilTags branch takes rgb8 / bgr8 uchar3 frames, src/apriltag_node.cpp:469-486): the
+    # same B frames as bgr8 -- the gray value in all three channels, so that the BT.601 statement gives the mono8 frame back exactly
+    # and the records must equal the mono8 run's -- through amdAprilTagsDetectBatchColorEx, whose threshold pass reads the interleaved
+    # frame, writes the gray plane and thresholds in one launch: 3 N read + 2 N written per frame
+    if args.decimate == 1:
+        try:
+            bgr = batch.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
+            pm = det.prepare(batch, max_dets=64, intrinsics=intr)
+            det.run_prepared(pm)
+            ref = det.unpack(pm)
+            pc = det.prepare(bgr, max_dets=64, intrinsics=intr, encoding="bgr8")
+            det.run_prepared(pc)
+            got = det.unpack(pc)
+            same = len(ref) == len(got) and all(len(a) == len(b) and all(x["id"] == y["id"] and np.array_equal(x["p"], y["p"]) and np.array_equal(x["R"], y["R"])
+                                                                       for x, y in zip(a, b)) for a, b in zip(ref, got))
+            tm, tc = [], []
+            for _ in range(5):
+                t = time.perf_counter(); det.run_prepared(pm); tm.append(time.perf_counter() - t)
+                t = time.perf_counter(); det.run_prepared(pc); tc.append(time.perf_counter() - t)
+            det.set_profiling(True)
+            det.run_prepared(pc)
+            thr_ms = det.stage_ms()["threshold"]
+            det.set_profiling(False)
+            N = float(W * H)
+            gbs = 5.0 * N * B / (thr_ms * 1e-3) / 1e9
+            row = {"fps_median": round(B / float(np.median(tc)), 1), "ms_median": round(float(np.median(tc)) * 1e3, 3),
+                   "mono8_ms_median_same_loop": round(float(np.median(tm)) * 1e3, 3),
+                   "vs_mono8": round(float(np.median(tm)) / float(np.median(tc)), 4), "records_equal_mono8_run": bool(same),
+                   "threshold_pass_in_pipeline": {"kernel": "k_threshold<1, bgr8>", "ms": round(thr_ms, 4), "alg_bytes_per_frame": int(5 * N),
+                                                  "GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4)}}
+            del bgr, pc
+            # the colour threshold launch alone, 160 frames per launch like the mono8 roofline measurement (995 MB in, 663 MB out)
+            nb = 160
+            big = batch.repeat(int(np.ceil(nb / B)), 1, 1)[:nb].unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
+            dt = AprilTagDetector(W, H, max_batch=nb, max_points=4096, hash_slots=256, max_clusters=256, max_quads=64, max_detections=16,
+                                  device=dev_index)
+            dt.set_profiling(True)
+            for _ in range(3):
+                dt.threshold_only(big, encoding="bgr8")
+            ms = []
+            for _ in range(12):
+                dt.threshold_only(big, encoding="bgr8")
+                ms.append(dt.stage_ms()["threshold"])
+            dt.close()
+            del big
+            g2 = 5.0 * N * nb / (float(np.mean(ms)) * 1e-3) / 1e9
+            row["threshold_pass_alone"] = {"frames_per_launch": nb, "avg_launch_ms": round(float(np.mean(ms)), 4), "min_launch_ms": round(float(np.min(ms)), 4),
+                                           "bytes_per_launch": 5.0 * N * nb, "GB/s": round(g2, 1), "frac_of_8TBs": round(g2 / HBM_PEAK_GBS, 4)}
+            ex["bgr8_input"] = row
+        except Exception as e:   # (informational row: never in the way of the line)
+            ex["bgr8_input"] = {"error": repr(e)[:300]}
     # H2D-included: the same B frames start in pinned host memory every step.  (a) serial: copy, then detect;
     # (b) double-buffered: the copy of step k+1 runs on a side stream while the blocking call of step k computes
     host = torch.from_numpy(frames_np).pin_memory()

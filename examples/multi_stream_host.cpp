@@ -10,7 +10,13 @@
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude examples/multi_stream_host.cpp \
 //         -Lisaac_ros_apriltag_amd -lapriltag_amd -lrccl -Wl,-rpath,$PWD/isaac_ros_apriltag_amd -o examples/multi_stream_host
 //   python tools/dump_streams.py streams.bin            # frames + per-stream parameters (same generator as bench.py)
-//   ./examples/multi_stream_host streams.bin [gpus] [steps] [--host-frames]
+//   ./examples/multi_stream_host streams.bin [gpus] [steps] [--host-frames] [--shared-gpu]
+//
+// --shared-gpu: the G "GPUs" are G ranks on device 0 -- G worker threads, G handles (each with its own streams, side streams and
+// pinned blocks), G communicator ranks -- so that a one-GPU box exercises what the 8-GPU run relies on inside the library: the
+// family registry's lock, the device guard of every entry point, eight handles' launch sequences side by side on one device.
+// RCCL refuses a communicator with one device twice; the flag then (and only then) replaces the broadcast by a device-to-device
+// fan-out of the same block from rank 0's copy, and the JSON line says which of the two ran.
 //
 // --host-frames: the frames start in (pinned) HOST memory every step, as they do behind a camera driver.  Every GPU's thread
 // double-buffers: amdAprilTagsSubmitBatch on buffer A returns at once, the next step's frames are copied into buffer B on a
@@ -63,10 +69,12 @@ static uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
 }
 
 int main(int argc, char** argv) {
-  if (argc < 2) { fprintf(stderr, "usage: %s streams.bin [gpus] [steps] [--host-frames]\n", argv[0]); return 2; }
-  bool host_frames = false;
-  for (int i = 2; i < argc; i++)
-    if (!strcmp(argv[i], "--host-frames")) { host_frames = true; for (int j = i; j + 1 < argc; j++) argv[j] = argv[j + 1]; argc--; i--; }
+  if (argc < 2) { fprintf(stderr, "usage: %s streams.bin [gpus] [steps] [--host-frames] [--shared-gpu]\n", argv[0]); return 2; }
+  bool host_frames = false, shared_gpu = false;
+  for (int i = 2; i < argc; i++) {
+    const bool hf = !strcmp(argv[i], "--host-frames"), sg = !strcmp(argv[i], "--shared-gpu");
+    if (hf || sg) { host_frames |= hf; shared_gpu |= sg; for (int j = i; j + 1 < argc; j++) argv[j] = argv[j + 1]; argc--; i--; }
+  }
   FILE* f = fopen(argv[1], "rb");
   if (!f) { perror(argv[1]); return 2; }
   int32_t hdr[6];
@@ -82,19 +90,26 @@ int main(int argc, char** argv) {
   int ndev = 0;
   CHECK_HIP(hipGetDeviceCount(&ndev));
   int G = argc > 2 ? atoi(argv[2]) : ndev;
-  if (G < 1 || G > ndev) { fprintf(stderr, "%d GPUs requested, %d visible\n", G, ndev); return 2; }
+  if (G < 1 || (G > ndev && !shared_gpu) || G > 64) { fprintf(stderr, "%d GPUs requested, %d visible\n", G, ndev); return 2; }
+  auto dev_of = [&](int rank) { return shared_gpu ? 0 : rank; };
   const int steps = argc > 3 ? atoi(argv[3]) : 5;
 
   // ---- the one collective: broadcast of the parameter block from device 0 (RCCL over xGMI) ---------------------
   std::vector<int> devs(G);
-  for (int i = 0; i < G; i++) devs[i] = i;
-  std::vector<ncclComm_t> comms(G);
-  CHECK_NCCL(ncclCommInitAll(comms.data(), G, devs.data()));
+  for (int i = 0; i < G; i++) devs[i] = dev_of(i);
+  std::vector<ncclComm_t> comms(G, nullptr);
+  bool rccl = true;
+  if (shared_gpu && G > 1) {   // RCCL may refuse one device twice: only then, and only behind the flag, the fan-out below
+    rccl = ncclCommInitAll(comms.data(), G, devs.data()) == ncclSuccess;
+    if (!rccl) for (auto& c : comms) c = nullptr;
+  } else {
+    CHECK_NCCL(ncclCommInitAll(comms.data(), G, devs.data()));
+  }
   std::vector<hipStream_t> streams(G);
   std::vector<double*> d_block(G);
   const size_t block_doubles = (size_t)S * 5 + 1;   // parameters + decimate
   for (int i = 0; i < G; i++) {
-    CHECK_HIP(hipSetDevice(i));
+    CHECK_HIP(hipSetDevice(dev_of(i)));
     CHECK_HIP(hipStreamCreate(&streams[i]));
     CHECK_HIP(hipMalloc((void**)&d_block[i], block_doubles * 8));
     CHECK_HIP(hipMemset(d_block[i], 0, block_doubles * 8));
@@ -106,13 +121,17 @@ int main(int argc, char** argv) {
     CHECK_HIP(hipSetDevice(0));
     CHECK_HIP(hipMemcpy(d_block[0], host.data(), block_doubles * 8, hipMemcpyHostToDevice));   // only device 0 holds it
   }
-  CHECK_NCCL(ncclGroupStart());
-  for (int i = 0; i < G; i++) {
-    CHECK_HIP(hipSetDevice(i));
-    CHECK_NCCL(ncclBroadcast(d_block[i], d_block[i], block_doubles, ncclDouble, 0, comms[i], streams[i]));
+  if (rccl) {
+    CHECK_NCCL(ncclGroupStart());
+    for (int i = 0; i < G; i++) {
+      CHECK_HIP(hipSetDevice(dev_of(i)));
+      CHECK_NCCL(ncclBroadcast(d_block[i], d_block[i], block_doubles, ncclDouble, 0, comms[i], streams[i]));
+    }
+    CHECK_NCCL(ncclGroupEnd());
+  } else {   // (--shared-gpu only) the same block to every rank's copy, device to device on the rank's stream
+    for (int i = 1; i < G; i++) CHECK_HIP(hipMemcpyAsync(d_block[i], d_block[0], block_doubles * 8, hipMemcpyDeviceToDevice, streams[i]));
   }
-  CHECK_NCCL(ncclGroupEnd());
-  for (int i = 0; i < G; i++) { CHECK_HIP(hipSetDevice(i)); CHECK_HIP(hipStreamSynchronize(streams[i])); }
+  for (int i = 0; i < G; i++) { CHECK_HIP(hipSetDevice(dev_of(i))); CHECK_HIP(hipStreamSynchronize(streams[i])); }
 
   // ---- one host thread, one handle, one share of the streams per GPU ------------------------------------------
   Barrier bar(G);
@@ -121,7 +140,7 @@ int main(int argc, char** argv) {
   std::vector<uint32_t> ndet(S, 0);
   const uint32_t max_tags = 64;
   auto worker = [&](int g) {
-    CHECK_HIP(hipSetDevice(g));
+    CHECK_HIP(hipSetDevice(dev_of(g)));
     // this GPU's copy of the block, as received through the broadcast
     std::vector<double> blk(block_doubles);
     CHECK_HIP(hipMemcpy(blk.data(), d_block[g], block_doubles * 8, hipMemcpyDeviceToHost));
@@ -152,7 +171,7 @@ int main(int argc, char** argv) {
       amdAprilTagsDefaultConfig(&cfg, (uint32_t)W, (uint32_t)H);
       cfg.decimate = (uint32_t)blk[(size_t)S * 5];
       cfg.max_batch = B;
-      cfg.device = g;
+      cfg.device = dev_of(g);
       cfg.tag_size = kv.first;
       CHECK_AT(amdCreateAprilTagsDetectorEx(&gr.h, &cfg));
       CHECK_HIP(hipMalloc((void**)&gr.d_frames, (size_t)B * fbytes));
@@ -233,10 +252,11 @@ int main(int argc, char** argv) {
   for (auto& t : th) t.join();
   double worst = 0;
   for (double s : seconds) worst = s > worst ? s : worst;
-  for (int i = 0; i < G; i++) { CHECK_HIP(hipSetDevice(i)); (void)hipFree(d_block[i]); (void)hipStreamDestroy(streams[i]); ncclCommDestroy(comms[i]); }
+  for (int i = 0; i < G; i++) { CHECK_HIP(hipSetDevice(dev_of(i))); (void)hipFree(d_block[i]); (void)hipStreamDestroy(streams[i]); if (comms[i]) ncclCommDestroy(comms[i]); }
 
-  printf("{\"gpus\": %d, \"streams\": %d, \"frames_per_stream\": %d, \"steps\": %d, \"fps\": %.1f, \"collective\": \"ncclBroadcast of %zu doubles\", ",
-         G, S, F, steps, worst > 0 ? (double)S * F * steps / worst : 0.0, block_doubles);
+  printf("{\"gpus\": %d, \"shared_gpu\": %s, \"streams\": %d, \"frames_per_stream\": %d, \"steps\": %d, \"fps\": %.1f, \"collective\": \"%s of %zu doubles\", ",
+         G, shared_gpu ? "true" : "false", S, F, steps, worst > 0 ? (double)S * F * steps / worst : 0.0,
+         rccl ? "ncclBroadcast" : "device-to-device fan-out (RCCL refused one device twice)", block_doubles);
   // wall time of every GPU's own timed loop (a straggler shows here; fps uses the slowest)
   if (host_frames) {
     double worst_h = 0;

@@ -12,9 +12,12 @@
  *   amdAprilTagsFamily           replaces cuAprilTagsFamily           src/apriltag_node.cpp:401-407
  *
  * Differences that are part of the contract (north_star of BASELINE.json):
- *   - the image is mono8 (1 byte/pixel, pitch-linear, DEVICE memory); colour input is converted
- *     first with amdAprilTagsConvertToMono8 (stands in for vpiSubmitConvertImageFormat,
- *     src/apriltag_node.cpp:275-282; accepted encodings = the table at :76-82);
+ *   - the image is mono8 (1 byte/pixel, pitch-linear, DEVICE memory) for the calls above; colour frames as the reference
+ *     feeds them -- rgb8 / bgr8 `uchar3` on its cuAprilTags branch (src/apriltag_node.cpp:469-486), the encoding table of
+ *     :76-82 on its VPI branch -- go through amdAprilTagsDetectColor / amdAprilTagsDetectBatchColor /
+ *     amdAprilTagsSubmitBatchColor, whose threshold pass reads the interleaved frame itself (no separate conversion launch
+ *     at tile_size 4, decimate 1); amdAprilTagsConvertToMono8 remains as the stand-alone conversion
+ *     (vpiSubmitConvertImageFormat, src/apriltag_node.cpp:275-282);
  *   - a batched entry point (amdAprilTagsDetectBatch) processes independent frames in one
  *     submission -- also in two halves, amdAprilTagsSubmitBatch / amdAprilTagsWaitBatch, so that a host
  *     overlaps its next host-to-device copy with the detection; a HIP stream replaces the CUDA stream;
@@ -80,10 +83,26 @@ typedef struct {
   float fx, fy, cx, cy;
 } amdAprilTagsCameraIntrinsics_t;
 
+/* Pixel layout of the frames of a colour submission: the ROS encoding strings the reference accepts
+ * (src/apriltag_node.cpp:76-82; its cuAprilTags branch takes rgb8 / bgr8 only, :469-476). */
+typedef enum {
+  AMDAT_ENC_MONO8 = 0,
+  AMDAT_ENC_RGB8 = 1,
+  AMDAT_ENC_BGR8 = 2,
+  AMDAT_ENC_RGBA8 = 3,
+  AMDAT_ENC_BGRA8 = 4
+} amdAprilTagsEncoding;
+/* "mono8", "rgb8", "bgr8", "rgba8", "bgra8" -> amdAprilTagsEncoding; -1 for any other string. */
+int amdAprilTagsEncodingFromName(const char* name);
+
+/* Field NAMES follow cuAprilTagsImageInput_t as the reference assigns them (width, height, dev_ptr, pitch:
+ * src/apriltag_node.cpp:481-486), so its binding compiles unchanged; the LAYOUT is this library's own (the closed header's
+ * is not known), i.e. name-compatible, not binary-compatible, with cuAprilTags.  In the *Color calls dev_ptr is the
+ * interleaved frame (the reference's uchar3*) and pitch its row stride in bytes. */
 typedef struct {
   uint32_t width;
   uint32_t height;
-  const uint8_t* dev_ptr; /* mono8, device memory */
+  const uint8_t* dev_ptr; /* mono8 (or, in the *Color calls, interleaved colour), device memory */
   size_t pitch;           /* bytes per row; pitch * height must stay below 2^31 (AMDAT_INVALID_ARGUMENT otherwise) */
 } amdAprilTagsImageInput_t;
 
@@ -171,6 +190,13 @@ int amdAprilTagsDetect(amdAprilTagsHandle handle, const amdAprilTagsImageInput_t
                        amdAprilTagsID_t* tags_out, uint32_t* num_tags, uint32_t max_tags,
                        amdAprilTagsStream stream);
 
+/* The same call on a colour frame, as the reference's cuAprilTags branch makes it (uchar3 rgb8 / bgr8 device image,
+ * src/apriltag_node.cpp:469-493): the gray value is the fixed-point BT.601 statement of amdAprilTagsConvertToMono8, formed by the
+ * threshold pass's loader; results equal those of the mono8 call on the converted frame bit for bit.  encoding AMDAT_ENC_MONO8
+ * is amdAprilTagsDetect. */
+int amdAprilTagsDetectColor(amdAprilTagsHandle handle, const amdAprilTagsImageInput_t* img_input, amdAprilTagsEncoding encoding,
+                            amdAprilTagsID_t* tags_out, uint32_t* num_tags, uint32_t max_tags, amdAprilTagsStream stream);
+
 /* Batched call: n independent frames (n <= max_batch).  tags_out holds n*max_tags records,
  * num_tags n counts.  per_frame_intrinsics may be NULL (handle intrinsics used for all frames). */
 int amdAprilTagsDetectBatch(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
@@ -183,6 +209,15 @@ int amdAprilTagsDetectBatchEx(amdAprilTagsHandle handle, uint32_t n, const amdAp
                               amdAprilTagsDetectionEx_t* dets_out, uint32_t* num_dets, uint32_t max_dets,
                               amdAprilTagsStream stream);
 
+/* The batched calls on colour frames (all frames of a submission share one encoding). */
+int amdAprilTagsDetectBatchColor(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
+                                 amdAprilTagsEncoding encoding, const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics,
+                                 amdAprilTagsID_t* tags_out, uint32_t* num_tags, uint32_t max_tags, amdAprilTagsStream stream);
+int amdAprilTagsDetectBatchColorEx(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
+                                   amdAprilTagsEncoding encoding, const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics,
+                                   amdAprilTagsDetectionEx_t* dets_out, uint32_t* num_dets, uint32_t max_dets,
+                                   amdAprilTagsStream stream);
+
 /* The batched call in two halves, for hosts that overlap the NEXT batch's host-to-device copy (on a stream of their own) with
  * this batch's detection: amdAprilTagsSubmitBatch enqueues the submission and returns; amdAprilTagsWaitBatch[Ex] blocks until
  * it is done and hands out the records (layout as amdAprilTagsDetectBatch[Ex] with the max_tags given at submit).  One
@@ -192,6 +227,9 @@ int amdAprilTagsDetectBatchEx(amdAprilTagsHandle handle, uint32_t n, const amdAp
 int amdAprilTagsSubmitBatch(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
                             const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics, uint32_t max_tags,
                             amdAprilTagsStream stream);
+int amdAprilTagsSubmitBatchColor(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
+                                 amdAprilTagsEncoding encoding, const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics,
+                                 uint32_t max_tags, amdAprilTagsStream stream);
 int amdAprilTagsWaitBatch(amdAprilTagsHandle handle, amdAprilTagsID_t* tags_out, uint32_t* num_tags);
 int amdAprilTagsWaitBatchEx(amdAprilTagsHandle handle, amdAprilTagsDetectionEx_t* dets_out, uint32_t* num_dets);
 
@@ -232,6 +270,11 @@ int amdAprilTagsRectifyMono8(const uint8_t* src_dev, size_t src_pitch, uint8_t* 
 int amdAprilTagsDeviceAlloc(void** dev_ptr, size_t bytes);
 int amdAprilTagsDeviceFree(void* dev_ptr);
 int amdAprilTagsCopyToDevice(void* dst_dev, const void* src_host, size_t bytes, amdAprilTagsStream stream);
+/* Enqueue-only form on a stream of the host's (amdAprilTagsStreamCreate): the copy is ordered ahead of a detection submitted on the
+ * same stream, whose wait then covers both; the source must stay valid until that detection has returned. */
+int amdAprilTagsCopyToDeviceAsync(void* dst_dev, const void* src_host, size_t bytes, amdAprilTagsStream stream);
+int amdAprilTagsStreamCreate(amdAprilTagsStream* stream);    /* a non-blocking HIP stream */
+int amdAprilTagsStreamDestroy(amdAprilTagsStream stream);   /* waits for it first */
 
 /* Registers a tag family as data (row-major codes, MSB = top-left data cell) in a custom slot. */
 int amdAprilTagsRegisterFamily(amdAprilTagsFamily slot, const char* name, uint32_t data_bits_per_side,

@@ -26,6 +26,10 @@ int amdAprilTagsGetStageMs(amdAprilTagsHandle handle, float* ms);
 /* Runs only the threshold pass (S1+S2) on n frames; used by the roofline measurement. */
 int amdAprilTagsThresholdOnly(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
                               amdAprilTagsStream stream);
+/* The same on colour frames: at tile_size 4, decimate 1 the one-pass kernel with the colour loader (3 or 4 bytes read, the gray
+ * plane and the threshold image written: 5 or 6 bytes per pixel), otherwise the conversion launch and the mono8 pass. */
+int amdAprilTagsThresholdOnlyColor(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
+                                   amdAprilTagsEncoding encoding, amdAprilTagsStream stream);
 
 /* Which launch set a submission gets.  The library picks it from the submission's size: up to eight 1080p frames' worth of
  * working pixels take the LATENCY set (k_cc_local<16>, every small cluster in the one-wave class of k_fit_quads, no
@@ -42,6 +46,11 @@ int amdAprilTagsDebugLastSubmissionPath(amdAprilTagsHandle handle);
 /* Launches of this handle whose stream wait returned before their results were there (every launch's counters carry its sequence
  * number; the library then waits for the whole device and checks again): 0 on a healthy runtime. */
 int amdAprilTagsDebugLateWaits(amdAprilTagsHandle handle);
+/* Captured-graph replay of small submissions: returns 1 while the handle still captures launch graphs for new submission shapes,
+ * 0 once it has stopped (a failed capture, eight cache evictions in a row, or too many retired graphs: such a handle replays the
+ * graphs it has and enqueues everything else plainly, ~0.1 ms more per one-frame call), -1 for a null handle; the counts of live
+ * cache entries and of retired graphs (kept until the handle is destroyed, see csrc/detector.hip: retire_graph) through the outputs. */
+int amdAprilTagsDebugGraphReplay(amdAprilTagsHandle handle, uint32_t* live_graphs, uint32_t* retired_graphs);
 
 /* ---- stage inspection (parity tests) ------------------------------------------------------ */
 typedef enum {

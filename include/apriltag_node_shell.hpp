@@ -69,6 +69,11 @@ struct NodeOptions {
   std::string tag_family = "tag36h11";
   std::string backends = "CUDA";  // reference default VPI_BACKEND_CUDA; "CUDA" | "HIP" | "GPU" select this library
   uint32_t decimate = 1;          // extension (AprilRobotics quad_decimate); 1 = cuAprilTags behaviour
+  // The reference's cuAprilTags branch (backends == "CUDA") throws on every encoding but rgb8 / bgr8
+  // (src/apriltag_node.cpp:469-476); its VPI branch takes the five of :76-82.  This shell takes the five in BOTH modes by default --
+  // a superset: mono8 is what north_star feeds the detector, and the library's colour entry point reads rgba8 / bgra8 as well.
+  // true: cuAprilTags mode refuses everything but rgb8 / bgr8 with the reference's own text.
+  bool strict_cuapriltags_encodings = false;
 };
 
 class AprilTagNode {

@@ -106,6 +106,35 @@ def build_stress(force=False):
     return LIB_STRESS
 
 
+MUTANTS = (1, 2, 3)   # csrc/tools_hooks.h, AMDAT_MUTATE
+
+
+def lib_mutant(n):
+    return os.path.join(_HERE, "libapriltag_amd_mut%d.so" % n)
+
+
+def build_mutants(force=False):
+    """Deliberately WRONG builds of the same sources (csrc/tools_hooks.h: -DAMDAT_MUTATE=1 the launch sequence without k_fit_small,
+    2 one row constant off in k_cc_local<4>, 3 one sector too many in k_fit_prefilter<64>'s test), shipped like the stress build so
+    that the GPU suite itself shows, under the driver's eyes, that its stage tests FAIL on each of them
+    (tests/test_gpu_parity.py::test_the_suite_fails_on_wrong_builds).  Never loaded by the product path."""
+    import threading
+    err = []
+
+    def _one(n):
+        try:
+            if force or _newer(lib_mutant(n), [os.path.join(_CSRC, "detector.hip")] + _sources(".h")):
+                build_amd_variant("mut%d" % n, ["AMDAT_MUTATE=%d" % n])
+        except (subprocess.CalledProcessError, OSError) as e:
+            err.append(e)
+    ts = [threading.Thread(target=_one, args=(n,)) for n in MUTANTS]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    if err:
+        raise err[0]
+    return [lib_mutant(n) for n in MUTANTS]
+
+
 def build_all(force=False):
     import threading
     build_synth(force)
@@ -116,13 +145,22 @@ def build_all(force=False):
             build_stress(force)
         except (subprocess.CalledProcessError, OSError) as e:   # only its test needs it
             err.append(e)
+
+    def _mutants():
+        try:
+            build_mutants(force)
+        except (subprocess.CalledProcessError, OSError) as e:   # only their test needs them
+            err.append(e)
     t = threading.Thread(target=_stress)
-    t.start()                      # (next to the product library: two hipcc runs of the same translation unit)
+    t.start()                      # (next to the product library: hipcc runs of the same translation unit)
     build_amd(force)
     t.join()
+    tm = threading.Thread(target=_mutants)
+    tm.start()
+    tm.join()
     if err:
         import sys
-        sys.stderr.write("isaac_ros_apriltag_amd.build: stress variant not built (%s); only its test needs it\n" % (err[0],))
+        sys.stderr.write("isaac_ros_apriltag_amd.build: stress / mutant variants not built (%s); only their tests need them\n" % (err[0],))
     build_node(force)
     try:   # the multi-GPU example links RCCL; a machine without it still gets the product libraries
         build_host(force)

@@ -63,8 +63,13 @@ EXPORTS = ["amdAprilTagsDefaultConfig", "amdCreateAprilTagsDetector", "amdCreate
            "amdAprilTagsSetProfiling", "amdAprilTagsGetStageMs", "amdAprilTagsThresholdOnly",
            "amdAprilTagsDebugCopy", "amdAprilTagsDebugMath", "amdAprilTagsDeviceAlloc", "amdAprilTagsDeviceFree",
            "amdAprilTagsCopyToDevice", "amdAprilTagsResizeMono8", "amdAprilTagsRectifyMono8",
-           "amdAprilTagsGetDeviceBytes", "amdAprilTagsDebugSetSubmissionPath", "amdAprilTagsDebugLastSubmissionPath", "amdAprilTagsDebugLateWaits"]
+           "amdAprilTagsGetDeviceBytes", "amdAprilTagsDebugSetSubmissionPath", "amdAprilTagsDebugLastSubmissionPath", "amdAprilTagsDebugLateWaits",
+           "amdAprilTagsEncodingFromName", "amdAprilTagsDetectColor", "amdAprilTagsDetectBatchColor", "amdAprilTagsDetectBatchColorEx",
+           "amdAprilTagsSubmitBatchColor", "amdAprilTagsThresholdOnlyColor", "amdAprilTagsCopyToDeviceAsync", "amdAprilTagsStreamCreate",
+           "amdAprilTagsStreamDestroy", "amdAprilTagsDebugGraphReplay"]
 PATH_AUTO, PATH_LATENCY, PATH_THROUGHPUT = 0, 1, 2
+ENCODINGS = {"mono8": 0, "rgb8": 1, "bgr8": 2, "rgba8": 3, "bgra8": 4}   # amdAprilTagsEncoding
+ENC_CHANNELS = {"mono8": 1, "rgb8": 3, "bgr8": 3, "rgba8": 4, "bgra8": 4}
 
 _lib = None
 
@@ -91,6 +96,14 @@ def lib():
     L.amdAprilTagsDetectBatchEx.argtypes = [H, C.c_uint32, C.POINTER(ImageInput), C.POINTER(Intrinsics),
                                             C.POINTER(DetectionEx), C.POINTER(C.c_uint32), C.c_uint32, H]
     L.amdAprilTagsSubmitBatch.argtypes = [H, C.c_uint32, C.POINTER(ImageInput), C.POINTER(Intrinsics), C.c_uint32, H]
+    L.amdAprilTagsEncodingFromName.argtypes = [C.c_char_p]
+    L.amdAprilTagsDetectColor.argtypes = [H, C.POINTER(ImageInput), C.c_int, C.POINTER(TagID), C.POINTER(C.c_uint32), C.c_uint32, H]
+    L.amdAprilTagsDetectBatchColor.argtypes = [H, C.c_uint32, C.POINTER(ImageInput), C.c_int, C.POINTER(Intrinsics),
+                                               C.POINTER(TagID), C.POINTER(C.c_uint32), C.c_uint32, H]
+    L.amdAprilTagsDetectBatchColorEx.argtypes = [H, C.c_uint32, C.POINTER(ImageInput), C.c_int, C.POINTER(Intrinsics),
+                                                 C.POINTER(DetectionEx), C.POINTER(C.c_uint32), C.c_uint32, H]
+    L.amdAprilTagsSubmitBatchColor.argtypes = [H, C.c_uint32, C.POINTER(ImageInput), C.c_int, C.POINTER(Intrinsics), C.c_uint32, H]
+    L.amdAprilTagsThresholdOnlyColor.argtypes = [H, C.c_uint32, C.POINTER(ImageInput), C.c_int, H]
     L.amdAprilTagsWaitBatch.argtypes = [H, C.POINTER(TagID), C.POINTER(C.c_uint32)]
     L.amdAprilTagsWaitBatchEx.argtypes = [H, C.POINTER(DetectionEx), C.POINTER(C.c_uint32)]
     L.amdAprilTagsSetFrameSkews.argtypes = [H, C.c_uint32, C.POINTER(C.c_float)]
@@ -113,6 +126,9 @@ def lib():
     L.amdAprilTagsDeviceAlloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     L.amdAprilTagsDeviceFree.argtypes = [C.c_void_p]
     L.amdAprilTagsCopyToDevice.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, H]
+    L.amdAprilTagsCopyToDeviceAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, H]
+    L.amdAprilTagsStreamCreate.argtypes = [C.POINTER(H)]
+    L.amdAprilTagsStreamDestroy.argtypes = [H]
     L.amdAprilTagsResizeMono8.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32,
                                           C.c_uint32, H]
     L.amdAprilTagsRectifyMono8.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32,
@@ -121,10 +137,11 @@ def lib():
     L.amdAprilTagsDebugSetSubmissionPath.argtypes = [H, C.c_int]
     L.amdAprilTagsDebugLastSubmissionPath.argtypes = [H]
     L.amdAprilTagsDebugLateWaits.argtypes = [H]
+    L.amdAprilTagsDebugGraphReplay.argtypes = [H, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.amdAprilTagsDebugMath.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if fn.restype is C.c_int or name in ("amdAprilTagsFamilyFromName",):
+        if fn.restype is C.c_int or name in ("amdAprilTagsFamilyFromName", "amdAprilTagsEncodingFromName"):
             fn.restype = C.c_int
     _lib = L
     return L

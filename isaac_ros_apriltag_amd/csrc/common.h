@@ -17,11 +17,15 @@
 
 // Per-frame descriptor (device copy of amdAprilTagsImageInput_t + intrinsics), one per batch slot.
 struct FrameDesc {
-  const uint8_t* img;  // mono8, full resolution
+  const uint8_t* img;  // mono8, full resolution -- of a colour submission: the handle's gray plane, which the threshold pass (or the
+                       // conversion launch ahead of it) fills from `src`; every later stage reads `img` and never sees the colour frame
   uint32_t pitch;
   uint32_t seq;        // number of the launch this descriptor was written for (the handle's counter): comes back in FrameCounters::seq
   double fx, fy, cx, cy;
   double skew;
+  const uint8_t* src;  // colour submissions (amdAprilTagsEncoding != mono8): the caller's interleaved frame; null otherwise
+  uint32_t src_pitch;
+  uint32_t fmt;        // amdAprilTagsEncoding of `src`
 };
 
 // Per-frame counters (one struct per batch slot), zeroed at the start of every submission.

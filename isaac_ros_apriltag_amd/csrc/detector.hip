@@ -168,7 +168,9 @@ struct amdAprilTagsDetector_st {
   hipStream_t aux_stream[FQ_NAUX] = {};
   hipEvent_t ev_fork = nullptr, ev_join[FQ_NAUX] = {};
   // device buffers
-  uint8_t* d_gray = nullptr;
+  uint8_t* d_gray = nullptr;          // working-size gray plane: decimated handles, and (allocated on first use) colour submissions at decimate 1
+  uint8_t* d_conv = nullptr;          // full-size mono8 plane of colour submissions that take the conversion launch (decimate > 1, tile_size 8)
+  size_t conv_pitch = 0;
   uint8_t* d_thr = nullptr;
   uint8_t* d_tmin = nullptr;         // per-tile min / max of the two-pass threshold (tile_size != 4 only)
   uint8_t* d_tmax = nullptr;
@@ -222,7 +224,7 @@ struct amdAprilTagsDetector_st {
   bool fq_attr_set = false;
   // captured enqueue sequence of small submissions (see run_batch)
   uint32_t graph_max_frames = 8;
-  struct GraphEntry { hipGraphExec_t exec = nullptr; uint32_t n = 0, ostride = 0; hipStream_t stream = nullptr; uint64_t last_use = 0; };
+  struct GraphEntry { hipGraphExec_t exec = nullptr; uint32_t n = 0, ostride = 0, fmt = 0; hipStream_t stream = nullptr; uint64_t last_use = 0; };
   GraphEntry graphs[6];
   std::vector<hipGraphExec_t> retired_graphs;   // see drop_graphs
   uint64_t graph_clock = 0;
@@ -234,6 +236,7 @@ struct amdAprilTagsDetector_st {
   struct { bool active = false; uint32_t n = 0, ostride = 0, max_out = 0; hipStream_t stream = nullptr; } inflight;   // amdAprilTagsSubmitBatch .. WaitBatch
   std::vector<float> frame_skew;     // per batch slot, amdAprilTagsSetFrameSkews; empty: cfg.skew for every frame
   uint32_t launched_n = 0;
+  uint32_t launched_fmt = 0;         // amdAprilTagsEncoding of the submission in flight (a regrowth relaunch repeats it)
   uint32_t seq = 0;                  // launch counter: travels through the descriptor block and comes back with the counters
   uint32_t late_waits = 0;           // launches whose stream wait returned before their results (finish_once); amdAprilTagsDebugLateWaits
   int path_mode = AMDAT_PATH_AUTO;
@@ -272,10 +275,35 @@ __global__ __launch_bounds__(256) void k_to_mono8(const uint8_t* __restrict__ sr
   }
 }
 
+// The same conversion for the frames of a colour submission that does not take the fused loader of k_threshold (decimate > 1,
+// tile_size 8): source and destination of frame blockIdx.z come from its descriptor (src -> img), one launch per submission.
+template <int NCH, int RIDX, int BIDX>
+__global__ __launch_bounds__(256) void k_to_mono8_frames(const FrameDesc* __restrict__ frames, uint32_t w, uint32_t h) {
+  const FrameDesc fd = frames[blockIdx.z];
+  const uint32_t x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const uint32_t y = blockIdx.y;
+  if (x4 >= w || y >= h) return;
+  const uint8_t* s = fd.src + (size_t)y * fd.src_pitch + (size_t)x4 * NCH;
+  uint8_t* d = const_cast<uint8_t*>(fd.img) + (size_t)y * fd.pitch + x4;
+  for (uint32_t k = 0; k < 4 && x4 + k < w; k++) {
+    const uint32_t R = s[k * NCH + RIDX], G = s[k * NCH + 1], B = s[k * NCH + BIDX];
+    d[k] = (uint8_t)((4899u * R + 9617u * G + 1868u * B + 8192u) >> 14);
+  }
+}
+
+static inline uint32_t enc_channels(uint32_t fmt) { return fmt == AMDAT_ENC_MONO8 ? 1u : (fmt <= AMDAT_ENC_BGR8 ? 3u : 4u); }
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" {
+
+int amdAprilTagsEncodingFromName(const char* name) {
+  if (!name) return -1;
+  static const char* const kNames[5] = {"mono8", "rgb8", "bgr8", "rgba8", "bgra8"};   // src/apriltag_node.cpp:76-82
+  for (int i = 0; i < 5; i++) if (!strcmp(name, kNames[i])) return i;
+  return -1;
+}
 
 void amdAprilTagsDefaultConfig(amdAprilTagsConfig_t* cfg, uint32_t width, uint32_t height) {
   memset(cfg, 0, sizeof(*cfg));
@@ -393,7 +421,7 @@ const char* amdAprilTagsStageName(uint32_t stage) { return stage < AMDAT_NUM_STA
 static void free_all(amdAprilTagsDetector_st* D) {
   for (auto& g : D->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
   for (hipGraphExec_t e : D->retired_graphs) hipGraphExecDestroy(e);
-  hipFree(D->d_gray); hipFree(D->d_thr); hipFree(D->d_tmin); hipFree(D->d_tmax); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_roots); hipFree(D->d_hkeys);
+  hipFree(D->d_gray); hipFree(D->d_conv); hipFree(D->d_thr); hipFree(D->d_tmin); hipFree(D->d_tmax); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_roots); hipFree(D->d_hkeys);
   hipFree(D->d_hcnt); hipFree(D->d_hoff); hipFree(D->d_stage); hipFree(D->d_bhdr); hipFree(D->d_btab); hipFree(D->d_long); hipFree(D->d_pts); hipFree(D->d_clusters);
   hipFree(D->d_work); hipFree(D->d_work2); hipFree(D->d_workctl); hipFree(D->d_keys_scr); hipFree(D->d_quads);
   for (auto& c : D->cls) { hipFree(c.d_lf); hipFree(c.d_errs); }
@@ -706,9 +734,14 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
     if (ok && hipMemcpy(D->d_codes[i], codes.data(), codes.size() * 8, hipMemcpyHostToDevice) != hipSuccess) ok = false;
     P.fam[i].codes = D->d_codes[i];
   }
-  if (ok && hipHostMalloc((void**)&D->h_frames, B * sizeof(FrameDesc)) != hipSuccess) ok = false;
-  if (ok && hipHostMalloc((void**)&D->h_counters, B * sizeof(FrameCounters)) != hipSuccess) ok = false;
-  if (ok && hipHostMalloc((void**)&D->h_out, B * (size_t)P.dcap * sizeof(DetRec)) != hipSuccess) ok = false;
+  // pinned blocks the kernels read (descriptors) and write (records, counters + stamp) over the bus: COHERENT (fine-grained) host
+  // memory, stated rather than left to the runtime's default -- the host reads them right after a stream wait, not after a
+  // device-wide one
+  const unsigned host_flags = hipHostMallocCoherent | hipHostMallocMapped;
+  if (ok && hipHostMalloc((void**)&D->h_frames, B * sizeof(FrameDesc), host_flags) != hipSuccess) ok = false;
+  if (ok && hipHostMalloc((void**)&D->h_counters, B * sizeof(FrameCounters), host_flags) != hipSuccess) ok = false;
+  if (ok && hipHostMalloc((void**)&D->h_out, B * (size_t)P.dcap * sizeof(DetRec), host_flags) != hipSuccess) ok = false;
+  if (ok) memset(D->h_counters, 0, B * sizeof(FrameCounters));
   if (ok && hipStreamCreateWithFlags(&D->own_stream, hipStreamNonBlocking) != hipSuccess) ok = false;
   for (auto& e : D->ev) if (ok && hipEventCreate(&e) != hipSuccess) ok = false;
   for (auto& a : D->aux_stream) if (ok && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) ok = false;
@@ -775,6 +808,7 @@ static void drop_graphs(amdAprilTagsDetector_st* D);   // (defined with the subm
 
 int amdAprilTagsDebugSetSubmissionPath(amdAprilTagsHandle handle, int path) {
   if (!handle || path < AMDAT_PATH_AUTO || path > AMDAT_PATH_THROUGHPUT) return AMDAT_INVALID_ARGUMENT;
+  if (handle->inflight.active) return AMDAT_INVALID_ARGUMENT;   // (a regrowth relaunch inside the wait must run the set the submit reported)
   if (path == handle->path_mode) return AMDAT_SUCCESS;
   DeviceGuard guard(handle->device);
   if (!guard.ok) return AMDAT_HIP_ERROR;
@@ -784,6 +818,15 @@ int amdAprilTagsDebugSetSubmissionPath(amdAprilTagsHandle handle, int path) {
 }
 
 int amdAprilTagsDebugLateWaits(amdAprilTagsHandle handle) { return handle ? (int)handle->late_waits : -1; }
+
+int amdAprilTagsDebugGraphReplay(amdAprilTagsHandle handle, uint32_t* live_graphs, uint32_t* retired_graphs) {
+  if (!handle) return -1;
+  uint32_t live = 0;
+  for (const auto& g : handle->graphs) live += g.exec ? 1u : 0u;
+  if (live_graphs) *live_graphs = live;
+  if (retired_graphs) *retired_graphs = (uint32_t)handle->retired_graphs.size();
+  return handle->graph_max_frames ? 1 : 0;
+}
 
 int amdAprilTagsDebugLastSubmissionPath(amdAprilTagsHandle handle) {
   return handle ? handle->last_path : -1;
@@ -795,24 +838,61 @@ int amdAprilTagsGetStageMs(amdAprilTagsHandle handle, float* ms) {
   return AMDAT_SUCCESS;
 }
 
-static int check_images(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images) {
+static int check_images(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images, uint32_t fmt = AMDAT_ENC_MONO8) {
   if (n == 0 || !images) return AMDAT_INVALID_ARGUMENT;
+  if (fmt > AMDAT_ENC_BGRA8) return AMDAT_UNSUPPORTED;
   if (n > D->cfg.max_batch) return AMDAT_BATCH_TOO_LARGE;
   for (uint32_t i = 0; i < n; i++) {
     if (!images[i].dev_ptr) return AMDAT_INVALID_ARGUMENT;
     if (images[i].width != D->cfg.width || images[i].height != D->cfg.height) return AMDAT_SIZE_MISMATCH;
-    if (images[i].pitch < images[i].width) return AMDAT_INVALID_ARGUMENT;
+    if (images[i].pitch < (size_t)images[i].width * enc_channels(fmt)) return AMDAT_INVALID_ARGUMENT;
     if ((uint64_t)images[i].pitch * images[i].height > 0x7FFFFFFFull) return AMDAT_INVALID_ARGUMENT;   // 32-bit pixel offsets on the device
   }
   return AMDAT_SUCCESS;
 }
 
+// A colour submission takes the fused loader of the one-pass threshold kernel where that kernel runs undecimated (tile_size 4,
+// decimate 1: the reference's cuAprilTags configuration); otherwise one conversion launch ahead of the mono8 pipeline.
+static inline bool colour_fused(const amdAprilTagsDetector_st* D, uint32_t fmt) {
+  return fmt != AMDAT_ENC_MONO8 && D->P.decimate == 1 && D->P.tile == 4;
+}
+// The gray plane the colour frames of a submission become (allocated on the first colour submission; the pointers travel
+// through the descriptor block, so captured launch sequences of earlier mono8 submissions stay valid).
+static int ensure_colour_plane(amdAprilTagsDetector_st* D, uint32_t fmt) {
+  if (fmt == AMDAT_ENC_MONO8) return AMDAT_SUCCESS;
+  const size_t B = D->cfg.max_batch;
+  if (colour_fused(D, fmt)) {
+    if (D->d_gray) return AMDAT_SUCCESS;
+    const size_t bytes = B * (size_t)D->P.H * D->P.WS;
+    if (hipMalloc((void**)&D->d_gray, bytes) != hipSuccess) { D->d_gray = nullptr; return AMDAT_OUT_OF_MEMORY; }
+    D->device_bytes += bytes;
+    if (hipMemset(D->d_gray, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return AMDAT_HIP_ERROR;
+    return AMDAT_SUCCESS;
+  }
+  if (D->d_conv) return AMDAT_SUCCESS;
+  D->conv_pitch = ((size_t)D->cfg.width + 63) & ~(size_t)63;
+  const size_t bytes = B * D->conv_pitch * D->cfg.height;
+  if (hipMalloc((void**)&D->d_conv, bytes) != hipSuccess) { D->d_conv = nullptr; return AMDAT_OUT_OF_MEMORY; }
+  D->device_bytes += bytes;
+  return AMDAT_SUCCESS;
+}
+
 static void fill_frames(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images,
-                        const amdAprilTagsCameraIntrinsics_t* intr) {
+                        const amdAprilTagsCameraIntrinsics_t* intr, uint32_t fmt = AMDAT_ENC_MONO8) {
   for (uint32_t i = 0; i < n; i++) {
     const amdAprilTagsCameraIntrinsics_t& k = intr ? intr[i] : D->cfg.intrinsics;
-    D->h_frames[i].img = images[i].dev_ptr;
-    D->h_frames[i].pitch = (uint32_t)images[i].pitch;
+    if (fmt == AMDAT_ENC_MONO8) {
+      D->h_frames[i].img = images[i].dev_ptr;
+      D->h_frames[i].pitch = (uint32_t)images[i].pitch;
+      D->h_frames[i].src = nullptr; D->h_frames[i].src_pitch = 0;
+    } else {   // every stage behind the threshold pass (or the conversion launch) reads the handle's gray plane
+      const bool fused = colour_fused(D, fmt);
+      D->h_frames[i].img = fused ? D->d_gray + (size_t)i * D->P.H * D->P.WS : D->d_conv + (size_t)i * D->conv_pitch * D->cfg.height;
+      D->h_frames[i].pitch = fused ? (uint32_t)D->P.WS : (uint32_t)D->conv_pitch;
+      D->h_frames[i].src = images[i].dev_ptr;
+      D->h_frames[i].src_pitch = (uint32_t)images[i].pitch;
+    }
+    D->h_frames[i].fmt = fmt;
     D->h_frames[i].seq = D->seq;
     D->h_frames[i].fx = (double)k.fx; D->h_frames[i].fy = (double)k.fy;
     D->h_frames[i].cx = (double)k.cx; D->h_frames[i].cy = (double)k.cy;
@@ -820,7 +900,17 @@ static void fill_frames(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTa
   }
 }
 
-static void launch_threshold(amdAprilTagsDetector_st* D, const DetParams& P, uint32_t n, hipStream_t s) {
+static void launch_threshold(amdAprilTagsDetector_st* D, const DetParams& P, uint32_t n, hipStream_t s, uint32_t fmt = AMDAT_ENC_MONO8) {
+  if (fmt != AMDAT_ENC_MONO8 && !colour_fused(D, fmt)) {   // conversion launch: src -> the full-size mono8 plane the descriptors name
+    const dim3 g((P.W0 + 1023) / 1024, (unsigned)P.H0, n);
+    switch (fmt) {
+      case AMDAT_ENC_RGB8: hipLaunchKernelGGL((k_to_mono8_frames<3, 0, 2>), g, dim3(256), 0, s, D->d_frames, (uint32_t)P.W0, (uint32_t)P.H0); break;
+      case AMDAT_ENC_BGR8: hipLaunchKernelGGL((k_to_mono8_frames<3, 2, 0>), g, dim3(256), 0, s, D->d_frames, (uint32_t)P.W0, (uint32_t)P.H0); break;
+      case AMDAT_ENC_RGBA8: hipLaunchKernelGGL((k_to_mono8_frames<4, 0, 2>), g, dim3(256), 0, s, D->d_frames, (uint32_t)P.W0, (uint32_t)P.H0); break;
+      default: hipLaunchKernelGGL((k_to_mono8_frames<4, 2, 0>), g, dim3(256), 0, s, D->d_frames, (uint32_t)P.W0, (uint32_t)P.H0); break;
+    }
+    fmt = AMDAT_ENC_MONO8;
+  }
   if (P.tile != 4) {   // the two-pass statement (kernels_threshold.h); 4 keeps the one-pass kernel below
     const dim3 g1((unsigned)((P.tw * P.th + 255) / 256), 1, n), g2((unsigned)((P.W + 255) / 256), (unsigned)P.H, n);
 #define TH_ANY(DEC)                                                                                                      \
@@ -844,6 +934,19 @@ static void launch_threshold(amdAprilTagsDetector_st* D, const DetParams& P, uin
 #define TH_LAUNCH(DEC)                                                                                                   \
   hipLaunchKernelGGL(k_threshold<DEC>, grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, gx, gy, (int)n, P);     \
   if (leftover) hipLaunchKernelGGL(k_threshold_leftover<DEC>, lgrid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
+#define TH_LAUNCH_FMT(FMT)                                                                                                 \
+  hipLaunchKernelGGL((k_threshold<1, FMT>), grid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, gx, gy, (int)n, P);   \
+  if (leftover) hipLaunchKernelGGL((k_threshold_leftover<1, FMT>), lgrid, dim3(256), 0, s, D->d_frames, D->d_gray, D->d_thr, P);
+  if (fmt != AMDAT_ENC_MONO8) {   // (decimate 1: colour_fused)
+    switch (fmt) {
+      case AMDAT_ENC_RGB8: TH_LAUNCH_FMT(1) break;
+      case AMDAT_ENC_BGR8: TH_LAUNCH_FMT(2) break;
+      case AMDAT_ENC_RGBA8: TH_LAUNCH_FMT(3) break;
+      default: TH_LAUNCH_FMT(4) break;
+    }
+    return;
+  }
+#undef TH_LAUNCH_FMT
   switch (P.decimate) {
     case 1: TH_LAUNCH(1) break;
     case 2: TH_LAUNCH(2) break;
@@ -873,9 +976,18 @@ __global__ __launch_bounds__(64) void k_prologue(const uint32_t* __restrict__ ho
 // is a workgroup's only one, the stage ends with its longest chain, and a launch more costs more than k_fit_small's shorter
 // chain per small cluster saves (measured: 0.54 against 0.47 ms per one-frame call).  Such a submission buckets all clusters
 // up to the one-wave class's bound into that class (work_layout_small) and launches no k_fit_small.
-static inline bool small_submission(const amdAprilTagsDetector_st* D, const DetParams& P, uint32_t n) {
+#ifndef AMDAT_SMALL_PX
+#define AMDAT_SMALL_PX (16ull << 20)
+#endif
+#ifndef AMDAT_SMALL_PX_CC      // k_cc_local<16> below this many working pixels per submission
+#define AMDAT_SMALL_PX_CC AMDAT_SMALL_PX
+#endif
+#ifndef AMDAT_SMALL_PX_PF      // CU-wide prefilter workgroups below this
+#define AMDAT_SMALL_PX_PF AMDAT_SMALL_PX
+#endif
+static inline bool small_submission(const amdAprilTagsDetector_st* D, const DetParams& P, uint32_t n, uint64_t limit = AMDAT_SMALL_PX) {
   if (D->path_mode != AMDAT_PATH_AUTO) return D->path_mode == AMDAT_PATH_LATENCY;
-  return (uint64_t)n * (uint64_t)P.W * (uint64_t)P.H < (16ull << 20);
+  return (uint64_t)n * (uint64_t)P.W * (uint64_t)P.H < limit;
 }
 // the frame count the launch heuristics see (chunks of k_cluster_select, clusters per pop): a pinned path takes the values of
 // the submissions that path is for, whatever the real count
@@ -885,15 +997,15 @@ static inline uint32_t heuristic_frames(const amdAprilTagsDetector_st* D, uint32
   return n;
 }
 
-static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s, const std::function<void()>& mark) {
+static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s, uint32_t fmt, const std::function<void()>& mark) {
   DetParams P = D->P;
   P.frame0 = 0;
-  launch_threshold(D, P, n, s);
+  launch_threshold(D, P, n, s, fmt);
   mark();
 #ifndef AMDAT_CC_WIDE
 #define AMDAT_CC_WIDE 1
 #endif
-  if (AMDAT_CC_WIDE && small_submission(D, P, n))   // sixteen waves per tile: a quarter of the rows per lane (latency, not throughput)
+  if (AMDAT_CC_WIDE && small_submission(D, P, n, AMDAT_SMALL_PX_CC))   // sixteen waves per tile: a quarter of the rows per lane (latency, not throughput)
     hipLaunchKernelGGL((k_cc_local<16>), dim3((P.W + CC_T - 1) / CC_T, (P.H + CC_T - 1) / CC_T, n), dim3(1024), 0, s, D->d_thr,
                      D->d_label, D->d_csize, D->d_roots, D->d_counters, P);
   else
@@ -962,7 +1074,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
       if (!prefilter) return;
       if (FQ_SKIP_PREFILTER()) return;   // (tools_hooks.h: always 0 in the product build)
       // small submissions: one cluster per CU-wide workgroup (latency); otherwise one per wave (throughput)
-      const bool wide = small;
+      const bool wide = small_submission(D, P, n, AMDAT_SMALL_PX_PF);
 #define PF_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work, D->d_workctl, work2, D->d_workctl + 16, D->work_layout,   \
                 pf_first, (D->fq_counters ? D->d_fqprof : nullptr), P
       if (wide) {
@@ -1088,7 +1200,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
 
 // Everything one submission enqueues on stream s (and the auxiliary streams forked from it): descriptor upload, clears,
 // the stage sequence, result download.  No host synchronisation inside, so the sequence can be stream-captured.
-static int enqueue_submission(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s, const std::function<void()>& mark) {
+static int enqueue_submission(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s, uint32_t fmt, const std::function<void()>& mark) {
   mark();
   // descriptor upload + clears in one small kernel (it reads the pinned descriptor block over the bus itself): a copy
   // command and a fill command ahead of the first kernel cost a one-frame call about 15 us, this launch 4
@@ -1099,7 +1211,7 @@ static int enqueue_submission(amdAprilTagsDetector_st* D, uint32_t n, uint32_t o
   if (D->fq_counters) HIP_TRY(hipMemsetAsync(D->d_fqprof, 0, (64 + 8) * 8, s));
   mark();
   {
-    const int rc = issue_pipeline(D, n, ostride, s, mark);
+    const int rc = issue_pipeline(D, n, ostride, s, fmt, mark);
     if (rc) return rc;
   }
   mark();
@@ -1107,33 +1219,50 @@ static int enqueue_submission(amdAprilTagsDetector_st* D, uint32_t n, uint32_t o
 }
 
 // An instantiated graph that is no longer wanted -- a capacity grew (its launches carry the old pointers), the cache evicted it,
-// the submission path was pinned -- is RETIRED, not destroyed: hipGraphExecDestroy followed by the capture, instantiation and launch
-// of the next graph crashed the host inside the runtime (a segmentation fault, ROCm 7.2) once a process had done it a few dozen
-// times -- tools/stress_regrow.py: 3 of 3 runs within seconds; the full GPU suite inside the pair-table regrowth test in about half
-// of its runs -- and a device-wide wait ahead of the destroy only made it rarer (1 of 3 stress runs, 2 of 3 suite runs still died).
-// Retired graphs are destroyed with the handle, after its device-wide wait and with no capture behind them (every handle has
-// always destroyed its graphs there); the list is short: a regrowth retires at most the six cache entries, and the cache stops
-// capturing after eight consecutive evictions.
+// the submission path was pinned -- is RETIRED, not destroyed.  Root cause (round 6): hipGraphExecDestroy
+// followed, with no device-wide wait in between, by the capture, instantiation and launch of the next graph crashes inside
+// hipGraphLaunch -- a null node pointer in the runtime's walk over the new graph's nodes -- on the HIP runtime 7.0.51831 that
+// PyTorch 2.10.0+rocm7.0 bundles (torch/lib/libamdhip64.so: the runtime every Python process of this repository binds, tests and
+// bench included), and NOT on the system's ROCm 7.2.0 runtime the C and C++ hosts link.  tools/repro_graph_regrow.hip is the
+// reproducer without library code: `repro_graph_regrow 400 destroy_nosync 3 16` dies with the same runtime frames on PyTorch's
+// runtime and completes on ROCm 7.2's.  With the destroy taken out of the way -- retired graphs die with the handle, after its
+// device-wide wait and with no capture behind them -- re-capturing on regrown buffers is clean (tools/stress_regrow.py with
+// replay kept: 15 of 15 runs of 150 handles; with hipGraphExecDestroy at the regrowth: 11 of 12 runs die), so a regrown handle
+// keeps graph replay.  The list is bounded: beyond AMDAT_MAX_RETIRED_GRAPHS the handle stops capturing new graphs (plain
+// enqueues for the submission shapes it has no graph for; it says so once on stderr and through amdAprilTagsDebugGraphReplay).
+#ifndef AMDAT_MAX_RETIRED_GRAPHS
+#define AMDAT_MAX_RETIRED_GRAPHS 24
+#endif
 static void retire_graph(amdAprilTagsDetector_st* D, amdAprilTagsDetector_st::GraphEntry& g) {
   if (!g.exec) return;
+#ifdef AMDAT_GRAPH_DESTROY_NOW   // (tools build of the crash hunt: what the library did until round 4)
+  hipGraphExecDestroy(g.exec);
+#else
   D->retired_graphs.push_back(g.exec);
+  if (D->retired_graphs.size() > AMDAT_MAX_RETIRED_GRAPHS && D->graph_max_frames) {
+    D->graph_max_frames = 0;   // (the live cache entries keep replaying; nothing new is captured)
+    fprintf(stderr, "[apriltag_amd] handle %p: %zu retired launch graphs -- no new graphs are captured from here on (plain enqueues "
+                    "for submission shapes without one)\n", (void*)D, D->retired_graphs.size());
+  }
+#endif
   g.exec = nullptr;
 }
 static void drop_graphs(amdAprilTagsDetector_st* D) {
   for (auto& g : D->graphs) retire_graph(D, g);
 }
-// ... and a handle whose capacities had to grow gives graph replay up for good (plain enqueues from then on: a one-frame call of
-// such a handle costs ~0.1 ms more).  Capturing, instantiating and launching a NEW graph on a handle right after its buffers were
-// reallocated is what the crash needs: with replay given up after the first regrowth the stress loop and the suite are clean
-// (DESIGN.md section 5), with the graphs merely retired -- and re-captured -- 4 of 6 stress runs still died.
+// A capacity grew: the captured launches carry the old pointers and capacities.  The next submission of each shape is captured
+// again on the new buffers (rounds 4 and 5 gave replay up for good here, at ~0.1 ms per later one-frame call; see retire_graph).
 static void drop_graphs_for_regrowth(amdAprilTagsDetector_st* D) {
   drop_graphs(D);
+#ifdef AMDAT_REGROW_DROPS_REPLAY   // (tools build: round 5's behaviour)
   D->graph_max_frames = 0;
+#endif
 }
 
 // One pass of a submission over the device: captured-graph replay for small submissions, plain enqueues otherwise.
 // launch_once enqueues it and returns; finish_once waits for it (and reads the stage events when profiling is on).
-static int launch_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s) {
+static int launch_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s, uint32_t fmt) {
+  D->launched_fmt = fmt;
   D->seq++;
   for (uint32_t i = 0; i < n; i++) D->h_frames[i].seq = D->seq;   // (k_prologue reads the pinned block when the launch executes)
   D->launched_n = n;
@@ -1158,14 +1287,14 @@ static int launch_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride,
   // handful of instantiated graphs is kept (a host that alternates batch sizes or streams would otherwise re-capture on
   // every call, far slower than the plain enqueues the graph replaces); after a few consecutive misses with the cache
   // full, or one failed capture, the handle falls back to plain enqueues for good.
-  if (D->graph_max_frames && n <= D->graph_max_frames && !prof && D->path_mode != AMDAT_PATH_THROUGHPUT) {
+  if (n <= 8 && !prof && D->path_mode != AMDAT_PATH_THROUGHPUT) {
     amdAprilTagsDetector_st::GraphEntry* hit = nullptr;
     for (auto& g : D->graphs)
-      if (g.exec && g.n == n && g.ostride == ostride && g.stream == s) hit = &g;
+      if (g.exec && g.n == n && g.ostride == ostride && g.stream == s && g.fmt == fmt) hit = &g;
     if (hit) {
       D->graph_misses = 0;
       hit->last_use = ++D->graph_clock;
-    } else if (D->graph_misses < 8) {
+    } else if (D->graph_max_frames && n <= D->graph_max_frames && D->graph_misses < 8) {
       amdAprilTagsDetector_st::GraphEntry* slot = nullptr;
       for (auto& g : D->graphs) if (!g.exec) { slot = &g; break; }
       if (!slot) {   // evict the least recently used entry
@@ -1177,13 +1306,13 @@ static int launch_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride,
       hipGraph_t graph = nullptr;
       bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
       if (ok) {
-        const int rc = enqueue_submission(D, n, ostride, s, nomark);
+        const int rc = enqueue_submission(D, n, ostride, s, fmt, nomark);
         const hipError_t e = hipStreamEndCapture(s, &graph);
         ok = rc == AMDAT_SUCCESS && e == hipSuccess && graph != nullptr;
       }
       if (ok) ok = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess;
       if (graph) hipGraphDestroy(graph);
-      if (ok) { slot->n = n; slot->ostride = ostride; slot->stream = s; slot->last_use = ++D->graph_clock; hit = slot; }
+      if (ok) { slot->n = n; slot->ostride = ostride; slot->fmt = fmt; slot->stream = s; slot->last_use = ++D->graph_clock; hit = slot; }
       else {
         (void)hipGetLastError();
         slot->exec = nullptr;
@@ -1196,7 +1325,7 @@ static int launch_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride,
     }
   }
   {
-    const int rc = enqueue_submission(D, n, ostride, s, mark);
+    const int rc = enqueue_submission(D, n, ostride, s, fmt, mark);
     if (rc) return rc;
   }
   D->events_recorded = prof;
@@ -1238,12 +1367,13 @@ static int finish_once(amdAprilTagsDetector_st* D, hipStream_t s) {
 // begin_batch fills the descriptor block and enqueues the submission; end_batch waits for it, and where a frame overflowed a
 // capacity the handle may grow, grows it and runs the submission again (the descriptors are still in the pinned block).
 static int begin_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images,
-                       const amdAprilTagsCameraIntrinsics_t* intr, uint32_t ostride, hipStream_t s) {
+                       const amdAprilTagsCameraIntrinsics_t* intr, uint32_t ostride, hipStream_t s, uint32_t fmt = AMDAT_ENC_MONO8) {
   if (D->inflight.active) return AMDAT_INVALID_ARGUMENT;   // one submission per handle at a time (amdAprilTagsWaitBatch first)
   DeviceGuard guard(D->device);
   if (!guard.ok) return AMDAT_HIP_ERROR;
   if (D->unusable) return AMDAT_OUT_OF_MEMORY;   // (never launch on the half-allocated buffers of a failed regrowth)
-  fill_frames(D, n, images, intr);   // image pointers, pitches and intrinsics travel through the pinned descriptor block
+  { const int crc = ensure_colour_plane(D, fmt); if (crc) return crc; }
+  fill_frames(D, n, images, intr, fmt);   // image pointers, pitches and intrinsics travel through the pinned descriptor block
   D->last_n = n;
   D->last_path = small_submission(D, D->P, n) ? AMDAT_PATH_LATENCY : AMDAT_PATH_THROUGHPUT;
   if (ostride > D->P.dcap) ostride = D->P.dcap;
@@ -1263,7 +1393,7 @@ static int begin_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTag
   }
   if (D->tables_dirty) { const int crc = clear_hash_tables(D); if (crc) return crc; }
   D->tables_dirty = true;
-  const int rc = launch_once(D, n, ostride, s);
+  const int rc = launch_once(D, n, ostride, s, fmt);
   if (rc) return rc;
   D->inflight.active = true; D->inflight.n = n; D->inflight.ostride = ostride; D->inflight.stream = s;
   return AMDAT_SUCCESS;
@@ -1339,14 +1469,14 @@ static int end_batch(amdAprilTagsDetector_st* D) {
     // run the submission again on the grown buffers
     if (D->tables_dirty) { const int crc = clear_hash_tables(D); if (crc) return crc; }
     D->tables_dirty = true;
-    const int lrc = launch_once(D, n, ostride, s);
+    const int lrc = launch_once(D, n, ostride, s, D->launched_fmt);
     if (lrc) return lrc;
   }
 }
 
 static int run_batch(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTagsImageInput_t* images,
-                     const amdAprilTagsCameraIntrinsics_t* intr, uint32_t ostride, hipStream_t s) {
-  const int rc = begin_batch(D, n, images, intr, ostride, s);
+                     const amdAprilTagsCameraIntrinsics_t* intr, uint32_t ostride, hipStream_t s, uint32_t fmt = AMDAT_ENC_MONO8) {
+  const int rc = begin_batch(D, n, images, intr, ostride, s, fmt);
   return rc ? rc : end_batch(D);
 }
 
@@ -1360,18 +1490,24 @@ static void copy_out_ex(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride
   }
 }
 
-int amdAprilTagsDetectBatchEx(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
-                              const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics, amdAprilTagsDetectionEx_t* dets_out,
-                              uint32_t* num_dets, uint32_t max_dets, amdAprilTagsStream stream) {
+int amdAprilTagsDetectBatchColorEx(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images, amdAprilTagsEncoding encoding,
+                                   const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics, amdAprilTagsDetectionEx_t* dets_out,
+                                   uint32_t* num_dets, uint32_t max_dets, amdAprilTagsStream stream) {
   if (!handle || !dets_out || !num_dets || max_dets == 0) return AMDAT_INVALID_ARGUMENT;
-  int rc = check_images(handle, n, images);
+  int rc = check_images(handle, n, images, (uint32_t)encoding);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : handle->own_stream;
   uint32_t ostride = max_dets < handle->P.dcap ? max_dets : handle->P.dcap;
-  rc = run_batch(handle, n, images, per_frame_intrinsics, ostride, s);
+  rc = run_batch(handle, n, images, per_frame_intrinsics, ostride, s, (uint32_t)encoding);
   if (rc) return rc;
   copy_out_ex(handle, n, ostride, max_dets, dets_out, num_dets);
   return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsDetectBatchEx(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
+                              const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics, amdAprilTagsDetectionEx_t* dets_out,
+                              uint32_t* num_dets, uint32_t max_dets, amdAprilTagsStream stream) {
+  return amdAprilTagsDetectBatchColorEx(handle, n, images, AMDAT_ENC_MONO8, per_frame_intrinsics, dets_out, num_dets, max_dets, stream);
 }
 
 static void to_public(const DetRec& d, uint16_t family_enum, uint32_t corner_convention, amdAprilTagsID_t* o) {
@@ -1404,18 +1540,29 @@ static void copy_out_public(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ost
   }
 }
 
-int amdAprilTagsDetectBatch(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
-                            const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics, amdAprilTagsID_t* tags_out,
-                            uint32_t* num_tags, uint32_t max_tags, amdAprilTagsStream stream) {
+int amdAprilTagsDetectBatchColor(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images, amdAprilTagsEncoding encoding,
+                                 const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics, amdAprilTagsID_t* tags_out,
+                                 uint32_t* num_tags, uint32_t max_tags, amdAprilTagsStream stream) {
   if (!handle || !tags_out || !num_tags || max_tags == 0) return AMDAT_INVALID_ARGUMENT;
-  int rc = check_images(handle, n, images);
+  int rc = check_images(handle, n, images, (uint32_t)encoding);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : handle->own_stream;
   uint32_t ostride = max_tags < handle->P.dcap ? max_tags : handle->P.dcap;
-  rc = run_batch(handle, n, images, per_frame_intrinsics, ostride, s);
+  rc = run_batch(handle, n, images, per_frame_intrinsics, ostride, s, (uint32_t)encoding);
   if (rc) return rc;
   copy_out_public(handle, n, ostride, max_tags, tags_out, num_tags);
   return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsDetectBatch(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
+                            const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics, amdAprilTagsID_t* tags_out,
+                            uint32_t* num_tags, uint32_t max_tags, amdAprilTagsStream stream) {
+  return amdAprilTagsDetectBatchColor(handle, n, images, AMDAT_ENC_MONO8, per_frame_intrinsics, tags_out, num_tags, max_tags, stream);
+}
+
+int amdAprilTagsDetectColor(amdAprilTagsHandle handle, const amdAprilTagsImageInput_t* img_input, amdAprilTagsEncoding encoding,
+                            amdAprilTagsID_t* tags_out, uint32_t* num_tags, uint32_t max_tags, amdAprilTagsStream stream) {
+  return amdAprilTagsDetectBatchColor(handle, 1, img_input, encoding, nullptr, tags_out, num_tags, max_tags, stream);
 }
 
 // ---- the same submission in two halves: enqueue, then wait -------------------------------------------------------------
@@ -1423,17 +1570,22 @@ int amdAprilTagsDetectBatch(amdAprilTagsHandle handle, uint32_t n, const amdApri
 // batch's frames to the device on a stream of its own, to serve other handles -- until amdAprilTagsWaitBatch[Ex] blocks for
 // the results.  One submission per handle may be in flight; the images (and their device buffers) must stay valid until the
 // wait returns.  Submit + Wait gives exactly what the blocking call gives (the blocking call IS the two, back to back).
-int amdAprilTagsSubmitBatch(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
-                            const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics, uint32_t max_tags, amdAprilTagsStream stream) {
+int amdAprilTagsSubmitBatchColor(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images, amdAprilTagsEncoding encoding,
+                                 const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics, uint32_t max_tags, amdAprilTagsStream stream) {
   if (!handle || max_tags == 0) return AMDAT_INVALID_ARGUMENT;
-  int rc = check_images(handle, n, images);
+  int rc = check_images(handle, n, images, (uint32_t)encoding);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : handle->own_stream;
   const uint32_t ostride = max_tags < handle->P.dcap ? max_tags : handle->P.dcap;
-  rc = begin_batch(handle, n, images, per_frame_intrinsics, ostride, s);
+  rc = begin_batch(handle, n, images, per_frame_intrinsics, ostride, s, (uint32_t)encoding);
   if (rc) return rc;
   handle->inflight.max_out = max_tags;
   return AMDAT_SUCCESS;
+}
+
+int amdAprilTagsSubmitBatch(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
+                            const amdAprilTagsCameraIntrinsics_t* per_frame_intrinsics, uint32_t max_tags, amdAprilTagsStream stream) {
+  return amdAprilTagsSubmitBatchColor(handle, n, images, AMDAT_ENC_MONO8, per_frame_intrinsics, max_tags, stream);
 }
 
 int amdAprilTagsWaitBatch(amdAprilTagsHandle handle, amdAprilTagsID_t* tags_out, uint32_t* num_tags) {
@@ -1473,17 +1625,25 @@ int amdAprilTagsGetFrameFlags(amdAprilTagsHandle handle, uint32_t* flags, uint32
 
 int amdAprilTagsThresholdOnly(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images,
                               amdAprilTagsStream stream) {
+  return amdAprilTagsThresholdOnlyColor(handle, n, images, AMDAT_ENC_MONO8, stream);
+}
+
+int amdAprilTagsThresholdOnlyColor(amdAprilTagsHandle handle, uint32_t n, const amdAprilTagsImageInput_t* images, amdAprilTagsEncoding encoding,
+                                   amdAprilTagsStream stream) {
   if (!handle || handle->inflight.active) return AMDAT_INVALID_ARGUMENT;
-  int rc = check_images(handle, n, images);
+  const uint32_t fmt = (uint32_t)encoding;
+  int rc = check_images(handle, n, images, fmt);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : handle->own_stream;
   DeviceGuard guard(handle->device);
   if (!guard.ok) return AMDAT_HIP_ERROR;
-  fill_frames(handle, n, images, nullptr);
+  rc = ensure_colour_plane(handle, fmt);
+  if (rc) return rc;
+  fill_frames(handle, n, images, nullptr, fmt);
   handle->last_n = n;
   HIP_TRY(hipMemcpyAsync(handle->d_frames, handle->h_frames, n * sizeof(FrameDesc), hipMemcpyHostToDevice, s));
   if (handle->profiling) hipEventRecord(handle->ev[1], s);
-  { DetParams P0 = handle->P; P0.frame0 = 0; launch_threshold(handle, P0, n, s); }
+  { DetParams P0 = handle->P; P0.frame0 = 0; launch_threshold(handle, P0, n, s, fmt); }
   if (handle->profiling) hipEventRecord(handle->ev[2], s);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));
@@ -1555,6 +1715,27 @@ int amdAprilTagsCopyToDevice(void* dst_dev, const void* src_host, size_t bytes, 
   if (!dst_dev || !src_host) return AMDAT_INVALID_ARGUMENT;
   HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return AMDAT_SUCCESS;
+}
+
+// enqueue-only copy + stream helpers for hosts that do not link the HIP runtime (the node shell): the copy is ordered on `stream`
+// ahead of the detection the host enqueues on the same stream, and the detection's own wait covers it -- no second host wait
+int amdAprilTagsCopyToDeviceAsync(void* dst_dev, const void* src_host, size_t bytes, amdAprilTagsStream stream) {
+  if (!dst_dev || !src_host || !stream) return AMDAT_INVALID_ARGUMENT;
+  HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return AMDAT_SUCCESS;
+}
+int amdAprilTagsStreamCreate(amdAprilTagsStream* stream) {
+  if (!stream) return AMDAT_INVALID_ARGUMENT;
+  hipStream_t s = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = (amdAprilTagsStream)s;
+  return AMDAT_SUCCESS;
+}
+int amdAprilTagsStreamDestroy(amdAprilTagsStream stream) {
+  if (!stream) return AMDAT_INVALID_ARGUMENT;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  HIP_TRY(hipStreamDestroy((hipStream_t)stream));
   return AMDAT_SUCCESS;
 }
 

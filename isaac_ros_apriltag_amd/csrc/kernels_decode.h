@@ -198,8 +198,19 @@ __global__ __launch_bounds__(64) void k_reconcile(const FrameDesc* __restrict__ 
     pose_from_homography_dev(d.H, fd.fx, fd.fy, fd.cx, fd.cy, fd.skew, P.tag_size, d.R, d.t);
     if (i < host_stride) host_out[(size_t)frame * host_stride + i] = d;
   }
+  // The stamp is the LAST thing the host can see of this launch: every lane's records are out (barrier) and ordered ahead of
+  // it system-wide (fence), then the counters without the stamp, another fence, and the stamp as one store of its own -- a host
+  // that reads the stamp of this launch reads this launch's records and counters.
+  __threadfence_system();
+  __syncthreads();
   if (threadIdx.x == 0) {
+    static_assert(offsetof(FrameCounters, seq) == sizeof(FrameCounters) - 4, "the stamp is the struct's last word");
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&counters[frame]);   // (this block wrote the last field, nout, itself)
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&host_counters[frame]);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(FrameCounters) / 4) - 1; i++) dst[i] = src[i];   // (the previous launch's stamp stays until the store below)
+    __threadfence_system();
+    __hip_atomic_store(&host_counters[frame].seq, fd.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     counters[frame].seq = fd.seq;
-    host_counters[frame] = counters[frame];   // (this block wrote the last fields, nout and seq, itself)
   }
 }

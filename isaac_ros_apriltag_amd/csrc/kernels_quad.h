@@ -403,7 +403,7 @@ __device__ __forceinline__ int fq_sector64(float slope) {
 }
 // fq_feasible over 64 groups for a one-wave workgroup: lane b evaluates the arcs (a, b) of one cut group a per trip, so a
 // ballot is row a of the relation; the path search keeps one 64-bit row per lane.
-template <int ST, int WI>
+template <int ST, int WI, int MUT_EXTRA = 0>   // (MUT_EXTRA: tools_hooks.h, 0 in the product build)
 __device__ __forceinline__ bool fq_feasible64(const double* sP, double mse_limit, int W, int H) {
   const int b = (int)threadIdx.x;   // 0..63
   const double thr = mse_limit * 1.02 + 0.1 + 0x1p-44 * (sP[64 * ST + 2] + sP[64 * ST + 4]) +
@@ -413,7 +413,7 @@ __device__ __forceinline__ bool fq_feasible64(const double* sP, double mse_limit
   for (int a = 0; a < 64; a++) {
     bool okf = true, okw = true;
     if (b >= a) {
-      if (b >= a + 2) okf = fq_arc_possible(sP + (a + 1) * ST, sP + b * ST, nullptr, sP[(b + 1) * ST + WI] - sP[a * ST + WI], thr);
+      if (b >= a + 2) okf = fq_arc_possible(sP + (a + 1 - MUT_EXTRA) * ST, sP + (b + MUT_EXTRA) * ST, nullptr, sP[(b + 1) * ST + WI] - sP[a * ST + WI], thr);
       __builtin_amdgcn_sched_barrier(0);
       okw = fq_arc_possible(sP + (b + 1) * ST, sP + 64 * ST, sP + a * ST, (sP[64 * ST + WI] - sP[b * ST + WI]) + sP[(a + 1) * ST + WI], thr);
     }
@@ -1876,7 +1876,7 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
       reject = !fq_feasible<FQ_PF_NT, 14, 6>(sB, P.max_line_fit_mse, W, H, s_okf, s_okw, &s_feasible);
       PF_TICK(62)
       if (!reject) {   // (one wave evaluates the 64 x 64 relation; a larger workgroup waits for its verdict)
-        if (tid < 64) { const bool f64 = fq_feasible64<7, 6>(sB, P.max_line_fit_mse, W, H); if (tid == 0) s_feasible = f64 ? 1 : 0; }
+        if (tid < 64) { const bool f64 = fq_feasible64<7, 6, PF_MUT_EXTRA_SECTOR(FQ_PF_NT)>(sB, P.max_line_fit_mse, W, H); if (tid == 0) s_feasible = f64 ? 1 : 0; }
         __syncthreads();
         reject = s_feasible == 0;
       }

@@ -18,21 +18,82 @@
 typedef const __attribute__((address_space(1))) uint8_t* th_gimg_t;
 typedef uint32_t th_u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 is a class: no copy out of an address space)
 typedef const __attribute__((address_space(1))) th_u32x4* th_gimg4_t;
+// ---- colour frames as the reference's default path feeds them (rgb8 / bgr8 of its cuAprilTags branch, src/apriltag_node.cpp:469-486;
+// rgba8 / bgra8 of its encoding table, :76-82).  FMT = amdAprilTagsEncoding: 0 mono8, 1 rgb8, 2 bgr8, 3 rgba8, 4 bgra8.  The loader
+// of the one-pass kernel reads the interleaved frame itself and forms the gray value on the fly, the kernel writes the gray plane
+// once (as it does for a decimated image) and thresholds in the same pass: 3 (4) bytes read + 2 written per pixel, instead of a
+// conversion launch (3 + 1) and the mono8 pass (1 + 1) behind it.  Decimation 1 only (the reference's cuAprilTags path has none).
+// Gray value: the fixed-point BT.601 weights of cv_bridge / OpenCV, Y = (4899 R + 9617 G + 1868 B + 8192) >> 14 -- the same
+// statement as k_to_mono8 (detector.hip) -- evaluated with two 4 x u8 dot products per pixel: 4899 = 19 * 256 + 35,
+// 9617 = 37 * 256 + 145, 1868 = 7 * 256 + 76, so Y = ((dot(px, hi) << 8) + dot(px, lo) + 8192) >> 14 exactly; the weight of a
+// fourth byte (alpha, or the next pixel's first byte of a 3-byte format) is 0.
+template <int FMT> struct th_fmt {
+  static constexpr int nch = FMT == 0 ? 1 : (FMT <= 2 ? 3 : 4);
+  static constexpr bool red_first = FMT == 1 || FMT == 3;
+  static constexpr uint32_t w_hi = red_first ? 0x00072513u : 0x00132507u;   // bytes {19, 37, 7} in memory order
+  static constexpr uint32_t w_lo = red_first ? 0x004C9123u : 0x0023914Cu;   // bytes {35, 145, 76}
+};
+template <int FMT>
+__device__ __forceinline__ uint32_t th_gray_of(uint32_t px) {   // px: the pixel's bytes in memory order in bits 0..23
+  const uint32_t lo = __builtin_amdgcn_udot4(px, th_fmt<FMT>::w_lo, 8192u, false);
+  const uint32_t hi = __builtin_amdgcn_udot4(px, th_fmt<FMT>::w_hi, 0u, false);
+  return ((hi << 8) + lo) >> 14;
+}
+
 // one working-image pixel through the decimating gather (slow path: halos, edges, unaligned input)
-template <int DEC>
+template <int DEC, int FMT = 0>
 __device__ __forceinline__ uint32_t th_px(th_gimg_t img, uint32_t pitch, int W0, int H0, int x, int y) {
   int sx = x * DEC, sy = y * DEC;
   if (sx >= W0 || sy >= H0) return 0;
-  return img[(size_t)sy * pitch + sx];
+  if (FMT == 0) return img[(size_t)sy * pitch + sx];
+  th_gimg_t p = img + (size_t)sy * pitch + (size_t)sx * th_fmt<FMT>::nch;
+  return th_gray_of<FMT>((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16));
 }
 
 // loads 16 consecutive working pixels of row y starting at x0 (multiple of 16) into 4 dwords
-template <int DEC>
+template <int DEC, int FMT = 0>
 __device__ __forceinline__ void th_load16(th_gimg_t img, uint32_t pitch, int W0, int H0, bool aligned,
                                           int x0, int y, uint32_t out[4]) {
   int sy = y * DEC;
   if (sy >= H0 || x0 * DEC >= W0) { out[0] = out[1] = out[2] = out[3] = 0; return; }
   th_gimg_t row = img + (size_t)sy * pitch;
+  if (FMT != 0) {   // (DEC == 1) 16 pixels = 48 or 64 consecutive bytes: three or four 16-byte loads, then the dot products
+    constexpr int NCH = th_fmt<FMT>::nch;
+    if (aligned && x0 + 16 <= W0) {
+      uint32_t d[4 * NCH + 1];
+#pragma unroll
+      for (int q = 0; q < NCH; q++) {
+        const th_u32x4 v = *(th_gimg4_t)(row + (size_t)x0 * NCH + 16 * q);
+        d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
+      }
+      d[4 * NCH] = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const int k = 4 * j + b;   // pixel k starts at byte NCH * k of the 16-pixel run
+          const uint32_t px = NCH == 4 ? d[k] : __builtin_amdgcn_alignbyte(d[(3 * k) / 4 + 1], d[(3 * k) / 4], (3 * k) & 3);
+          w |= th_gray_of<FMT>(px) << (8 * b);
+        }
+        out[j] = w;
+      }
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int sx = x0 + 4 * j + b;
+        uint32_t v = 0;
+        if (sx < W0) { th_gimg_t p = row + (size_t)sx * NCH; v = th_gray_of<FMT>((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)); }
+        w |= v << (8 * b);
+      }
+      out[j] = w;
+    }
+    return;
+  }
   if (DEC == 1) {
     if (aligned && x0 + 16 <= W0) {
       const th_u32x4 v = *(th_gimg4_t)(row + x0);
@@ -84,9 +145,10 @@ __device__ __forceinline__ void th_minmax_word(uint32_t w, uint32_t& mn, uint32_
 // row segment.
 #define TH_BTX 256  // tiles per block in x
 #define TH_BTY 8    // tiles per block in y
-template <int DEC>
+template <int DEC, int FMT = 0>
 __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__ frames, uint8_t* __restrict__ gray_all,
                                                    uint8_t* __restrict__ thr_all, int gx, int gy, int nframes, DetParams P) {
+  static_assert(FMT == 0 || DEC == 1, "the colour loader does not decimate");
   __shared__ __attribute__((aligned(16))) uint8_t smin[10 * TH_LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) uint8_t smax[10 * TH_LDS_STRIDE];
 
@@ -99,12 +161,15 @@ __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__
   const int frame = lframe + P.frame0;
   const int bx = trem % gx, by = trem / gx;
   const FrameDesc fd = frames[frame];
-  const bool aligned = ((((uintptr_t)fd.img) | (uintptr_t)fd.pitch) & 15) == 0;
+  // (a colour submission: the loader reads the caller's interleaved frame, fd.img is the handle's gray plane of pitch WS)
+  const th_gimg_t simg = (th_gimg_t)(FMT ? fd.src : fd.img);
+  const uint32_t spitch = FMT ? fd.src_pitch : fd.pitch;
+  const bool aligned = ((((uintptr_t)simg) | (uintptr_t)spitch) & 15) == 0;
   const int tid = threadIdx.x;
   const int tx64 = tid & 63, ty4 = tid >> 6;
   const int TX0 = bx * TH_BTX, TY0 = by * TH_BTY;  // first tile of the block
   uint8_t* thr = thr_all + (size_t)frame * P.H * P.WS;
-  uint8_t* gray = (DEC > 1) ? gray_all + (size_t)frame * P.H * P.WS : nullptr;
+  uint8_t* gray = (DEC > 1) ? gray_all + (size_t)frame * P.H * P.WS : (FMT ? const_cast<uint8_t*>(fd.img) : nullptr);
 
   // ---- own units: 2 x (16 x 4 pixels) ---------------------------------------------------------
   const int ux = (TX0 + 4 * tx64) * 4;
@@ -113,13 +178,13 @@ __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__
   for (int v = 0; v < 2; v++) {
     const int uy = (TY0 + 2 * ty4 + v) * 4;
 #pragma unroll
-    for (int r = 0; r < 4; r++) th_load16<DEC>((th_gimg_t)fd.img, fd.pitch, P.W0, P.H0, aligned, ux, uy + r, u[v][r]);
+    for (int r = 0; r < 4; r++) th_load16<DEC, FMT>(simg, spitch, P.W0, P.H0, aligned, ux, uy + r, u[v][r]);
   }
 #pragma unroll
   for (int v = 0; v < 2; v++) {
     const int lty = 2 * ty4 + v;
     const int tY = TY0 + lty, uy = tY * 4;
-    if (DEC > 1) {
+    if (DEC > 1 || FMT) {
 #pragma unroll
       for (int r = 0; r < 4; r++)
         if (uy + r < P.H && ux < P.WS)
@@ -146,7 +211,7 @@ __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__
     const bool rowok = tY >= 0 && tY < P.th;
     if (rowok) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) th_load16<DEC>((th_gimg_t)fd.img, fd.pitch, P.W0, P.H0, aligned, (TX0 + 4 * c) * 4, tY * 4 + r, h[r]);
+      for (int r = 0; r < 4; r++) th_load16<DEC, FMT>(simg, spitch, P.W0, P.H0, aligned, (TX0 + 4 * c) * 4, tY * 4 + r, h[r]);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -168,7 +233,7 @@ __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__
     if (tX >= 0 && tX < P.tw && tY >= 0 && tY < P.th) {
       for (int r = 0; r < 4; r++)
         for (int c = 0; c < 4; c++) {
-          uint32_t v = th_px<DEC>((th_gimg_t)fd.img, fd.pitch, P.W0, P.H0, tX * 4 + c, tY * 4 + r);
+          uint32_t v = th_px<DEC, FMT>(simg, spitch, P.W0, P.H0, tX * 4 + c, tY * 4 + r);
           mn = min(mn, v);
           mx = max(mx, v);
         }
@@ -252,11 +317,13 @@ __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__
 // Pixels right of / below the last full tile (only when W or H is not a multiple of 4): threshold
 // against the nearest tile's dilated min/max, recomputed from its 12x12 neighbourhood.  No
 // low-contrast rule there.
-template <int DEC>
+template <int DEC, int FMT = 0>
 __global__ __launch_bounds__(256) void k_threshold_leftover(const FrameDesc* __restrict__ frames, uint8_t* __restrict__ gray_all,
                                                             uint8_t* __restrict__ thr_all, DetParams P) {
   const int frame = (int)blockIdx.z + P.frame0;
   const FrameDesc fd = frames[frame];
+  const th_gimg_t simg = (th_gimg_t)(FMT ? fd.src : fd.img);
+  const uint32_t spitch = FMT ? fd.src_pitch : fd.pitch;
   const int nright = P.W - P.tw * 4;  // columns per row in the right strip
   const int nbot = P.H - P.th * 4;    // rows in the bottom strip
   const int right_cnt = nright * (P.th * 4);
@@ -272,14 +339,15 @@ __global__ __launch_bounds__(256) void k_threshold_leftover(const FrameDesc* __r
     for (int tx = max(tX - 1, 0); tx <= min(tX + 1, P.tw - 1); tx++)
       for (int r = 0; r < 4; r++)
         for (int c = 0; c < 4; c++) {
-          uint32_t v = th_px<DEC>((th_gimg_t)fd.img, fd.pitch, P.W0, P.H0, tx * 4 + c, ty * 4 + r);
+          uint32_t v = th_px<DEC, FMT>(simg, spitch, P.W0, P.H0, tx * 4 + c, ty * 4 + r);
           mn = min(mn, v);
           mx = max(mx, v);
         }
   uint32_t thresh = mn + (mx - mn) / 2;
-  uint32_t v = th_px<DEC>((th_gimg_t)fd.img, fd.pitch, P.W0, P.H0, x, y);
+  uint32_t v = th_px<DEC, FMT>(simg, spitch, P.W0, P.H0, x, y);
   thr_all[(size_t)frame * P.H * P.WS + (size_t)y * P.WS + x] = v > thresh ? 255 : 0;
   if (DEC > 1) gray_all[(size_t)frame * P.H * P.WS + (size_t)y * P.WS + x] = (uint8_t)v;
+  // (FMT: the one-pass kernel's units cover these pixels too and have written their gray values)
 }
 
 // ---- tile sizes other than 4 (the reference's settable `tile_size`, src/apriltag_node.cpp:566, handed to the library at

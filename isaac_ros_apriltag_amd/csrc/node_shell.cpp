@@ -36,6 +36,12 @@ struct DetectorApi {
   decltype(&amdAprilTagsDeviceFree) dev_free = nullptr;
   decltype(&amdAprilTagsCopyToDevice) copy_to_device = nullptr;
   decltype(&amdAprilTagsSetFrameSkews) set_frame_skews = nullptr;
+  decltype(&amdAprilTagsDetectColor) detect_color = nullptr;
+  decltype(&amdAprilTagsDetectBatchColor) detect_batch_color = nullptr;
+  decltype(&amdAprilTagsEncodingFromName) encoding_from_name = nullptr;
+  decltype(&amdAprilTagsCopyToDeviceAsync) copy_to_device_async = nullptr;
+  decltype(&amdAprilTagsStreamCreate) stream_create = nullptr;
+  decltype(&amdAprilTagsStreamDestroy) stream_destroy = nullptr;
 };
 
 DetectorApi& api() {
@@ -64,6 +70,12 @@ DetectorApi& api() {
   BIND(dev_free, "amdAprilTagsDeviceFree")
   BIND(copy_to_device, "amdAprilTagsCopyToDevice")
   BIND(set_frame_skews, "amdAprilTagsSetFrameSkews")
+  BIND(detect_color, "amdAprilTagsDetectColor")
+  BIND(detect_batch_color, "amdAprilTagsDetectBatchColor")
+  BIND(encoding_from_name, "amdAprilTagsEncodingFromName")
+  BIND(copy_to_device_async, "amdAprilTagsCopyToDeviceAsync")
+  BIND(stream_create, "amdAprilTagsStreamCreate")
+  BIND(stream_destroy, "amdAprilTagsStreamDestroy")
 #undef BIND
   return a;
 }
@@ -207,8 +219,7 @@ struct AprilTagNode::Impl {
   uint32_t width = 0, height = 0;
   void* d_input = nullptr;   // staging for host images
   size_t d_input_bytes = 0;
-  uint8_t* d_mono = nullptr; // converted mono8 frame
-  size_t d_mono_pitch = 0;
+  amdAprilTagsStream stream = nullptr;   // the host-to-device copy and the detection are ordered on it: one host wait per frame
 
   // exactly {CUDA}: the reference runs cuAprilTags, which decodes tag36h11 only (src/apriltag_node.cpp:429-432)
   bool cuapriltags_mode = false;
@@ -216,7 +227,6 @@ struct AprilTagNode::Impl {
   void Initialize(const Image& image, const CameraInfo& info) {
     if (opt.max_tags <= 0) throw std::runtime_error("'max_tags' must be positive");
     if (detector) { api().destroy(detector); detector = nullptr; }   // left over from a failed attempt
-    if (d_mono) { api().dev_free(d_mono); d_mono = nullptr; }
     // intrinsics from K, double -> float as the reference does (src/apriltag_node.cpp:442-447)
     amdAprilTagsConfig_t cfg;
     api().default_config(&cfg, info.width, info.height);
@@ -239,18 +249,22 @@ struct AprilTagNode::Impl {
     }
     width = info.width;
     height = info.height;
-    d_mono_pitch = (static_cast<size_t>(width) + 63) & ~static_cast<size_t>(63);
-    void* p = nullptr;
-    if (api().dev_alloc(&p, d_mono_pitch * height) != 0) throw std::runtime_error("device allocation failed");
-    d_mono = static_cast<uint8_t*>(p);
+    if (!stream && api().stream_create(&stream) != 0) throw std::runtime_error("stream creation failed");
     initialized = true;   // only now: a failed creation is retried (and reported) on the next frame
     (void)image;
   }
 
   void OnCameraFrame(const Image& image, const CameraInfo& info) {
     const int bpp = bytes_per_pixel(image.encoding);
+    if (cuapriltags_mode && opt.strict_cuapriltags_encodings && image.encoding != "rgb8" && image.encoding != "bgr8") {
+      // the reference's cuAprilTags branch, text and all (src/apriltag_node.cpp:469-476)
+      std::fprintf(stderr, "[apriltag_node] Unsupported image encoding: %s (only 'rgb8' or 'bgr8' supported)\n", image.encoding.c_str());
+      throw std::runtime_error("cuAprilTags detector only supports 'rgb8' or 'bgr8' image input");
+    }
     if (bpp == 0) {
-      std::fprintf(stderr, "[apriltag_node] Unsupported image encoding: %s\n", image.encoding.c_str());
+      // (a superset of the reference's cuAprilTags branch, which takes rgb8 / bgr8 only: NodeOptions::strict_cuapriltags_encodings)
+      std::fprintf(stderr, "[apriltag_node] Unsupported image encoding: %s (supported: 'mono8', 'rgb8', 'bgr8', 'rgba8', 'bgra8'%s)\n",
+                   image.encoding.c_str(), cuapriltags_mode ? "; the reference's cuAprilTags mode takes 'rgb8' / 'bgr8' only" : "");
       throw std::runtime_error("AprilTags detector only supports 'mono8', 'rgb8', 'bgr8', 'rgba8' or 'bgra8' image input");
     }
     // the detector and the conversion buffer are sized from camera_info at initialisation
@@ -270,29 +284,26 @@ struct AprilTagNode::Impl {
         if (api().dev_alloc(&d_input, bytes) != 0) throw std::runtime_error("device allocation failed");
         d_input_bytes = bytes;
       }
-      if (api().copy_to_device(d_input, image.data, bytes, nullptr) != 0) {
+      // enqueue-only, on the stream the detection runs on (image.data stays valid until the detection below has returned)
+      if (api().copy_to_device_async(d_input, image.data, bytes, stream) != 0) {
         std::fprintf(stderr, "[apriltag_node] host-to-device copy failed\n");
         return;
       }
       dev_src = static_cast<const uint8_t*>(d_input);
     }
+    // The frame goes to the detector in the encoding it arrived in -- the reference hands cuAprilTags its rgb8 / bgr8 uchar3 image
+    // (src/apriltag_node.cpp:469-486), its VPI branch converts first (:275-282): here the threshold pass of the one call reads the
+    // interleaved frame itself, there is no conversion launch (and no second device buffer) in between.
     amdAprilTagsImageInput_t input;
     input.width = image.width;
     input.height = image.height;
-    if (bpp == 1) {
-      input.dev_ptr = dev_src;
-      input.pitch = image.step;
-    } else {
-      if (api().to_mono8(dev_src, image.step, image.encoding.c_str(), image.width, image.height, d_mono, d_mono_pitch, nullptr) != 0) {
-        std::fprintf(stderr, "[apriltag_node] colour conversion failed\n");
-        return;
-      }
-      input.dev_ptr = d_mono;
-      input.pitch = d_mono_pitch;
-    }
+    input.dev_ptr = dev_src;
+    input.pitch = image.step;
     uint32_t num_detections = 0;
     std::vector<amdAprilTagsID_t> tags(static_cast<size_t>(opt.max_tags));
-    const int error = api().detect(detector, &input, tags.data(), &num_detections, static_cast<uint32_t>(opt.max_tags), nullptr);
+    const int enc = api().encoding_from_name(image.encoding.c_str());
+    const int error = api().detect_color(detector, &input, static_cast<amdAprilTagsEncoding>(enc), tags.data(), &num_detections,
+                                         static_cast<uint32_t>(opt.max_tags), stream);
     if (error != 0) {
       // the reference logs and drops the frame (src/apriltag_node.cpp:494-497)
       std::fprintf(stderr, "[apriltag_node] Failed to run AprilTags detector (error code %d)\n", error);
@@ -318,8 +329,8 @@ AprilTagNode::AprilTagNode(const NodeOptions& options) : impl_(new Impl()) {
 AprilTagNode::~AprilTagNode() {
   if (impl_) {
     if (impl_->detector) api().destroy(impl_->detector);
+    if (impl_->stream) api().stream_destroy(impl_->stream);
     if (impl_->d_input) api().dev_free(impl_->d_input);
-    if (impl_->d_mono) api().dev_free(impl_->d_mono);
   }
 }
 
@@ -484,7 +495,11 @@ uint32_t AprilTagMultiCameraNode::Flush() {
   if (!I.cuapriltags_mode) {   // every stream's own K[1], as S independent VPI-mode nodes would pass it
     std::vector<float> skews(n);
     for (uint32_t i = 0; i < n; i++) skews[i] = static_cast<float>(I.slots[who[i]].k[1]);
-    api().set_frame_skews(I.detector, n, skews.data());
+    if (api().set_frame_skews(I.detector, n, skews.data()) != 0) {   // (a round whose skews were refused must not run with stale ones)
+      std::fprintf(stderr, "[apriltag_node] per-stream skews refused: round dropped\n");
+      for (uint32_t s : who) I.slots[s].pending = false;
+      return 0;
+    }
   }
   const int error = api().detect_batch(I.detector, n, imgs.data(), intr.data(), tags.data(), counts.data(), max_tags, nullptr);
   for (uint32_t s : who) I.slots[s].pending = false;
@@ -541,6 +556,25 @@ NodeShellHarness* node_shell_create(int max_tags, double size, int tile_size, co
     NodeOptions o;
     o.max_tags = max_tags; o.size = size; o.tile_size = static_cast<uint16_t>(tile_size);
     o.tag_family = tag_family; o.backends = backends; o.decimate = static_cast<uint32_t>(decimate);
+    auto* h = new NodeShellHarness();
+    h->node.reset(new AprilTagNode(o));
+    h->node->set_detections_callback([h](const AprilTagDetectionArray& m) { h->last = m; h->publishes++; });
+    h->node->set_transforms_callback([h](const std::vector<TransformStamped>& t) { h->last_tf = t; });
+    return h;
+  } catch (const std::exception& e) {
+    if (err && err_len) { std::strncpy(err, e.what(), err_len - 1); err[err_len - 1] = 0; }
+    return nullptr;
+  }
+}
+
+// the same with NodeOptions::strict_cuapriltags_encodings set
+NodeShellHarness* node_shell_create_strict(int max_tags, double size, int tile_size, const char* tag_family, const char* backends,
+                                           int decimate, char* err, size_t err_len) {
+  try {
+    NodeOptions o;
+    o.max_tags = max_tags; o.size = size; o.tile_size = static_cast<uint16_t>(tile_size);
+    o.tag_family = tag_family; o.backends = backends; o.decimate = static_cast<uint32_t>(decimate);
+    o.strict_cuapriltags_encodings = true;
     auto* h = new NodeShellHarness();
     h->node.reset(new AprilTagNode(o));
     h->node->set_detections_callback([h](const AprilTagDetectionArray& m) { h->last = m; h->publishes++; });

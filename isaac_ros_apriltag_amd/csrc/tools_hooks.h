@@ -11,6 +11,11 @@
 //   -DAMDAT_MUTATE=n        a deliberately WRONG build for tools/mutation_check.sh, which shows that the GPU suite fails on it:
 //                           1 = the launch sequence leaves out k_fit_small (the throughput set's small-cluster fit);
 //                           2 = k_cc_local<4> flags the perimeter on the wrong last row (one row constant off in the 4-wave instance only)
+//                           3 = k_fit_prefilter<64>'s 64-sector test counts one sector too many at either end of every forward arc
+//                               (the cut sectors themselves, which hold the corners): it then "proves" real quads above 2048 points
+//                               impossible and drops them
+//                           the GPU suite ships all three (build.py: build_mutants) and asserts that its stage tests FAIL on each
+//                           (tests/test_gpu_parity.py::test_the_suite_fails_on_wrong_builds)
 // The stop builds key on P.max_nmaxima == 10 (always true) so that the compiler cannot fold the early exit at compile time
 // into dead-code elimination of the phases before it.
 #pragma once
@@ -114,6 +119,11 @@
 
 // ---- the SOUND early exits of the quad fit can be compiled out, one by one, to show that no result depends on them
 // (-DAMDAT_FQ_NO_PRESORT_EXIT, -DAMDAT_FQ_NO_EARLY_EXIT, -DAMDAT_FQ_NO_PREFILTER: the A/B builds give the same bytes) ---------
+#if defined(AMDAT_MUTATE) && AMDAT_MUTATE == 3
+#define PF_MUT_EXTRA_SECTOR(nt) ((nt) == 64 ? 1 : 0)
+#else
+#define PF_MUT_EXTRA_SECTOR(nt) 0
+#endif
 #ifdef AMDAT_FQ_NO_PRESORT_EXIT
 #define FQ_SOUND_EXIT_PRESORT 0
 #else

@@ -11,21 +11,27 @@ import numpy as np
 from . import capi
 
 
-def _as_images(frames, width, height):
-    """frames: torch uint8 CUDA tensor [n,H,W] / [H,W], or a list of such 2-D tensors, or a list of
-    (dev_ptr, pitch) pairs.  Returns (ctypes array, keepalive)."""
+def _as_images(frames, width, height, channels=1):
+    """frames: torch uint8 CUDA tensor [n,H,W] / [H,W] (colour: [n,H,W,C] / [H,W,C], interleaved), or a list of such tensors,
+    or a list of (dev_ptr, pitch) pairs.  Returns (ctypes array, keepalive)."""
     items = []
     if hasattr(frames, "data_ptr"):
         t = frames
-        if t.dim() == 2:
+        if t.dim() == (2 if channels == 1 else 3):
             t = t.unsqueeze(0)
-        assert t.dim() == 3 and t.stride(2) == 1, "expected [n,H,W] mono8 with unit pixel stride"
+        if channels == 1:
+            assert t.dim() == 3 and t.stride(2) == 1, "expected [n,H,W] mono8 with unit pixel stride"
+        else:
+            assert t.dim() == 4 and t.shape[3] == channels and t.stride(3) == 1 and t.stride(2) == channels, "expected [n,H,W,C] interleaved"
         for i in range(t.shape[0]):
             items.append((t[i].data_ptr(), t.stride(1)))
     else:
         for f in frames:
             if hasattr(f, "data_ptr"):
-                assert f.dim() == 2 and f.stride(1) == 1
+                if channels == 1:
+                    assert f.dim() == 2 and f.stride(1) == 1
+                else:
+                    assert f.dim() == 3 and f.shape[2] == channels and f.stride(2) == 1 and f.stride(1) == channels
                 items.append((f.data_ptr(), f.stride(0)))
             else:
                 items.append((int(f[0]), int(f[1])))
@@ -77,16 +83,21 @@ class AprilTagDetector:
             pass
 
     # ---- detection --------------------------------------------------------------------------------
-    def detect_batch_ex(self, frames, max_dets=64, intrinsics=None, stream=None):
-        imgs, keep = _as_images(frames, self.width, self.height)
+    def detect_batch_ex(self, frames, max_dets=64, intrinsics=None, stream=None, encoding="mono8"):
+        """encoding != "mono8": frames are interleaved colour ([n,H,W,C]) and go through amdAprilTagsDetectBatchColorEx."""
+        imgs, keep = _as_images(frames, self.width, self.height, capi.ENC_CHANNELS[encoding])
         n = len(imgs)
         out = (capi.DetectionEx * (n * max_dets))()
         cnt = (C.c_uint32 * n)()
         intr = None
         if intrinsics is not None:
             intr = (capi.Intrinsics * n)(*[capi.Intrinsics(*[float(v) for v in k]) for k in intrinsics])
-        capi._check("amdAprilTagsDetectBatchEx",
-                    self._L.amdAprilTagsDetectBatchEx(self._h, n, imgs, intr, out, cnt, max_dets, stream))
+        if encoding == "mono8":
+            capi._check("amdAprilTagsDetectBatchEx",
+                        self._L.amdAprilTagsDetectBatchEx(self._h, n, imgs, intr, out, cnt, max_dets, stream))
+        else:
+            capi._check("amdAprilTagsDetectBatchColorEx",
+                        self._L.amdAprilTagsDetectBatchColorEx(self._h, n, imgs, capi.ENCODINGS[encoding], intr, out, cnt, max_dets, stream))
         res = []
         for f in range(n):
             dets = []
@@ -101,24 +112,33 @@ class AprilTagDetector:
         return res
 
     # ---- prepared submissions: argument marshalling done once, the timed call is only the C ABI call ----
-    def prepare(self, frames, max_dets=64, intrinsics=None):
-        imgs, keep = _as_images(frames, self.width, self.height)
+    def prepare(self, frames, max_dets=64, intrinsics=None, encoding="mono8"):
+        imgs, keep = _as_images(frames, self.width, self.height, capi.ENC_CHANNELS[encoding])
         n = len(imgs)
         intr = None
         if intrinsics is not None:
             assert len(intrinsics) == n
             intr = (capi.Intrinsics * n)(*[capi.Intrinsics(*[float(v) for v in k]) for k in intrinsics])
-        return {"imgs": imgs, "keep": keep, "n": n, "max_dets": max_dets, "intr": intr,
+        return {"imgs": imgs, "keep": keep, "n": n, "max_dets": max_dets, "intr": intr, "enc": capi.ENCODINGS[encoding],
                 "out": (capi.DetectionEx * (n * max_dets))(), "cnt": (C.c_uint32 * n)()}
 
     def run_prepared(self, prep, stream=None):
         """One blocking amdAprilTagsDetectBatchEx call; results stay in prep['out'] / prep['cnt']."""
+        if prep.get("enc", 0):
+            capi._check("amdAprilTagsDetectBatchColorEx",
+                        self._L.amdAprilTagsDetectBatchColorEx(self._h, prep["n"], prep["imgs"], prep["enc"], prep.get("intr"), prep["out"],
+                                                               prep["cnt"], prep["max_dets"], stream))
+            return
         capi._check("amdAprilTagsDetectBatchEx",
                     self._L.amdAprilTagsDetectBatchEx(self._h, prep["n"], prep["imgs"], prep.get("intr"), prep["out"],
                                                       prep["cnt"], prep["max_dets"], stream))
 
     def submit_prepared(self, prep, stream=None):
         """amdAprilTagsSubmitBatch: enqueues and returns; wait_prepared() collects (results in prep['out'] / prep['cnt'])."""
+        if prep.get("enc", 0):
+            capi._check("amdAprilTagsSubmitBatchColor",
+                        self._L.amdAprilTagsSubmitBatchColor(self._h, prep["n"], prep["imgs"], prep["enc"], prep.get("intr"), prep["max_dets"], stream))
+            return
         capi._check("amdAprilTagsSubmitBatch",
                     self._L.amdAprilTagsSubmitBatch(self._h, prep["n"], prep["imgs"], prep.get("intr"), prep["max_dets"], stream))
 
@@ -153,9 +173,13 @@ class AprilTagDetector:
                     self._L.amdAprilTagsDetectBatch(self._h, n, imgs, intr, out, cnt, max_tags, stream))
         return out, [int(c) for c in cnt]
 
-    def threshold_only(self, frames, stream=None):
-        imgs, keep = _as_images(frames, self.width, self.height)
-        capi._check("amdAprilTagsThresholdOnly", self._L.amdAprilTagsThresholdOnly(self._h, len(imgs), imgs, stream))
+    def threshold_only(self, frames, stream=None, encoding="mono8"):
+        imgs, keep = _as_images(frames, self.width, self.height, capi.ENC_CHANNELS[encoding])
+        if encoding == "mono8":
+            capi._check("amdAprilTagsThresholdOnly", self._L.amdAprilTagsThresholdOnly(self._h, len(imgs), imgs, stream))
+        else:
+            capi._check("amdAprilTagsThresholdOnlyColor",
+                        self._L.amdAprilTagsThresholdOnlyColor(self._h, len(imgs), imgs, capi.ENCODINGS[encoding], stream))
 
     # ---- measurement / inspection ---------------------------------------------------------------------
     def set_profiling(self, enable=True):
@@ -169,6 +193,12 @@ class AprilTagDetector:
 
     def late_waits(self):
         return int(self._L.amdAprilTagsDebugLateWaits(self._h))
+
+    def graph_replay(self):
+        """(still capturing new launch graphs?, live cache entries, retired graphs) -- include/apriltag_amd_debug.h."""
+        live, ret = C.c_uint32(), C.c_uint32()
+        on = self._L.amdAprilTagsDebugGraphReplay(self._h, C.byref(live), C.byref(ret))
+        return bool(on), int(live.value), int(ret.value)
 
     def last_submission_path(self):
         return {capi.PATH_AUTO: "none", capi.PATH_LATENCY: "latency", capi.PATH_THROUGHPUT: "throughput"}[

@@ -27,6 +27,8 @@ def lib():
         L = C.CDLL(path)
         L.node_shell_create.restype = C.c_void_p
         L.node_shell_create.argtypes = [C.c_int, C.c_double, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
+        L.node_shell_create_strict.restype = C.c_void_p
+        L.node_shell_create_strict.argtypes = L.node_shell_create.argtypes
         L.node_shell_destroy.argtypes = [C.c_void_p]
         L.node_shell_on_frame.restype = C.c_int
         L.node_shell_on_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -112,10 +114,12 @@ class AprilTagMultiCameraNode:
 class AprilTagNode:
     """Parameters and defaults of the reference node (apriltag_node.cpp:564-568)."""
 
-    def __init__(self, max_tags=64, size=0.22, tile_size=4, tag_family="tag36h11", backends="CUDA", decimate=1):
+    def __init__(self, max_tags=64, size=0.22, tile_size=4, tag_family="tag36h11", backends="CUDA", decimate=1,
+                 strict_cuapriltags_encodings=False):
         err = C.create_string_buffer(1024)
         self._L = lib()
-        self._h = self._L.node_shell_create(max_tags, size, tile_size, tag_family.encode(), backends.encode(), decimate, err, 1024)
+        create = self._L.node_shell_create_strict if strict_cuapriltags_encodings else self._L.node_shell_create
+        self._h = create(max_tags, size, tile_size, tag_family.encode(), backends.encode(), decimate, err, 1024)
         if not self._h:
             raise RuntimeError(err.value.decode())
         self.max_tags = max_tags

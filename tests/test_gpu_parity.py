@@ -176,15 +176,18 @@ def test_throughput_set_decimate2_and_two_families(built, families, decimate, sc
     ("noise_ragged", lambda: (np.random.default_rng(8).integers(0, 256, size=(477, 635), dtype=np.uint8), synth.default_K(635, 477)), 1),
     ("noise_ragged_dec3", lambda: (np.random.default_rng(9).integers(0, 256, size=(203, 301), dtype=np.uint8), synth.default_K(301, 203)), 3),
 ])
-def test_tile_size_8(built, name, scene, decimate):
+@pytest.mark.parametrize("path", PATHS)
+def test_tile_size_8(built, name, scene, decimate, path):
     """`tile_size` as the reference declares it (apriltag_node.cpp:566, handed to the library at :451): 8 constructs and detects,
     threshold image and every later stage bit-exact against the oracle run with tile 8 -- config 1, config 2, ragged noise (the
-    pixels right of / below the last full 8 x 8 tile) -- and anything but 4 or 8 is still refused."""
+    pixels right of / below the last full 8 x 8 tile) -- on BOTH launch sets, and anything but 4 or 8 is still refused."""
     r = scene()
     img, K = np.ascontiguousarray(r[0]), r[1]
     h, w = img.shape
     det = AprilTagDetector(w, h, decimate=decimate, intrinsics=_k4(K), max_batch=1, tile_size=8)
+    det.set_submission_path(path)
     g = det.detect_batch_ex(torch.from_numpy(img).cuda(), max_dets=64)[0]
+    assert det.last_submission_path() == path
     errs, odets = pu.compare_stages(det, 0, img, ("tag36h11",), K, decimate, tile_size=8)
     errs += pu.compare_detections(g, odets)
     # the threshold does depend on the tile: the same frame with tile 4 gives another image
@@ -220,16 +223,38 @@ def test_tile_size_8_through_the_node_shell(built):
     n5.close()
 
 
-def test_c3_4k_board_decimate2(built):
+@pytest.mark.parametrize("path", PATHS)
+def test_c3_4k_board_decimate2(built, path):
     img, K, truth, size = synth.scene_c3()
     h, w = img.shape
     det = AprilTagDetector(w, h, families=("tag36h11",), decimate=2, intrinsics=_k4(K), tag_size=size, max_batch=1)
+    det.set_submission_path(path)
     g = det.detect_batch_ex(torch.from_numpy(img).cuda(), max_dets=256)[0]
+    assert det.last_submission_path() == path
     errs, odets = pu.compare_stages(det, 0, img, ("tag36h11",), K, 2, tag_size=size)
     errs += pu.compare_detections(g, odets)
     det.close()
     assert not errs, errs[:5]
     assert sorted(d["id"] for d in g) == list(range(100))
+
+
+def test_c3_ten_4k_boards_in_one_submission(built):
+    """Config 3 as the throughput set sees it: TEN distinct 3840 x 2160 boards at decimate 2 in one call --
+    ten 1920 x 1080 working images are beyond the size up to which a submission takes the latency set, so the library itself
+    (path AUTO) runs k_cc_local<4>, k_fit_small, the per-wave prefilter on them -- and every stage of EVERY frame equals the oracle's."""
+    scenes = [synth.scene_c3(seed=500 + 11 * i, sigma=(2.0 if i % 2 else 0.0)) for i in range(10)]
+    K, size = scenes[0][1], scenes[0][3]
+    frames = [np.ascontiguousarray(sc[0]) for sc in scenes]
+    det = AprilTagDetector(3840, 2160, decimate=2, intrinsics=_k4(K), tag_size=size, max_batch=len(frames))
+    res = det.detect_batch_ex(torch.from_numpy(np.stack(frames)).cuda(), max_dets=128)
+    assert det.last_submission_path() == "throughput"
+    assert det.frame_flags(len(frames)) == [0] * len(frames)
+    for i, img in enumerate(frames):
+        errs, odets = pu.compare_stages(det, i, img, ("tag36h11",), K, 2, tag_size=size)
+        errs += pu.compare_detections(res[i], odets)
+        assert not errs, (i, errs[:4])
+        assert sorted(d["id"] for d in res[i]) == list(range(100))
+    det.close()
 
 
 @pytest.mark.parametrize("shape,pitch", [((480, 644), 644), ((477, 635), 640), ((203, 301), 301), ((64, 64), 64), ((33, 70), 83)])
@@ -383,6 +408,103 @@ def test_bgr8_input_through_conversion(built):
     assert [d["id"] for d in g] == [0]
 
 
+def _colour_frame(gray_like, encoding, seed, pitch_pad=0):
+    """A colour frame whose BT.601 gray value is NOT the input (random chroma around it), in the given encoding, with `pitch_pad`
+    bytes of garbage behind every row; returns (host buffer [h, pitch], the numpy-converted gray frame)."""
+    rng = np.random.default_rng(seed)
+    h, w = gray_like.shape
+    nch = capi.ENC_CHANNELS[encoding]
+    order = (0, 1, 2) if encoding in ("rgb8", "rgba8") else (2, 1, 0)
+    base = gray_like.astype(np.int32)
+    rgb = np.stack([np.clip(base + rng.integers(-40, 41, size=(h, w)), 0, 255) for _ in range(3)], axis=2).astype(np.uint8)
+    pitch = w * nch + pitch_pad
+    buf = rng.integers(0, 256, size=(h, pitch), dtype=np.uint8)
+    px = buf[:, :w * nch].reshape(h, w, nch)
+    for c in range(3):
+        px[..., order[c]] = rgb[..., c]
+    return buf, _bt601(rgb)
+
+
+@pytest.mark.parametrize("encoding", ["rgb8", "bgr8", "rgba8", "bgra8"])
+@pytest.mark.parametrize("path", PATHS)
+def test_colour_frames_through_the_fused_threshold_loader(built, encoding, path):
+    """Colour frames as the reference feeds them (apriltag_node.cpp:469-486 rgb8 / bgr8 uchar3; the table of :76-82): one
+    amdAprilTagsDetectBatchColorEx call, no conversion launch -- the threshold pass reads the interleaved frame, writes the gray
+    plane and thresholds.  Gray plane, threshold image and every later stage equal the oracle's run on the numpy-converted
+    frame bit for bit, on both launch sets; config 2 with random chroma (a swapped channel order cannot pass), 16-byte aligned
+    and unaligned pitches."""
+    img, K, _ = synth.scene_c2(seed=1402)
+    for pad in (0, 7):
+        buf, gray = _colour_frame(img, encoding, seed=len(encoding) + pad, pitch_pad=pad)
+        nch = capi.ENC_CHANNELS[encoding]
+        det = AprilTagDetector(1920, 1080, intrinsics=_k4(K), max_batch=1)
+        det.set_submission_path(path)
+        src = torch.from_numpy(buf).cuda()
+        g = det.detect_batch_ex([(src.data_ptr(), buf.shape[1])], max_dets=64, encoding=encoding)[0]
+        errs, odets = pu.compare_stages(det, 0, gray, ("tag36h11",), K)
+        errs += pu.compare_detections(g, odets)
+        # the mono8 call on the converted frame gives the same records, and so does the colour call again (graph replay)
+        g2 = det.detect_batch_ex(torch.from_numpy(gray).cuda(), max_dets=64)[0]
+        g3 = det.detect_batch_ex([(src.data_ptr(), buf.shape[1])], max_dets=64, encoding=encoding)[0]
+        errs += pu.compare_detections(g2, odets) + pu.compare_detections(g3, odets)
+        det.close()
+        assert not errs, (pad, errs[:4])
+        assert len(g) == 10
+
+
+@pytest.mark.parametrize("shape,decimate,tile", [((477, 635), 1, 4), ((203, 301), 1, 4), ((480, 640), 2, 4), ((480, 640), 1, 8),
+                                                 ((36, 52), 1, 4)])
+def test_colour_frames_ragged_decimated_and_tile8(built, shape, decimate, tile):
+    """The colour entry point off the fast case: sizes that are no multiple of 4 or 16 (the slow loader and the leftover
+    kernel read the colour frame too), and the configurations that take the conversion launch inside the submission
+    (decimate 2, tile_size 8).  Random colour noise; every stage against the oracle on the converted frame."""
+    h, w = shape
+    rng = np.random.default_rng(h * 7 + w + decimate + tile)
+    K = synth.default_K(w, h)
+    for encoding in ("bgr8", "rgba8"):
+        nch = capi.ENC_CHANNELS[encoding]
+        buf = rng.integers(0, 256, size=(h, w * nch + 5), dtype=np.uint8)
+        px = buf[:, :w * nch].reshape(h, w, nch)
+        rgb = px[..., :3] if encoding == "rgba8" else px[..., ::-1]
+        gray = _bt601(np.ascontiguousarray(rgb))
+        det = AprilTagDetector(w, h, decimate=decimate, tile_size=tile, intrinsics=_k4(K), max_batch=2)
+        src = torch.from_numpy(buf).cuda()
+        r = det.detect_batch_ex([(src.data_ptr(), buf.shape[1])] * 2, max_dets=64, encoding=encoding)
+        for f in (0, 1):
+            errs, odets = pu.compare_stages(det, f, gray, ("tag36h11",), K, decimate, tile_size=tile)
+            errs += pu.compare_detections(r[f], odets)
+            assert not errs, (encoding, f, errs[:4])
+        det.close()
+
+
+def test_colour_batch_on_the_throughput_set_and_errors(built):
+    """Ten bgr8 1080p frames in one call (path AUTO: the throughput set), every stage of every frame; Submit / Wait with an
+    encoding; and the argument checks of the colour calls."""
+    K = synth.default_K(1920, 1080)
+    pairs = [_colour_frame(synth.scene_c2(seed=1500 + 3 * i)[0], "bgr8", seed=i) for i in range(10)]
+    det = AprilTagDetector(1920, 1080, intrinsics=_k4(K), max_batch=10)
+    srcs = [torch.from_numpy(b).cuda() for b, _ in pairs]
+    frames = [(t.data_ptr(), t.shape[1]) for t in srcs]
+    res = det.detect_batch_ex(frames, max_dets=64, encoding="bgr8")
+    assert det.last_submission_path() == "throughput"
+    _check_every_frame(det, res, [g for _, g in pairs], ("tag36h11",), K)
+    prep = det.prepare(frames, max_dets=64, encoding="bgr8")
+    det.submit_prepared(prep)
+    det.wait_prepared(prep)
+    for a, b in zip(det.unpack(prep), res):
+        assert not pu.compare_detections(a, b)
+    L = capi.lib()
+    assert L.amdAprilTagsEncodingFromName(b"bgr8") == 2 and L.amdAprilTagsEncodingFromName(b"yuv422") == -1
+    imgs = (capi.ImageInput * 1)()
+    imgs[0].width, imgs[0].height, imgs[0].dev_ptr, imgs[0].pitch = 1920, 1080, srcs[0].data_ptr(), 1920 * 3 - 1
+    out, cnt = (capi.TagID * 16)(), (C.c_uint32 * 1)()
+    assert L.amdAprilTagsDetectColor(det._h, imgs, 2, out, cnt, 16, None) == 1      # pitch below three bytes per pixel
+    imgs[0].pitch = 1920 * 3
+    assert L.amdAprilTagsDetectColor(det._h, imgs, 7, out, cnt, 16, None) == 2      # no such encoding
+    assert L.amdAprilTagsDetectColor(det._h, imgs, 2, out, cnt, 16, None) == 0 and cnt[0] == 10
+    det.close()
+
+
 def test_skew_in_pose(built):
     """K[0][1] of the VPI path (apriltag_node.cpp:215-225): bit-identical to the oracle's skewed pose solve, and
     different from the skew-free pose; corners do not depend on the intrinsics."""
@@ -411,12 +533,16 @@ def test_4k_decimate1_batch(built):
     batch = torch.from_numpy(np.stack([img, img2, img, img2])).cuda()
     r = det.detect_batch_ex(batch, max_dets=128)
     assert det.frame_flags(4) == [0, 0, 0, 0]
-    det.close()
+    assert det.last_submission_path() == "throughput"
+    # every stage of the two distinct frames: working images above 2048 x 2048 have no k_fit_small, so all
+    # clusters go through k_fit_quads' classes and the large ones through the per-wave prefilter
     for f, im in ((0, img), (1, img2)):
-        o = po.detect(im, params=pu.oracle_params(K, 1, size))[0]
+        errs, o = pu.compare_stages(det, f, im, ("tag36h11",), K, 1, tag_size=size)
+        assert not errs, (f, errs[:4])
         assert sorted(d["id"] for d in o) == list(range(100))
         assert not pu.compare_detections(r[f], o)
         assert not pu.compare_detections(r[f + 2], o)
+    det.close()
 
 
 def test_batch_properties_full_size(built):
@@ -1231,3 +1357,87 @@ def test_long_staging_records_with_a_short_tile_list(built):
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "--cases", "200", "--seed", "4242"],
                          capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert out.returncode == 0 and "200 cases, 0 failed" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
+def _big_quads_frame(amp, w=1920, h=1080):
+    """Three large dark quadrilaterals on a bright ground -- a 760 x 640 rectangle, a rotated 460-px square and a tilted 920 x 340
+    one -- whose edges ripple with amplitude `amp` pixels, under sigma-1 noise: boundaries of 5 000 .. 8 000 points each, i.e.
+    clusters of the size classes above 2048 points, which go through k_fit_prefilter before their fit.  amp = 0: three clean
+    quads; amp = 3.2: the line fits of the sides come out at a mean square error of about 5 of the 10 a side may have, so the
+    sound sector test has to pass them on a margin a wrong test does not leave."""
+    rng = np.random.default_rng(606)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.full((h, w), 215.0)
+
+    def quad(cx, cy, hw, hh, ang, per):
+        c, s = np.cos(ang), np.sin(ang)
+        u, v = (xx - cx) * c + (yy - cy) * s, -(xx - cx) * s + (yy - cy) * c
+        ru = hw + amp * np.sin(2 * np.pi * v / per)
+        rv = hh + amp * np.sin(2 * np.pi * u / per + 1.0)
+        img[(np.abs(u) < ru) & (np.abs(v) < rv)] = 35
+    quad(470, 400, 380, 320, 0.0, 37.0)
+    quad(1400, 330, 230, 230, 0.5, 29.0)
+    quad(1250, 850, 460, 170, -0.12, 41.0)
+    return np.clip(np.rint(img + rng.normal(0, 1.0, (h, w))), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("amp,nbig", [(0.0, 3), (3.2, 2)])
+def test_large_quads_survive_the_prefilter(built, path, amp, nbig):
+    """Clusters above 2048 points that ARE quads: the sound sector test of k_fit_prefilter (one wave per cluster on the throughput
+    set, a CU-wide workgroup on the latency set) must let every one of them through to its fit -- clean ones and ones whose sides
+    fit a line only just; quads equal the oracle's, and the large ones are among them."""
+    img = _big_quads_frame(amp)
+    K = synth.default_K(1920, 1080)
+    det, g = _run(img, K, path=path)
+    errs, odets = pu.compare_stages(det, 0, img, ("tag36h11",), K, 1)
+    cl = det.debug(0, capi.DBG_CLUSTERS)
+    q = det.debug(0, capi.DBG_QUADS)
+    det.close()
+    assert not errs, errs[:4]
+    big = [i for i in range(len(q)) if np.linalg.norm(q["p"][i][0] - q["p"][i][2]) > 400]
+    assert (cl["count"] > 2048).sum() >= 3 and len(big) == nbig, (sorted(cl["count"])[-5:], len(big))
+
+
+# csrc/tools_hooks.h, -DAMDAT_MUTATE=n -> the test selection that must fail on libapriltag_amd_mut<n>.so
+_MUTANT_SELECTIONS = {
+    1: "test_throughput_set_every_stage_of_every_frame or (test_stage_and_detection_parity and throughput and c2) or "
+       "(test_tile_size_8 and throughput and c2) or (test_colour_frames_through_the_fused_threshold_loader and throughput and bgr8)",
+    2: "test_throughput_set_every_stage_of_every_frame or (test_stage_and_detection_parity and throughput and c2) or "
+       "(test_integer_stages_on_noise_ragged_sizes and throughput and 644)",
+    3: "test_large_quads_survive_the_prefilter",   # (its latency-set cases run the CU-wide prefilter instance and still pass)
+}
+
+
+@pytest.mark.parametrize("mutant", sorted(_MUTANT_SELECTIONS))
+def test_the_suite_fails_on_wrong_builds(built, mutant):
+    """The stage tests BITE: three deliberately wrong builds of the same sources ship next to the product
+    library -- 1: the launch sequence without k_fit_small, 2: one row constant off in k_cc_local<4>, 3: one sector too many in
+    k_fit_prefilter<64>'s test (csrc/tools_hooks.h) -- and a selection of this file's stage tests, run against each in a process
+    of its own, must FAIL, while the same selection passes on the product library.  The latency-set twins of the selected tests
+    must still pass on mutants 1 and 2, whose errors live in the throughput set only."""
+    import subprocess
+    import sys
+    from isaac_ros_apriltag_amd import build as bld
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(bld.lib_mutant(mutant)):
+        bld.build_mutants()
+    sel = _MUTANT_SELECTIONS[mutant]
+
+    def run(lib):
+        env = dict(os.environ)
+        env.pop("AMDAT_LIB", None)
+        if lib:
+            env["AMDAT_LIB"] = lib
+        out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q",
+                              "-p", "no:cacheprovider", "-k", sel], capture_output=True, text=True, timeout=1500, cwd=root, env=env)
+        tail = [l for l in out.stdout.splitlines() if " passed" in l or " failed" in l or l.startswith("FAILED")]
+        return out.returncode, tail, out
+    rc_bad, tail_bad, out_bad = run("mut%d" % mutant)
+    assert rc_bad == 1 and any(" failed" in l for l in tail_bad), (tail_bad, out_bad.stdout[-1500:], out_bad.stderr[-1500:])
+    nfailed = sum(1 for l in tail_bad if l.startswith("FAILED"))
+    assert nfailed >= 2, tail_bad
+    if mutant == 1:   # every selected test fails (none of them can pass without the small-cluster fit)
+        assert not any(" passed" in l and " failed" not in l for l in tail_bad), tail_bad
+    rc_ok, tail_ok, out_ok = run(None)
+    assert rc_ok == 0 and any(" passed" in l for l in tail_ok) and not any(" failed" in l for l in tail_ok), (tail_ok, out_ok.stdout[-1500:])
