@@ -110,7 +110,7 @@ int main(int argc, char** argv) {
   const size_t block_doubles = (size_t)S * 5 + 1;   // parameters + decimate
   for (int i = 0; i < G; i++) {
     CHECK_HIP(hipSetDevice(dev_of(i)));
-    CHECK_HIP(hipStreamCreate(&streams[i]));
+    CHECK_HIP(hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking));
     CHECK_HIP(hipMalloc((void**)&d_block[i], block_doubles * 8));
     CHECK_HIP(hipMemset(d_block[i], 0, block_doubles * 8));
   }
@@ -121,6 +121,7 @@ int main(int argc, char** argv) {
     CHECK_HIP(hipSetDevice(0));
     CHECK_HIP(hipMemcpy(d_block[0], host.data(), block_doubles * 8, hipMemcpyHostToDevice));   // only device 0 holds it
   }
+  for (int i = 0; i < G; i++) { CHECK_HIP(hipSetDevice(dev_of(i))); CHECK_HIP(hipDeviceSynchronize()); }   // the fills above, ahead of the non-blocking streams
   if (rccl) {
     CHECK_NCCL(ncclGroupStart());
     for (int i = 0; i < G; i++) {
@@ -143,7 +144,8 @@ int main(int argc, char** argv) {
     CHECK_HIP(hipSetDevice(dev_of(g)));
     // this GPU's copy of the block, as received through the broadcast
     std::vector<double> blk(block_doubles);
-    CHECK_HIP(hipMemcpy(blk.data(), d_block[g], block_doubles * 8, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpyAsync(blk.data(), d_block[g], block_doubles * 8, hipMemcpyDeviceToHost, streams[g]));
+    CHECK_HIP(hipStreamSynchronize(streams[g]));
     std::vector<int> mine;
     for (int s = 0; s < S; s++) if (s % G == g) mine.push_back(s);
     if (mine.empty()) { bar.wait(); bar.wait(); return; }
@@ -178,7 +180,10 @@ int main(int argc, char** argv) {
       gr.imgs.resize(B); gr.intr.resize(B); gr.tags.resize((size_t)B * max_tags); gr.cnt.resize(B);
       for (size_t k = 0; k < gr.streams.size(); k++) {
         const int s = gr.streams[k];
-        CHECK_HIP(hipMemcpy(gr.d_frames + k * F * fbytes, frames.data() + (size_t)s * F * fbytes, (size_t)F * fbytes, hipMemcpyHostToDevice));
+        // (on the rank's own stream, not the legacy stream: with several ranks on one device -- --shared-gpu -- a legacy-stream copy
+        // of this thread would meet the launch-graph capture of another thread's handle and fail)
+        CHECK_HIP(hipMemcpyAsync(gr.d_frames + k * F * fbytes, frames.data() + (size_t)s * F * fbytes, (size_t)F * fbytes, hipMemcpyHostToDevice, streams[g]));
+        CHECK_HIP(hipStreamSynchronize(streams[g]));
         for (int i = 0; i < F; i++) {
           const size_t b = k * F + i;
           gr.imgs[b] = {(uint32_t)W, (uint32_t)H, gr.d_frames + b * fbytes, (size_t)W};

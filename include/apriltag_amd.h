@@ -142,9 +142,13 @@ typedef struct {
 
 typedef struct {
   uint32_t struct_size;        /* sizeof(amdAprilTagsConfig_t) of the header the caller was built against: set by
-                                * amdAprilTagsDefaultConfig -- every configuration must start from that call.  The struct only ever
-                                * grows at its end: a caller built against an older, shorter header passes its smaller size and
-                                * the fields it does not know keep their defaults; 0, or a size beyond the library's own, is
+                                * amdAprilTagsDefaultConfig -- every configuration must start from that call.  Round 5's header is the
+                                * FIRST versioned layout (struct_size went in at offset 0 then: a one-time ABI break against the
+                                * rounds before it, which had no size field -- binaries built against those headers must be rebuilt;
+                                * amdAprilTagsConfigLayoutVersion() says which layout a library speaks).  From that layout on the
+                                * struct only grows at its end: a caller built against an older, shorter versioned header passes its
+                                * smaller size and the fields it does not know keep their defaults (round 6 appended
+                                * no_graph_replay); a size below the first versioned layout's, or beyond the library's own, is
                                 * AMDAT_INVALID_ARGUMENT (a struct that did not come from amdAprilTagsDefaultConfig). */
   uint32_t width, height;      /* input image size (fixed for the handle, as in the reference) */
   uint32_t tile_size;          /* 4 (src/apriltag_node.cpp:566) or 8; other values: AMDAT_UNSUPPORTED */
@@ -172,11 +176,20 @@ typedef struct {
                                 * AMDAT_CORNERS_ROTATED_180: the other reading of that frame -- corner index turned by two
                                 * (corners[i] = p[(5 - i) & 3]) and the tag frame turned about its normal, R * Rz(pi) -- kept
                                 * selectable until output of the closed library itself is available */
+  uint32_t no_graph_replay;    /* != 0: small submissions are never stream-captured into launch graphs (plain enqueues, ~0.1 ms more per
+                                * one-frame call).  For hosts whose OTHER threads make legacy-stream HIP calls (hipMemcpy, hipMemset on
+                                * stream 0) on the same device while this handle detects: on ROCm 7 such a call fails -- in the host's
+                                * thread -- whenever it meets a capture in progress, whatever the capture mode.  The
+                                * library itself survives the collision either way (the submission goes out uncaptured). */
 } amdAprilTagsConfig_t;
 #define AMDAT_CORNERS_DEFAULT 0u
 #define AMDAT_CORNERS_ROTATED_180 1u
 
 void amdAprilTagsDefaultConfig(amdAprilTagsConfig_t* cfg, uint32_t width, uint32_t height);
+/* Layout generation of amdAprilTagsConfig_t this library was built with: 1 = the first versioned layout (struct_size at offset 0,
+ * fields up to corner_convention), 2 = + no_graph_replay.  Layouts before 1 (no size field) are not accepted. */
+#define AMDAT_CONFIG_LAYOUT_VERSION 2
+uint32_t amdAprilTagsConfigLayoutVersion(void);
 
 /* nvCreateAprilTagsDetector-shaped constructor (one family, batch 1, decimate 1). */
 int amdCreateAprilTagsDetector(amdAprilTagsHandle* handle, uint32_t img_width, uint32_t img_height,

@@ -50,7 +50,8 @@ class Config(C.Structure):
                 ("tag_size", C.c_float), ("max_batch", C.c_uint32), ("refine_edges", C.c_uint32),
                 ("max_hamming", C.c_uint32), ("decode_sharpening", C.c_float), ("max_points", C.c_uint32),
                 ("hash_slots", C.c_uint32), ("max_clusters", C.c_uint32), ("max_quads", C.c_uint32),
-                ("max_detections", C.c_uint32), ("device", C.c_int32), ("skew", C.c_float), ("corner_convention", C.c_uint32)]
+                ("max_detections", C.c_uint32), ("device", C.c_int32), ("skew", C.c_float), ("corner_convention", C.c_uint32),
+                ("no_graph_replay", C.c_uint32)]
 
 
 # every symbol include/apriltag_amd.h declares
@@ -66,7 +67,7 @@ EXPORTS = ["amdAprilTagsDefaultConfig", "amdCreateAprilTagsDetector", "amdCreate
            "amdAprilTagsGetDeviceBytes", "amdAprilTagsDebugSetSubmissionPath", "amdAprilTagsDebugLastSubmissionPath", "amdAprilTagsDebugLateWaits",
            "amdAprilTagsEncodingFromName", "amdAprilTagsDetectColor", "amdAprilTagsDetectBatchColor", "amdAprilTagsDetectBatchColorEx",
            "amdAprilTagsSubmitBatchColor", "amdAprilTagsThresholdOnlyColor", "amdAprilTagsCopyToDeviceAsync", "amdAprilTagsStreamCreate",
-           "amdAprilTagsStreamDestroy", "amdAprilTagsDebugGraphReplay"]
+           "amdAprilTagsStreamDestroy", "amdAprilTagsDebugGraphReplay", "amdAprilTagsConfigLayoutVersion"]
 PATH_AUTO, PATH_LATENCY, PATH_THROUGHPUT = 0, 1, 2
 ENCODINGS = {"mono8": 0, "rgb8": 1, "bgr8": 2, "rgba8": 3, "bgra8": 4}   # amdAprilTagsEncoding
 ENC_CHANNELS = {"mono8": 1, "rgb8": 3, "bgr8": 3, "rgba8": 4, "bgra8": 4}

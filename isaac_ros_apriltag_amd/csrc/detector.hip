@@ -177,6 +177,7 @@ struct amdAprilTagsDetector_st {
   uint32_t* d_label = nullptr;
   uint32_t* d_csize = nullptr;
   uint32_t* d_roots = nullptr;
+  uint32_t* d_perim = nullptr;       // tile perimeters (class + tile-local root per pixel), k_cc_local -> k_cc_border (kernels_cc.h: CcPerim)
   unsigned long long* d_hkeys = nullptr;
   uint32_t* d_hcnt = nullptr;
   uint32_t* d_hoff = nullptr;
@@ -188,7 +189,7 @@ struct amdAprilTagsDetector_st {
   ClusterRec* d_clusters = nullptr;
   uint32_t* d_work = nullptr;        // work lists of the quad fit (all classes, FqWorkLayout)
   bool tables_dirty = false;         // a submission was cut short after k_points: the pair table is not empty
-  uint32_t* d_workctl = nullptr;     // [0..7] items per class, [8..15] pop cursors, [16..23] items per class after k_fit_prefilter
+  uint32_t* d_workctl = nullptr;     // [0..7] items per class, [8..15] pop cursors, [16..23] items per class after k_fit_prefilter, [24] the prefilter's own cursor
   uint32_t* d_work2 = nullptr;       // compact work lists of the prefiltered classes (same layout as d_work)
   unsigned long long* d_keys_scr = nullptr;  // only when a cluster can exceed the LDS key array (large images)
   QuadRec* d_quads = nullptr;
@@ -229,6 +230,7 @@ struct amdAprilTagsDetector_st {
   std::vector<hipGraphExec_t> retired_graphs;   // see drop_graphs
   uint64_t graph_clock = 0;
   uint32_t graph_misses = 0;         // consecutive captures that had to evict an entry
+  uint32_t capture_failures = 0;     // captures that did not end in a graph (recover_from_failed_capture)
   hipEvent_t ev[AMDAT_NUM_STAGES + 1] = {};
   // which launch set a submission gets: by its size (AMDAT_PATH_AUTO) or pinned by amdAprilTagsDebugSetSubmissionPath, so that
   // the parity tests can put BOTH launch sets under the oracle at any frame count
@@ -321,7 +323,10 @@ void amdAprilTagsDefaultConfig(amdAprilTagsConfig_t* cfg, uint32_t width, uint32
   cfg->max_hamming = 2;
   cfg->decode_sharpening = 0.25f;
   cfg->device = -1;
+  cfg->no_graph_replay = 0;
 }
+
+uint32_t amdAprilTagsConfigLayoutVersion(void) { return AMDAT_CONFIG_LAYOUT_VERSION; }
 
 // a registered name must fit the slot's buffer whole (a truncated name could never be found again), and a code word must not
 // carry bits above the family's width (it could never match, and the Hamming search would count the stray bits)
@@ -421,7 +426,7 @@ const char* amdAprilTagsStageName(uint32_t stage) { return stage < AMDAT_NUM_STA
 static void free_all(amdAprilTagsDetector_st* D) {
   for (auto& g : D->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
   for (hipGraphExec_t e : D->retired_graphs) hipGraphExecDestroy(e);
-  hipFree(D->d_gray); hipFree(D->d_conv); hipFree(D->d_thr); hipFree(D->d_tmin); hipFree(D->d_tmax); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_roots); hipFree(D->d_hkeys);
+  hipFree(D->d_gray); hipFree(D->d_conv); hipFree(D->d_thr); hipFree(D->d_tmin); hipFree(D->d_tmax); hipFree(D->d_label); hipFree(D->d_csize); hipFree(D->d_roots); hipFree(D->d_perim); hipFree(D->d_hkeys);
   hipFree(D->d_hcnt); hipFree(D->d_hoff); hipFree(D->d_stage); hipFree(D->d_bhdr); hipFree(D->d_btab); hipFree(D->d_long); hipFree(D->d_pts); hipFree(D->d_clusters);
   hipFree(D->d_work); hipFree(D->d_work2); hipFree(D->d_workctl); hipFree(D->d_keys_scr); hipFree(D->d_quads);
   for (auto& c : D->cls) { hipFree(c.d_lf); hipFree(c.d_errs); }
@@ -444,12 +449,13 @@ static void free_all(amdAprilTagsDetector_st* D) {
 // written here: after (re)allocation, and after a submission that did not run to its end (tables_dirty).
 static int clear_hash_tables(amdAprilTagsDetector_st* D) {
   const size_t B = D->cfg.max_batch;
-  // (null-stream fills and a device-wide wait: this runs at creation and when a capacity changes, never in a steady-state call.
-  // Filling on the handle's own stream instead -- so that a regrowth does not stall the caller's other streams -- was tried in
-  // round 4 and taken out again: the GPU suite crashed once in four runs inside the regrowth test with it, never without.)
-  if (hipMemset(D->d_hkeys, 0xFF, B * (size_t)D->P.hcap * 8) != hipSuccess) return AMDAT_HIP_ERROR;
-  if (hipMemset(D->d_hcnt, 0, B * (size_t)D->P.hcap * 4) != hipSuccess) return AMDAT_HIP_ERROR;
-  if (hipDeviceSynchronize() != hipSuccess) return AMDAT_HIP_ERROR;
+  // (this runs at creation and when a capacity changes, never in a steady-state call.  On the handle's OWN stream, and a wait for
+  // that stream only: a legacy-stream fill would fail -- here, in this thread -- whenever another host thread's handle on the
+  // same device is capturing its launch graph at that moment, and a device-wide wait would stall that thread's streams.  Round 4
+  // had tried this and taken it out again over a crash "inside the regrowth test" that round 6 traced to hipGraphExecDestroy.)
+  if (hipMemsetAsync(D->d_hkeys, 0xFF, B * (size_t)D->P.hcap * 8, D->own_stream) != hipSuccess) return AMDAT_HIP_ERROR;
+  if (hipMemsetAsync(D->d_hcnt, 0, B * (size_t)D->P.hcap * 4, D->own_stream) != hipSuccess) return AMDAT_HIP_ERROR;
+  if (hipStreamSynchronize(D->own_stream) != hipSuccess) return AMDAT_HIP_ERROR;
   D->tables_dirty = false;
   return AMDAT_SUCCESS;
 }
@@ -520,7 +526,8 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   *handle = nullptr;
   // the caller's struct may be an older, shorter one (include/apriltag_amd.h: struct_size): only its own bytes are read, the
   // fields beyond them keep the defaults
-  constexpr uint32_t kMinConfig = (uint32_t)offsetof(amdAprilTagsConfig_t, skew);   // the first published layout ended before `skew`
+  // layout 1 (round 5, the first with a size field) ended behind corner_convention; nothing shorter was ever published with a size
+  constexpr uint32_t kMinConfig = (uint32_t)offsetof(amdAprilTagsConfig_t, no_graph_replay);
   if (cfg_in->struct_size < kMinConfig || cfg_in->struct_size > sizeof(amdAprilTagsConfig_t)) return AMDAT_INVALID_ARGUMENT;
   amdAprilTagsConfig_t cfg;
   amdAprilTagsDefaultConfig(&cfg, 0, 0);
@@ -566,6 +573,8 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
     if (hipGetDeviceProperties(&prop, D->device) == hipSuccess && prop.multiProcessorCount > 0) D->num_cus = prop.multiProcessorCount;
   }
 
+  // (first: every creation-time fill and copy below runs on it -- no legacy-stream call in this library, see clear_hash_tables)
+  if (hipStreamCreateWithFlags(&D->own_stream, hipStreamNonBlocking) != hipSuccess) { delete D; return AMDAT_HIP_ERROR; }
   DetParams& P = D->P;
   memset(&P, 0, sizeof(P));
   P.W0 = (int)cfg.width; P.H0 = (int)cfg.height; P.W = W; P.H = H;
@@ -693,6 +702,7 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   // 252 (perimeter pixels) per tile
   P.rcap = (uint32_t)(((W + CC_T - 1) / CC_T) * ((H + CC_T - 1) / CC_T)) * (4u * CC_T - 4u);
   alloc((void**)&D->d_roots, B * (size_t)P.rcap * 4);
+  alloc((void**)&D->d_perim, B * (size_t)cc_perim_layout(W, H).words * 4);
   if (ok) ok = alloc_hash_buffers(D) == AMDAT_SUCCESS;   // (before the point buffers: it decides the staging format)
   {   // per block (64 x 16 tile) of k_points: header and component-pair table for k_scatter
     const size_t tiles = (size_t)((W + PT_TW - 1) / PT_TW) * (size_t)((H + PT_TH - 1) / PT_TH);
@@ -731,7 +741,8 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   for (int i = 0; ok && i < P.nfam; i++) {
     const std::vector<uint64_t>& codes = fams[i].codes;
     alloc((void**)&D->d_codes[i], codes.size() * 8);
-    if (ok && hipMemcpy(D->d_codes[i], codes.data(), codes.size() * 8, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+    if (ok && (hipMemcpyAsync(D->d_codes[i], codes.data(), codes.size() * 8, hipMemcpyHostToDevice, D->own_stream) != hipSuccess ||
+               hipStreamSynchronize(D->own_stream) != hipSuccess)) ok = false;   // (`fams` is pageable: waited for before it goes)
     P.fam[i].codes = D->d_codes[i];
   }
   // pinned blocks the kernels read (descriptors) and write (records, counters + stamp) over the bus: COHERENT (fine-grained) host
@@ -742,7 +753,6 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   if (ok && hipHostMalloc((void**)&D->h_counters, B * sizeof(FrameCounters), host_flags) != hipSuccess) ok = false;
   if (ok && hipHostMalloc((void**)&D->h_out, B * (size_t)P.dcap * sizeof(DetRec), host_flags) != hipSuccess) ok = false;
   if (ok) memset(D->h_counters, 0, B * sizeof(FrameCounters));
-  if (ok && hipStreamCreateWithFlags(&D->own_stream, hipStreamNonBlocking) != hipSuccess) ok = false;
   for (auto& e : D->ev) if (ok && hipEventCreate(&e) != hipSuccess) ok = false;
   for (auto& a : D->aux_stream) if (ok && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) ok = false;
   if (ok && hipEventCreateWithFlags(&D->ev_fork, hipEventDisableTiming) != hipSuccess) ok = false;
@@ -758,14 +768,16 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   }
   if (ok && D->d_thr) {
     // the padding columns of the working images are read by vector loads; define them once
-    if (hipMemset(D->d_thr, 127, B * (size_t)H * P.WS) != hipSuccess) ok = false;
-    if (ok && D->d_gray && hipMemset(D->d_gray, 0, B * (size_t)H * P.WS) != hipSuccess) ok = false;
+    if (hipMemsetAsync(D->d_thr, 127, B * (size_t)H * P.WS, D->own_stream) != hipSuccess) ok = false;
+    if (ok && D->d_gray && hipMemsetAsync(D->d_gray, 0, B * (size_t)H * P.WS, D->own_stream) != hipSuccess) ok = false;
+    if (ok && hipStreamSynchronize(D->own_stream) != hipSuccess) ok = false;
   }
   if (!ok) {
     free_all(D);
     delete D;
     return AMDAT_OUT_OF_MEMORY;
   }
+  if (cfg.no_graph_replay) D->graph_max_frames = 0;
   *handle = D;
   return AMDAT_SUCCESS;
 }
@@ -785,7 +797,10 @@ int amdCreateAprilTagsDetector(amdAprilTagsHandle* handle, uint32_t img_width, u
 int amdAprilTagsDestroy(amdAprilTagsHandle handle) {
   if (!handle) return AMDAT_INVALID_ARGUMENT;
   DeviceGuard guard(handle->device);
-  hipDeviceSynchronize();
+  if (handle->own_stream) (void)hipStreamSynchronize(handle->own_stream);
+  for (auto& a : handle->aux_stream) if (a) (void)hipStreamSynchronize(a);
+  (void)hipDeviceSynchronize();   // (a caller's stream may have carried the last submission; fails harmlessly under another thread's capture)
+  (void)hipGetLastError();
   free_all(handle);
   delete handle;
   return AMDAT_SUCCESS;
@@ -866,7 +881,7 @@ static int ensure_colour_plane(amdAprilTagsDetector_st* D, uint32_t fmt) {
     const size_t bytes = B * (size_t)D->P.H * D->P.WS;
     if (hipMalloc((void**)&D->d_gray, bytes) != hipSuccess) { D->d_gray = nullptr; return AMDAT_OUT_OF_MEMORY; }
     D->device_bytes += bytes;
-    if (hipMemset(D->d_gray, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return AMDAT_HIP_ERROR;
+    if (hipMemsetAsync(D->d_gray, 0, bytes, D->own_stream) != hipSuccess || hipStreamSynchronize(D->own_stream) != hipSuccess) return AMDAT_HIP_ERROR;
     return AMDAT_SUCCESS;
   }
   if (D->d_conv) return AMDAT_SUCCESS;
@@ -1007,16 +1022,16 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
 #endif
   if (AMDAT_CC_WIDE && small_submission(D, P, n, AMDAT_SMALL_PX_CC))   // sixteen waves per tile: a quarter of the rows per lane (latency, not throughput)
     hipLaunchKernelGGL((k_cc_local<16>), dim3((P.W + CC_T - 1) / CC_T, (P.H + CC_T - 1) / CC_T, n), dim3(1024), 0, s, D->d_thr,
-                     D->d_label, D->d_csize, D->d_roots, D->d_counters, P);
+                     D->d_label, D->d_csize, D->d_roots, D->d_perim, D->d_counters, P);
   else
     hipLaunchKernelGGL((k_cc_local<4>), dim3((P.W + CC_T - 1) / CC_T, (P.H + CC_T - 1) / CC_T, n), dim3(256), 0, s, D->d_thr,
-                     D->d_label, D->d_csize, D->d_roots, D->d_counters, P);
+                     D->d_label, D->d_csize, D->d_roots, D->d_perim, D->d_counters, P);
   mark();
   {
     const int nrows = (P.H - 1) / CC_T, ncols = (P.W - 1) / CC_T;
     const long total = (long)nrows * P.W + (long)ncols * P.H;
     if (total > 0)
-      hipLaunchKernelGGL(k_cc_border, dim3((unsigned)((total + 255) / 256) * n), dim3(256), 0, s, D->d_thr, D->d_label,
+      hipLaunchKernelGGL(k_cc_border, dim3((unsigned)((total + 255) / 256) * n), dim3(256), 0, s, D->d_perim, D->d_label,
                          (uint32_t)((total + 255) / 256), n, P);
   }
   mark();
@@ -1075,8 +1090,8 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
       if (FQ_SKIP_PREFILTER()) return;   // (tools_hooks.h: always 0 in the product build)
       // small submissions: one cluster per CU-wide workgroup (latency); otherwise one per wave (throughput)
       const bool wide = small_submission(D, P, n, AMDAT_SMALL_PX_PF);
-#define PF_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work, D->d_workctl, work2, D->d_workctl + 16, D->work_layout,   \
-                pf_first, (D->fq_counters ? D->d_fqprof : nullptr), P
+#define PF_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work, D->d_workctl, work2, D->d_workctl + 16, D->d_workctl + 24,   \
+                D->work_layout, pf_first, (D->fq_counters ? D->d_fqprof : nullptr), P
       if (wide) {
         unsigned gp = 2u * (unsigned)D->num_cus;
         if (gp > 256u * n) gp = 256u * n;
@@ -1145,10 +1160,19 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
       // A small submission leaves most of the chip empty either way: its classes below the prefilter start at once on the
       // side streams, beside the prefilter.
       if (!small) launch_prefilter(s);
+      // The two largest classes need (half) a CU's LDS per workgroup: queued beside the small classes' persistent grids they found no
+      // room until those drained -- the 1024-thread class, 15 us of work, sat behind k_fit_small for 1.4 ms whenever it lost that race
+      // (profiles/r05_v4_fit_timeline.txt) -- so a throughput-sized submission runs them right behind the prefilter, on the empty
+      // chip, and everything else starts when they are through (their lists hold the prefilter's few survivors).
+#ifndef AMDAT_BIG_FIRST
+#define AMDAT_BIG_FIRST 1
+#endif
+      const int big_first = (!small && AMDAT_BIG_FIRST) ? pf_first + 1 : FQ_NCLS;
+      for (int c = big_first; c < FQ_NCLS; c++) launch_class(c, s);
       HIP_TRY(hipEventRecord(D->ev_fork, s));
       for (int a = 0; a < FQ_NAUX; a++) HIP_TRY(hipStreamWaitEvent(aux[a], D->ev_fork, 0));
       if (small) launch_prefilter(s);
-      for (int c = pf_first; c < FQ_NCLS; c++) launch_class(c, s);   // (nearly all survivors are in the first of them)
+      for (int c = pf_first; c < big_first; c++) launch_class(c, s);   // (nearly all survivors are in the first of them)
       // the longest chains first; classes that launch nothing take no stream
       int a = 0;
       for (int c = pf_first - 1; c >= 0; c--)
@@ -1259,6 +1283,31 @@ static void drop_graphs_for_regrowth(amdAprilTagsDetector_st* D) {
 #endif
 }
 
+// After a capture that did not end in a graph: clear the error state and make sure no stream of the handle is left inside the
+// dead capture (a side stream that joined it through the fork event and was never joined back stays "capturing": every later
+// launch on it would fail with "operation failed due to a previous error during capture") -- such a stream is replaced.
+static int recover_from_failed_capture(amdAprilTagsDetector_st* D, hipStream_t s) {
+  for (int i = 0; i < 4 && hipGetLastError() != hipSuccess; i++) {}
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(s, &g);
+    if (g) hipGraphDestroy(g);
+  }
+  for (auto& a : D->aux_stream) {
+    st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(a, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      (void)hipStreamDestroy(a);
+      a = nullptr;
+      if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) return AMDAT_HIP_ERROR;
+      // (graphs captured on the old stream object are still valid: a graph holds nodes and edges, not the capture's streams)
+    }
+  }
+  for (int i = 0; i < 4 && hipGetLastError() != hipSuccess; i++) {}
+  return AMDAT_SUCCESS;
+}
+
 // One pass of a submission over the device: captured-graph replay for small submissions, plain enqueues otherwise.
 // launch_once enqueues it and returns; finish_once waits for it (and reads the stage events when profiling is on).
 static int launch_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride, hipStream_t s, uint32_t fmt) {
@@ -1314,9 +1363,15 @@ static int launch_once(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostride,
       if (graph) hipGraphDestroy(graph);
       if (ok) { slot->n = n; slot->ostride = ostride; slot->fmt = fmt; slot->stream = s; slot->last_use = ++D->graph_clock; hit = slot; }
       else {
-        (void)hipGetLastError();
+        // A capture can be invalidated from OUTSIDE the library: on this runtime a legacy-stream call of any other host thread on
+        // the same device (a plain hipMemcpy) while this thread captures fails that call and poisons the capture, in every capture
+        // mode (examples/multi_stream_host --shared-gpu met it with eight threads on one device).  The submission
+        // then goes out as plain enqueues -- after the side streams have been taken out of the dead capture -- and the handle
+        // tries a capture again on later submissions; three failures end graph replay for the handle.
         slot->exec = nullptr;
-        D->graph_max_frames = 0;   // capture is not usable here: plain enqueues from now on
+        const int crc = recover_from_failed_capture(D, s);
+        if (crc) return crc;
+        if (++D->capture_failures >= 3) D->graph_max_frames = 0;
       }
     }
     if (hit) {

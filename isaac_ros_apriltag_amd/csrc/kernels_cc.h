@@ -10,7 +10,11 @@
 //                per-run size counting; writes global labels (index of the tile-local root), the
 //                local size at root pixels, and appends the roots of components that touch the tile's
 //                perimeter (the only ones that can merge with another tile) to a per-frame root list.
-//   k_cc_border  unions across tile borders with global atomicMin (only first-overlap pixels).
+//   k_cc_border  unions across tile borders with global atomicMin (only first-overlap pixels).  It reads neither the threshold
+//                image nor the label array: k_cc_local leaves, per frame, the PERIMETER of every tile -- class and tile-local
+//                root of the pixels of its first / last row and first / last column -- in four compact arrays laid out along the
+//                borders (CcPerim below), so a border pixel's whole neighbourhood is a handful of coalesced words (the column
+//                borders used to gather bytes and labels at a stride of one image row: a cache line per lane and load).
 //   k_cc_sizes   over the root list only: every tile-local root is pointed at its final representative
 //                and its pixel count is added there.  Pixels keep the index of their tile-local root, so
 //                a consumer reaches the representative with two loads (label[label[p]]) and the image-wide
@@ -94,6 +98,26 @@ __device__ __forceinline__ void glb_union(uint32_t* L, uint32_t a, uint32_t b) {
   }
 }
 
+// Perimeter arrays of one frame (32-bit entries: tile-local root of the pixel = a pixel index, bit 31 set for a white pixel;
+// AT_NO_LABEL for a pixel without a class, which includes everything outside the image):
+//   top[ty][x], bot[ty][x]     first / last row of tile row ty, x = 0 .. WP - 1 (WP = tiles per row x 64)
+//   left[tx][y], right[tx][y]  first / last column of tile column tx, y = 0 .. HP - 1
+// i.e. a border between two tile rows is bot[ty - 1] over top[ty], entry for entry -- neighbours x - 1, x + 1 are the adjacent
+// entries, tile corners need no case of their own -- and a border between tile columns is right[tx - 1] beside left[tx].
+struct CcPerim {
+  int WP, HP;
+  uint32_t top, bot, left, right;   // word offsets of the four arrays inside a frame's block
+  uint32_t words;                   // words per frame
+};
+__host__ __device__ inline CcPerim cc_perim_layout(int W, int H) {
+  CcPerim L;
+  const int ntx = (W + CC_T - 1) / CC_T, nty = (H + CC_T - 1) / CC_T;
+  L.WP = ntx * CC_T; L.HP = nty * CC_T;
+  L.top = 0; L.bot = (uint32_t)(nty * L.WP); L.left = 2u * (uint32_t)(nty * L.WP); L.right = L.left + (uint32_t)(ntx * L.HP);
+  L.words = L.right + (uint32_t)(ntx * L.HP);
+  return L;
+}
+
 // NW waves per tile: 4 (throughput: a lane walks 16 rows, 7 workgroups per CU) or 16 (small submissions: 4 rows per lane --
 // a one-frame call has two tiles per CU and is over when the slowest tile is, so the chain per wave is what counts).
 // (register budget of k_cc_local: at least this many waves per SIMD)
@@ -103,7 +127,7 @@ __device__ __forceinline__ void glb_union(uint32_t* L, uint32_t a, uint32_t b) {
 template <int NW>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CC_LOCAL_MIN_WAVES, 8))) void k_cc_local(const uint8_t* __restrict__ thr_all, uint32_t* __restrict__ label_all,
                                                   uint32_t* __restrict__ csize_all, uint32_t* __restrict__ roots_all,
-                                                  FrameCounters* __restrict__ counters, DetParams P) {
+                                                  uint32_t* __restrict__ perim_all, FrameCounters* __restrict__ counters, DetParams P) {
   // (the threshold tile is only read into registers right after the load; the link-request lists of the union pass take
   // over its space -- a barrier lies between)
   constexpr int ROWS = CC_T / NW;                                   // rows of a wave's strip
@@ -344,6 +368,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CC_LOCA
     uint32_t gi = (uint32_t)(gyw * W + gx);   // (W * H pixels of a frame index 32 bits: the labels are such indices)
     const uint32_t me4 = fresh(me4w);
     const uint32_t* const sl4 = lds_at(sl, me4);
+    // the tile's perimeter for k_cc_border (CcPerim): the first / last row go out as one 256-byte store each, the first / last
+    // column as one two-lane store per row (lane 0 to `left`, lane 63 to `right`)
+    const CcPerim PL = cc_perim_layout(W, H);
+    uint32_t* const perim = perim_all + (size_t)frame * PL.words;
+    uint32_t* const pcol = perim + (lane == 0 ? PL.left + blockIdx.x * (uint32_t)PL.HP : PL.right + blockIdx.x * (uint32_t)PL.HP) + (uint32_t)gyw;
+    const bool col_lane = lane == 0 || lane == 63;
 #pragma unroll
     for (int k = 0; k < ROWS; k++, gi += (uint32_t)W) {
       const uint32_t rt = root[k];    // byte offset of the root pixel in the tile
@@ -351,6 +381,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CC_LOCA
       const bool isroot = rt == (me4 | (uint32_t)(k * CC_T * 4));   // (AT_NO_LABEL is no pixel's byte offset)
       // (24-bit multiply: one full-rate instruction; rows and the width are far below 2^24)
       uint32_t lab = __umul24((uint32_t)Y0 + (rt >> 8), (uint32_t)W) + (uint32_t)X0 + ((rt >> 2) & (CC_T - 1));
+      {
+        // (a perimeter pixel's root carries the perimeter flag, never the size bit: bit 31 of the entry is free for the class)
+        const uint32_t pe = rt == AT_NO_LABEL ? AT_NO_LABEL : (lab | (px(k) == CLS_WHITE ? 0x80000000u : 0u));
+        if (k == 0 && wv == 0) perim[PL.top + blockIdx.y * (uint32_t)PL.WP + (uint32_t)gx] = pe;
+        if (k == ROWS - 1 && wv == NW - 1) perim[PL.bot + blockIdx.y * (uint32_t)PL.WP + (uint32_t)gx] = pe;
+        if (col_lane) pcol[k] = pe;
+      }
       // complete inside this tile (no perimeter flag): size and representative are final
       if (isroot && !(cs >> 31) && (int)cs >= P.min_component_size) lab |= AT_LABEL_BIG;
       if (rt == AT_NO_LABEL) lab = AT_NO_LABEL;
@@ -365,47 +402,42 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CC_LOCA
   }
 }
 
-// Link requests of the border pass: up to three (pixel, partner) pairs per thread; a slot without a link holds
-// AT_NO_LABEL.  Pixel (gx, gy) on a tile-top row: its up, up-left and up-right links, evaluated on the global threshold
-// image with the same first-overlap rules as the tile kernel.
-__device__ __forceinline__ void cc_row_requests(const uint8_t* thr, int W, int H, int WS, int gx, int gy, uint32_t (&ra)[3], uint32_t (&rb)[3]) {
-  if (gx < 1 || gx > W - 2 || gy >= H || gy == 0) return;
-  const uint32_t v = thr[(size_t)gy * WS + gx];
-  if (v == 127) return;
-  const uint32_t me = (uint32_t)(gy * W + gx);
-  const uint32_t vl = thr[(size_t)gy * WS + gx - 1];
-  const uint32_t vu = thr[(size_t)(gy - 1) * WS + gx];
-  const uint32_t vul = thr[(size_t)(gy - 1) * WS + gx - 1];
+// Link requests of the border pass: up to three (root, partner root) pairs per thread; a slot without a link holds
+// AT_NO_LABEL.  Perimeter entries (CcPerim): AT_NO_LABEL = no class; otherwise bit 31 = white, the rest the pixel's tile-local root.
+__device__ __forceinline__ bool pe_white(uint32_t e) { return e != AT_NO_LABEL && (e >> 31); }
+__device__ __forceinline__ bool pe_same(uint32_t a, uint32_t b) {   // both have a class, and the same one
+  return a != AT_NO_LABEL && b != AT_NO_LABEL && ((a ^ b) >> 31) == 0;
+}
+// Pixel (gx, gy) on a tile-top row: its up, up-left and up-right links, with the same first-overlap rules as the tile kernel.
+// t* = entries of the row itself (left, own, right), b* = of the row above it (the last row of the tile row above).
+__device__ __forceinline__ void cc_row_requests(int W, int gx, uint32_t tl, uint32_t tc, uint32_t tr, uint32_t bl, uint32_t bc, uint32_t br,
+                                                uint32_t (&ra)[3], uint32_t (&rb)[3]) {
+  if (gx < 1 || gx > W - 2 || tc == AT_NO_LABEL) return;
+  const uint32_t me = tc & AT_LABEL_MASK;
   const bool left_src = gx - 1 >= 1;
-  if (vu == v && !(left_src && vl == v && vul == v)) { ra[0] = me; rb[0] = me - W; }
-  if (v == 255) {
-    if (vul == 255 && vu != 255 && !(left_src && vl == 255)) { ra[1] = me; rb[1] = me - W - 1; }
-    const uint32_t vur = thr[(size_t)(gy - 1) * WS + gx + 1];
-    const uint32_t vr = thr[(size_t)gy * WS + gx + 1];
+  if (pe_same(bc, tc) && !(left_src && pe_same(tl, tc) && pe_same(bl, tc))) { ra[0] = me; rb[0] = bc & AT_LABEL_MASK; }
+  if (pe_white(tc)) {
+    if (pe_white(bl) && !pe_white(bc) && !(left_src && pe_white(tl))) { ra[1] = me; rb[1] = bl & AT_LABEL_MASK; }
     const bool right_src = gx + 1 <= W - 2;
-    if (vur == 255 && !(right_src && (vu == 255 || vr == 255))) { ra[2] = me; rb[2] = me - W + 1; }
+    if (pe_white(br) && !(right_src && (pe_white(bc) || pe_white(tr)))) { ra[2] = me; rb[2] = br & AT_LABEL_MASK; }
   }
 }
 
 // Links across the vertical border between column gx - 1 (last of the left tile) and gx (first of the right tile) in
-// row gy: the left link and the up-left link of pixel (gx, gy), and the up-right link of pixel (gx - 1, gy).  All three
-// read the same 2 x 2 block of the threshold image, so one thread takes them (on tile-top rows only the left link: the
-// row pass owns every upward link of those rows).
-__device__ __forceinline__ void cc_column_requests(const uint8_t* thr, int W, int H, int WS, int gx, int gy, uint32_t (&ra)[3], uint32_t (&rb)[3]) {
-  if (gy >= H) return;
-  const uint32_t vL = thr[(size_t)gy * WS + gx - 1], vR = thr[(size_t)gy * WS + gx];
-  const bool upward = (gy % CC_T) != 0;
-  uint32_t vLu = 127, vRu = 127;
-  if (upward) { vLu = thr[(size_t)(gy - 1) * WS + gx - 1]; vRu = thr[(size_t)(gy - 1) * WS + gx]; }
-  const uint32_t meR = (uint32_t)(gy * W + gx), meL = meR - 1;
-  if (gx <= W - 2 && vR != 127) {                      // (gx, gy) is a link source
+// row gy: the left link and the up-left link of pixel (gx, gy), and the up-right link of pixel (gx - 1, gy).  eL / eR = entries
+// of the two pixels, eLu / eRu = of the pixels above them (tile-top rows take only the left link: the row pass owns every upward
+// link of those rows).
+__device__ __forceinline__ void cc_column_requests(int W, int gx, bool upward, uint32_t eL, uint32_t eR, uint32_t eLu, uint32_t eRu,
+                                                   uint32_t (&ra)[3], uint32_t (&rb)[3]) {
+  if (!upward) { eLu = AT_NO_LABEL; eRu = AT_NO_LABEL; }
+  if (gx <= W - 2 && eR != AT_NO_LABEL) {               // (gx, gy) is a link source
     // (the same link one row up, with both pixels joined to their upper neighbours inside their tiles, already implies it)
-    if (vL == vR && !(upward && vLu == vR && vRu == vR)) { ra[0] = meR; rb[0] = meL; }
-    if (upward && vR == 255 && vLu == 255 && vRu != 255 && vL != 255) { ra[1] = meR; rb[1] = meR - W - 1; }
+    if (pe_same(eL, eR) && !(upward && pe_same(eLu, eR) && pe_same(eRu, eR))) { ra[0] = eR & AT_LABEL_MASK; rb[0] = eL & AT_LABEL_MASK; }
+    if (upward && pe_white(eR) && pe_white(eLu) && !pe_white(eRu) && !pe_white(eL)) { ra[1] = eR & AT_LABEL_MASK; rb[1] = eLu & AT_LABEL_MASK; }
   }
-  if (upward && vL == 255) {                            // (gx - 1, gy) is a source (1 <= gx - 1 <= W - 2 always)
+  if (upward && pe_white(eL)) {                         // (gx - 1, gy) is a source (1 <= gx - 1 <= W - 2 always)
     const bool right_src = gx <= W - 2;
-    if (vRu == 255 && !(right_src && (vLu == 255 || vR == 255))) { ra[2] = meL; rb[2] = meL - W + 1; }
+    if (pe_white(eRu) && !(right_src && (pe_white(eLu) || pe_white(eR)))) { ra[2] = eL & AT_LABEL_MASK; rb[2] = eRu & AT_LABEL_MASK; }
   }
 }
 
@@ -413,40 +445,45 @@ __device__ __forceinline__ void cc_column_requests(const uint8_t* thr, int W, in
 #ifndef CC_ILEAVE
 #define CC_ILEAVE 256
 #endif
-__global__ __launch_bounds__(256) void k_cc_border(const uint8_t* __restrict__ thr_all, uint32_t* __restrict__ label_all,
+__global__ __launch_bounds__(256) void k_cc_border(const uint32_t* __restrict__ perim_all, uint32_t* __restrict__ label_all,
                                                    uint32_t bpf, uint32_t nframes, DetParams P) {
   uint32_t fr_, blk_;
   at_frame_block(blockIdx.x, bpf, nframes, CC_ILEAVE, &fr_, &blk_);
   const int frame = (int)fr_ + P.frame0;
   const int W = P.W, H = P.H;
-  const uint8_t* thr = thr_all + (size_t)frame * H * P.WS;
+  const CcPerim PL = cc_perim_layout(W, H);
+  const uint32_t* perim = perim_all + (size_t)frame * PL.words;
   uint32_t* label = label_all + (size_t)frame * W * H;
   const int nrows = (H - 1) / CC_T;  // tile-top rows at y = 64, 128, ...
   const int ncols = (W - 1) / CC_T;  // tile-left columns at x = 64, 128, ...
   int i = (int)blk_ * 256 + threadIdx.x;
   uint32_t ra[3] = {AT_NO_LABEL, AT_NO_LABEL, AT_NO_LABEL}, rb[3] = {AT_NO_LABEL, AT_NO_LABEL, AT_NO_LABEL};
   if (i < nrows * W) {
-    cc_row_requests(thr, W, H, P.WS, i % W, (i / W + 1) * CC_T, ra, rb);
+    const int gx = i % W, ty = i / W + 1;
+    const uint32_t* t = perim + PL.top + (uint32_t)ty * (uint32_t)PL.WP + (uint32_t)gx;
+    const uint32_t* b = perim + PL.bot + (uint32_t)(ty - 1) * (uint32_t)PL.WP + (uint32_t)gx;
+    // (x - 1 at gx = 0 and x + 1 at the array's end are never used by the rules: such a pixel is no link source)
+    const uint32_t tc = t[0], bc = b[0];
+    const uint32_t tl = gx > 0 ? t[-1] : AT_NO_LABEL, bl = gx > 0 ? b[-1] : AT_NO_LABEL;
+    const uint32_t tr = gx + 1 < PL.WP ? t[1] : AT_NO_LABEL, br = gx + 1 < PL.WP ? b[1] : AT_NO_LABEL;
+    cc_row_requests(W, gx, tl, tc, tr, bl, bc, br, ra, rb);
   } else {
     i -= nrows * W;
-    if (i < ncols * H) cc_column_requests(thr, W, H, P.WS, (i / H + 1) * CC_T, i % H, ra, rb);
+    if (i < ncols * H) {
+      const int tx = i / H + 1, gy = i % H;
+      const uint32_t* l = perim + PL.right + (uint32_t)(tx - 1) * (uint32_t)PL.HP + (uint32_t)gy;
+      const uint32_t* r = perim + PL.left + (uint32_t)tx * (uint32_t)PL.HP + (uint32_t)gy;
+      const bool upward = (gy % CC_T) != 0;
+      cc_column_requests(W, tx * CC_T, upward, l[0], r[0], upward ? l[-1] : AT_NO_LABEL, upward ? r[-1] : AT_NO_LABEL, ra, rb);
+    }
   }
-  // The entry of a pixel that is not a tile-local root never changes in this kernel (only root entries are lowered by
-  // atomicMin), so the first hop of either endpoint -- pixel -> its tile-local root -- is a plain cached load; the
-  // device-scope loads of the find start at the roots.  Along a tile border most links join the SAME two tile-local
-  // roots again and again (the big components of a textured background cross it dozens of times): a wave keeps one
-  // request per distinct pair of roots (a few leader rounds; what they do not cover is simply linked twice).
-  // (the first hops of all three requests are loaded before the first union: six independent loads in flight; a stale entry of
-  // a pixel that IS a root only names an ancestor the find passes through anyway)
-  uint32_t fa[3], fb[3];
+  // The requests name tile-local ROOTS (the perimeter entries carry them), so the device-scope loads of the find start at the
+  // roots.  Along a tile border most links join the SAME two tile-local roots again and again (the big components of a textured
+  // background cross it dozens of times): a wave keeps one request per distinct pair of roots (a few leader rounds; what they do
+  // not cover is simply linked twice).
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    fa[k] = fb[k] = AT_NO_LABEL;
-    if (ra[k] != AT_NO_LABEL) { fa[k] = label[ra[k]] & AT_LABEL_MASK; fb[k] = label[rb[k]] & AT_LABEL_MASK; }
-  }
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    uint32_t a = fa[k], b2 = fb[k];
+    uint32_t a = ra[k], b2 = rb[k];
     if (a != AT_NO_LABEL) {
       if (a > b2) { const uint32_t t = a; a = b2; b2 = t; }
       if (a == b2) a = b2 = AT_NO_LABEL;   // already the same tile-local root

