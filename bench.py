@@ -477,14 +477,20 @@ def extra_measurements(det, batch, frames_np, intr, args, torch, dev, tag_size, 
     for b in (1, 8, 64, 256):
         if b > B:
             continue
-        p = det.prepare(batch[:b], max_dets=64, intrinsics=intr[:b])
+        # the live shapes -- one camera, eight cameras -- on a handle of their own size, as a node creates it: a handle of up to eight
+        # frames replays captured launch graphs, a throughput-sized one has prioritised side streams and does not (csrc/detector.hip)
+        dsw = det if b > 8 else AprilTagDetector(W, H, families=("tag36h11",), decimate=args.decimate, intrinsics=intr[0], tag_size=tag_size,
+                                                 max_batch=b, device=dev_index)
+        p = dsw.prepare(batch[:b], max_dets=64, intrinsics=intr[:b])
         reps = max(3, min(40, 512 // b))
-        det.run_prepared(p)
+        dsw.run_prepared(p)
         ts = []
         for _ in range(reps):
             t = time.perf_counter()
-            det.run_prepared(p)
+            dsw.run_prepared(p)
             ts.append(time.perf_counter() - t)
+        if dsw is not det:
+            dsw.close()
         sweep[str(b)] = {"fps_median": round(b / float(np.median(ts)), 1), "ms_median": round(float(np.median(ts)) * 1e3, 3),
                          "ms_min": round(float(np.min(ts)) * 1e3, 3)}
     ex["batch_sweep"] = sweep

@@ -166,6 +166,7 @@ struct amdAprilTagsDetector_st {
   hipStream_t own_stream = nullptr;
   // the size classes of the quad fit fork to auxiliary streams and join before decode
   hipStream_t aux_stream[FQ_NAUX] = {};
+  bool aux_prioritised = false;      // the side streams carry priorities (handles above eight frames per submission; see creation)
   hipEvent_t ev_fork = nullptr, ev_join[FQ_NAUX] = {};
   // device buffers
   uint8_t* d_gray = nullptr;          // working-size gray plane: decimated handles, and (allocated on first use) colour submissions at decimate 1
@@ -754,7 +755,28 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   if (ok && hipHostMalloc((void**)&D->h_out, B * (size_t)P.dcap * sizeof(DetRec), host_flags) != hipSuccess) ok = false;
   if (ok) memset(D->h_counters, 0, B * sizeof(FrameCounters));
   for (auto& e : D->ev) if (ok && hipEventCreate(&e) != hipSuccess) ok = false;
-  for (auto& a : D->aux_stream) if (ok && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) ok = false;
+  // Side streams.  The persistent grids of the fit's classes each hold the whole chip's wave slots, so which class's workgroups
+  // are placed first decides who runs beside whom.  A handle sized for throughput (more than eight frames per submission) gets
+  // PRIORITISED side streams -- greatest, default, least: the class with the longest chains goes on the first and is placed
+  // first, the one-wave and small-cluster kernels fill what it leaves (AMDAT_AUX_PRIO: measured below) -- and never captures
+  // launch graphs: replaying a graph whose branches were captured on prioritised streams costs 0.25 ms per launch on this runtime
+  // (one frame: 0.39 -> 0.65 ms).  A handle of up to eight frames keeps plain side streams and graph replay.  (Both sets on one
+  // handle -- seven streams -- slowed every stage: 17.6 -> 18.1 ms per 256 frames; the runtime multiplexes its streams onto a
+  // few hardware queues.)
+#ifndef AMDAT_AUX_PRIO
+#define AMDAT_AUX_PRIO 1
+#endif
+  D->aux_prioritised = AMDAT_AUX_PRIO && cfg.max_batch > 8;
+  {
+    int lo = 0, hi = 0;   // (numerically hi <= lo: hi is the greatest priority)
+    if (D->aux_prioritised && hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { D->aux_prioritised = false; (void)hipGetLastError(); }
+    for (int k = 0; k < FQ_NAUX; k++) {
+      const int pr = k == 0 ? hi : (k == 1 ? (lo + hi) / 2 : lo);
+      if (ok && (D->aux_prioritised ? hipStreamCreateWithPriority(&D->aux_stream[k], hipStreamNonBlocking, pr)
+                                    : hipStreamCreateWithFlags(&D->aux_stream[k], hipStreamNonBlocking)) != hipSuccess) ok = false;
+    }
+    if (D->aux_prioritised) D->graph_max_frames = 0;
+  }
   if (ok && hipEventCreateWithFlags(&D->ev_fork, hipEventDisableTiming) != hipSuccess) ok = false;
   for (auto& e : D->ev_join) if (ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
   // dynamic LDS beyond 64 KB has to be allowed per kernel (once per device; not allowed while a stream is being captured)
@@ -1173,10 +1195,17 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
       for (int a = 0; a < FQ_NAUX; a++) HIP_TRY(hipStreamWaitEvent(aux[a], D->ev_fork, 0));
       if (small) launch_prefilter(s);
       for (int c = pf_first; c < big_first; c++) launch_class(c, s);   // (nearly all survivors are in the first of them)
-      // the longest chains first; classes that launch nothing take no stream
+      // the longest chains first; classes that launch nothing take no stream.  (The one-wave class on the submission stream itself,
+      // so that it starts without the 60 .. 90 us the fork event takes to reach a side stream -- measured with the wall clock inside
+      // the kernels -- cost 0.5 ms: its persistent grid then holds the chip before the 128-thread class is placed, which ends up
+      // running last and alone.)
+      // (holding the shorter-chained classes of a small submission back a few microseconds with a one-wave wait kernel ahead of
+      // them, to get on plain streams -- a captured graph -- the placement order stream priorities give, measured nothing: 0.395 vs
+      // 0.395 ms for one frame, 1.055 vs 1.065 for eight.  Priorities act on every slot that frees up, not on the first placement.)
       int a = 0;
       for (int c = pf_first - 1; c >= 0; c--)
         if (launch_class(c, aux[a % FQ_NAUX])) a++;
+
     } else {
     if (large_first) {
       launch_class(FQ_C0 + 3, s);

@@ -1724,6 +1724,7 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
   const int tid = threadIdx.x;
   const int W = P.W, H = P.H;
   PF_HOOKS_DECL   // (tools_hooks.h)
+  TL_MARK_MIN(0)
   // items of the classes first_class .. FQ_NCLS - 1, largest class first
   uint32_t cnt[FQ_NCLS], total = 0;
 #pragma unroll
@@ -1896,6 +1897,7 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
       work_out[L.off[cls] + pos] = wi;
     }
   }
+  TL_MARK_MAX(1)
 }
 
 // ---- k_quad_finish: corners, area and angle checks of the candidates k_fit_quads found (one thread per candidate) -------
@@ -1903,6 +1905,7 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
 // corners rounded to float, two Heron triangles, four corner angles with the winding test.
 __global__ __launch_bounds__(256) void k_quad_finish(const FitCand* __restrict__ cands_all, QuadRec* __restrict__ quads_all,
                                                      FrameCounters* __restrict__ counters, DetParams P) {
+  TL_MARK_MIN(3)
   const int frame = (int)blockIdx.y + P.frame0;
   uint32_t ncand = counters[frame].ncand;
   if (ncand > P.cand_cap) ncand = P.cand_cap;

@@ -145,6 +145,9 @@ __device__ __forceinline__ void th_minmax_word(uint32_t w, uint32_t& mn, uint32_
 // row segment.
 #define TH_BTX 256  // tiles per block in x
 #define TH_BTY 8    // tiles per block in y
+// (the colour instances take 117 registers -- all loads of both units in flight -- and run at four waves per SIMD against the mono8
+// instance's seven; a budget of 96 or 80 registers makes the compiler spill 12 / 28 of them instead of issuing the loads later, and
+// a scheduling fence between the two units changes nothing: measured 63 - 66 % of 8 TB/s on 5 N bytes as it stands)
 template <int DEC, int FMT = 0>
 __global__ __launch_bounds__(256) void k_threshold(const FrameDesc* __restrict__ frames, uint8_t* __restrict__ gray_all,
                                                    uint8_t* __restrict__ thr_all, int gx, int gy, int nframes, DetParams P) {

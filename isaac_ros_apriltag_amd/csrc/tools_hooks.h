@@ -57,6 +57,7 @@
 // ---- k_fit_quads --------------------------------------------------------------------------------------------------------
 #ifdef AMDAT_FQ_TIMELINE
 #define FQ_TIMELINE_GLOBALS                                                                                             \
+  __device__ unsigned long long g_pf_span[4];   /* prefilter: earliest block start, latest block end; k_scatter's latest end; k_quad_finish's earliest start */ \
   __device__ unsigned long long g_fq_tl[1 << 16][2];                                                                    \
   __device__ unsigned int g_fq_ph[1 << 16][8];   /* wall-clock ticks (10 ns) per phase of the same cluster */           \
   __device__ unsigned int g_fq_tl_n;
@@ -108,6 +109,13 @@
 #define FQ_STOP_AT(n)
 #endif
 
+#ifdef AMDAT_FQ_TIMELINE
+#define TL_MARK_MIN(slot) if (threadIdx.x == 0) atomicMin(&g_pf_span[slot], wall_clock64());
+#define TL_MARK_MAX(slot) if (threadIdx.x == 0) atomicMax(&g_pf_span[slot], wall_clock64());
+#else
+#define TL_MARK_MIN(slot)
+#define TL_MARK_MAX(slot)
+#endif
 // ---- k_fit_prefilter: prof[60..63] = box + dot, sector sums, scan + 32-sector test, 64-sector test --------------------
 #ifdef AMDAT_FQ_PROFILE
 #define PF_HOOKS_DECL unsigned long long t_prev_ = prof ? __builtin_readcyclecounter() : 0ull;

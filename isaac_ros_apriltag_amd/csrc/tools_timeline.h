@@ -9,6 +9,14 @@ extern "C" int amdAprilTagsDebugTimelinePhases(unsigned int* out, unsigned int n
   if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fq_ph), (size_t)n * 32) != hipSuccess) return -1;
   return (int)n;
 }
+// earliest prefilter block start, latest prefilter block end, (unused), earliest k_quad_finish block start; resets them
+extern "C" int amdAprilTagsDebugTimelineSpan(unsigned long long* out4) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_pf_span), 32) != hipSuccess) return -1;
+  const unsigned long long init[4] = {~0ull, 0ull, 0ull, ~0ull};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_pf_span), init, 32) != hipSuccess) return -1;
+  return 0;
+}
 extern "C" int amdAprilTagsDebugTimeline(unsigned long long* out, unsigned int cap) {
   unsigned int n = 0;
   if (hipDeviceSynchronize() != hipSuccess) return -1;

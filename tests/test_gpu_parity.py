@@ -655,6 +655,44 @@ def test_node_shell_pol_and_mono8(built):
     nv.close(); nc.close()
 
 
+def test_node_shell_colour_frames_and_strict_cuapriltags_encodings(built):
+    """Colour frames as the reference's cuAprilTags branch takes them (apriltag_node.cpp:469-486): the shell hands the frame to
+    amdAprilTagsDetectColor in the encoding it arrived in -- random chroma, so a swapped channel order cannot pass; host and device
+    payloads, padded step -- and publishes what a node fed the numpy-converted mono8 frame publishes.  With
+    strict_cuapriltags_encodings the cuAprilTags mode refuses everything but rgb8 / bgr8 with the reference's own text (:469-476);
+    a VPI-mode node keeps the five encodings of :76-82."""
+    from isaac_ros_apriltag_amd import node as nd
+    img, K, _ = synth.scene_c2(seed=1777)
+    K9 = [K[0, 0], 0, K[0, 2], 0, K[1, 1], K[1, 2], 0, 0, 1]
+    ref = nd.AprilTagNode()
+    want = {}
+    n = nd.AprilTagNode()
+    for enc in ("rgb8", "bgr8", "rgba8", "bgra8"):
+        buf, gray = _colour_frame(img, enc, seed=len(enc) * 3, pitch_pad=8)
+        want[enc], _ = ref.on_frame(gray.ctypes.data, False, "mono8", 1920, 1080, 1920, K9)
+        assert len(want[enc]) == 10
+        got, _ = n.on_frame(buf.ctypes.data, False, enc, 1920, 1080, buf.shape[1], K9)
+        assert got == want[enc], enc
+        t = torch.from_numpy(buf).cuda()
+        got_dev, _ = n.on_frame(t.data_ptr(), True, enc, 1920, 1080, buf.shape[1], K9)
+        assert got_dev == want[enc], enc
+    n.close()
+    strict = nd.AprilTagNode(backends="CUDA", strict_cuapriltags_encodings=True)
+    buf, gray = _colour_frame(img, "bgr8", seed=6)
+    want_strict, _ = ref.on_frame(gray.ctypes.data, False, "mono8", 1920, 1080, 1920, K9)
+    ref.close()
+    d, _ = strict.on_frame(buf.ctypes.data, False, "bgr8", 1920, 1080, buf.shape[1], K9)
+    assert len(d) == 10 and d == want_strict
+    for enc, step in (("mono8", 1920), ("rgba8", 1920 * 4)):
+        with pytest.raises(RuntimeError) as e:
+            strict.on_frame(img.ctypes.data, False, enc, 1920, 1080, step, K9)
+        assert "cuAprilTags detector only supports 'rgb8' or 'bgr8' image input" in str(e.value)
+    strict.close()
+    vpi = nd.AprilTagNode(backends="CUDA,CPU", strict_cuapriltags_encodings=True)     # not the cuAprilTags mode: nothing to be strict about
+    assert len(vpi.on_frame(img.ctypes.data, False, "mono8", 1920, 1080, 1920, K9)[0]) == 10
+    vpi.close()
+
+
 @pytest.mark.parametrize("shape", [(4, 4), (8, 8), (16, 20), (5, 7), (64, 4)])
 def test_tiny_and_degenerate_frames(built, shape):
     """Smallest legal sizes, flat frames (everything 127) and frames without any tag: no detections, no

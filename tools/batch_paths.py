@@ -13,7 +13,7 @@ calls = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 frames = np.stack([synth.scene_c2(seed=1234 + i)[0] for i in range(max(Bs))])
 tall = torch.from_numpy(frames).cuda()
 for B in Bs:
-    det = AprilTagDetector(1920, 1080, max_batch=B)
+    det = AprilTagDetector(1920, 1080, max_batch=B, **({"no_graph_replay": 1} if os.environ.get("NOGRAPH") else {}))
     prep = det.prepare(tall[:B].contiguous())
     for _ in range(10):
         det.run_prepared(prep)
@@ -23,7 +23,7 @@ for B in Bs:
     det.set_profiling(True)
     det.run_prepared(prep); det.run_prepared(prep)
     st = {k: round(v, 3) for k, v in det.stage_ms().items()}
-    print(json.dumps({"lib": os.environ.get("AMDAT_LIB", "default"), "B": B, "ms_median": round(float(np.median(ts)) * 1e3, 4),
+    print(json.dumps({"lib": os.environ.get("AMDAT_LIB", "default") + ("/nograph" if os.environ.get("NOGRAPH") else ""), "B": B, "ms_median": round(float(np.median(ts)) * 1e3, 4),
                       "ms_min": round(float(np.min(ts)) * 1e3, 4), "fps": round(B / float(np.median(ts)), 1),
                       "path": det.last_submission_path() if hasattr(det, "last_submission_path") else None, "stages": st}))
     det.close()

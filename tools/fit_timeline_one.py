@@ -18,7 +18,11 @@ buf = np.zeros((1 << 16, 2), dtype=np.uint64)
 for _ in range(6):
     det.run_prepared(prep)
 L.amdAprilTagsDebugTimeline(buf.ctypes.data, 1 << 16)
+span = np.zeros(4, dtype=np.uint64)
+L.amdAprilTagsDebugTimelineSpan.argtypes = [C.c_void_p]
+L.amdAprilTagsDebugTimelineSpan(span.ctypes.data)
 det.run_prepared(prep)
+L.amdAprilTagsDebugTimelineSpan(span.ctypes.data)
 ph = np.zeros((1 << 16, 8), dtype=np.uint32)
 L.amdAprilTagsDebugTimelinePhases.argtypes = [C.c_void_p, C.c_uint]
 L.amdAprilTagsDebugTimelinePhases(ph.ctypes.data, 1 << 16)
@@ -30,6 +34,9 @@ sz = (b[:, 1] & np.uint64(0xFFFFF)).astype(int)
 base = t0.min()
 tick = 0.01  # us per tick (100 MHz)
 print("%d clusters logged; span %.1f us" % (n, (t0 + dur).max() * tick - base * tick))
+if span[1] > 0:
+    print("prefilter: first block start %.1f us, last block end %.1f us; k_quad_finish first block start %.1f us (all relative to the first logged cluster start)" %
+          ((int(span[0]) - int(base)) * tick, (int(span[1]) - int(base)) * tick, (int(span[3]) - int(base)) * tick))
 for c in sorted(set(nt)):
     m = nt == c
     print("NT=%4d: %5d clusters, first start %.1f us, last start %.1f us, last end %.1f us, mean dur %.1f us, max dur %.1f us (sz %d)" %
