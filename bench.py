@@ -49,6 +49,7 @@ def parse_args(argv=None):
                     help="smoke only: ranks may share a device (local_rank %% device_count) when the box has fewer GPUs than ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--small-row", type=int, default=0, help=argparse.SUPPRESS)   # (internal: one row of the batch sweep, own process)
     ap.add_argument("--no-extra", action="store_true", help="skip the informational measurements (sweep, H2D, latency, sigma 0, decimate 2)")
     return ap.parse_args(argv)
 
@@ -252,6 +253,8 @@ def stage_rooflines(stage_ms, nframes, counts, decimate):
 
 def main():
     args = parse_args()
+    if args.small_row:
+        return small_row_main(args)
     maybe_spawn(args)
     import torch
     import torch.distributed as dist
@@ -467,32 +470,90 @@ def main():
         dist.destroy_process_group()
 
 
+def small_handle_row(b, args, dev_index):
+    """One row of the batch sweep in a process of its own (see extra_measurements): `python bench.py --small-row b`."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--small-row", str(b), "--sigma", str(args.sigma), "--decimate", str(args.decimate)]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["BENCH_SMALL_ROW_DEVICE"] = str(dev_index)
+    try:
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True).stdout.decode()
+        return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    except Exception as e:   # (informational row: never fails the bench line)
+        sys.stderr.write("bench.py: small-handle row %d not measured in its own process (%r)\n" % (b, e))
+        return None
+
+
+def small_row_main(args):
+    import torch
+    from isaac_ros_apriltag_amd import streams
+    from isaac_ros_apriltag_amd.detector import AprilTagDetector
+    b = args.small_row
+    dev_index = int(os.environ.get("BENCH_SMALL_ROW_DEVICE", "0"))
+    torch.cuda.set_device(dev_index)
+    block = streams.make_param_block(NUM_STREAMS, W, H, args.decimate)
+    sp = streams.stream_params(block, 0)
+    frames = torch.from_numpy(render_frames(int(sp["seed"]), b, args.sigma)).to(torch.device("cuda", dev_index))
+    K = (sp["fx"], sp["fy"], sp["cx"], sp["cy"])
+    det = AprilTagDetector(W, H, families=("tag36h11",), decimate=args.decimate, intrinsics=K, tag_size=sp["tag_size"], max_batch=b,
+                           device=dev_index)
+    p = det.prepare(frames, max_dets=64, intrinsics=[K] * b)
+    for _ in range(5):
+        det.run_prepared(p)
+    ts = []
+    for _ in range(max(3, min(100, 1024 // b))):
+        t = time.perf_counter()
+        det.run_prepared(p)
+        ts.append(time.perf_counter() - t)
+    nd = [len(d) for d in det.unpack(p)]
+    det.close()
+    print(json.dumps({"fps_median": round(b / float(np.median(ts)), 1), "ms_median": round(float(np.median(ts)) * 1e3, 3),
+                      "ms_min": round(float(np.min(ts)) * 1e3, 3), "own_process": True, "detections_per_frame": float(np.mean(nd))}))
+
+
 def extra_measurements(det, batch, frames_np, intr, args, torch, dev, tag_size, dev_index):
     """Informational rows of BASELINE.md's protocol; none of them is `value`."""
     from isaac_ros_apriltag_amd.detector import AprilTagDetector
     ex = {}
     B = batch.shape[0]
-    # batch-size sweep on the same handle (frames of stream 0 first, so small batches are one stream)
+    # batch-size sweep (frames of stream 0 first, so small batches are one stream).  64 and 256 frames run on the step's handle.  One
+    # and eight frames -- one camera, eight cameras: the live shapes -- run on a handle of their own size IN A PROCESS OF THEIR OWN, as
+    # a node holds it: a handle of up to eight frames replays captured launch graphs on plain streams, a throughput-sized one has
+    # prioritised side streams (csrc/detector.hip), and on this runtime a small handle created after a prioritised one in the same
+    # process finds its graph branches on that handle's hardware queues (0.49 against 0.38 ms per frame; INTEGRATION.md, "stream
+    # priorities"; the row measured that way is kept beside it as same_process_ms_median).
     sweep = {}
-    for b in (1, 8, 64, 256):
-        if b > B:
-            continue
-        # the live shapes -- one camera, eight cameras -- on a handle of their own size, as a node creates it: a handle of up to eight
-        # frames replays captured launch graphs, a throughput-sized one has prioritised side streams and does not (csrc/detector.hip)
-        dsw = det if b > 8 else AprilTagDetector(W, H, families=("tag36h11",), decimate=args.decimate, intrinsics=intr[0], tag_size=tag_size,
-                                                 max_batch=b, device=dev_index)
+    def timed(dsw, b, reps):
         p = dsw.prepare(batch[:b], max_dets=64, intrinsics=intr[:b])
-        reps = max(3, min(40, 512 // b))
         dsw.run_prepared(p)
         ts = []
         for _ in range(reps):
             t = time.perf_counter()
             dsw.run_prepared(p)
             ts.append(time.perf_counter() - t)
-        if dsw is not det:
+        return ts
+    for b in (1, 8, 64, 256):
+        if b > B:
+            continue
+        reps = max(3, min(40, 512 // b))
+        row = None
+        if b <= 8:
+            dsw = AprilTagDetector(W, H, families=("tag36h11",), decimate=args.decimate, intrinsics=intr[0], tag_size=tag_size,
+                                   max_batch=b, device=dev_index)
+            same = float(np.median(timed(dsw, b, reps))) * 1e3
             dsw.close()
-        sweep[str(b)] = {"fps_median": round(b / float(np.median(ts)), 1), "ms_median": round(float(np.median(ts)) * 1e3, 3),
-                         "ms_min": round(float(np.min(ts)) * 1e3, 3)}
+            row = small_handle_row(b, args, dev_index)
+            if row is not None:
+                row["same_process_ms_median"] = round(same, 3)
+            else:
+                row = {"fps_median": round(b / (same * 1e-3), 1), "ms_median": round(same, 3), "ms_min": None, "own_process": False}
+        else:
+            ts = timed(det, b, reps)
+            row = {"fps_median": round(b / float(np.median(ts)), 1), "ms_median": round(float(np.median(ts)) * 1e3, 3),
+                   "ms_min": round(float(np.min(ts)) * 1e3, 3)}
+        sweep[str(b)] = row
     ex["batch_sweep"] = sweep
     # the reference's own input format (its cuAprilTags branch takes rgb8 / bgr8 uchar3 frames, src/apriltag_node.cpp:469-486): the
     # same B frames as bgr8 -- the gray value in all three channels, so that the BT.601 statement gives the mono8 frame back exactly

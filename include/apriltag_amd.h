@@ -148,7 +148,7 @@ typedef struct {
                                 * amdAprilTagsConfigLayoutVersion() says which layout a library speaks).  From that layout on the
                                 * struct only grows at its end: a caller built against an older, shorter versioned header passes its
                                 * smaller size and the fields it does not know keep their defaults (round 6 appended
-                                * no_graph_replay); a size below the first versioned layout's, or beyond the library's own, is
+                                * no_graph_replay and no_stream_priorities); a size below the first versioned layout's, or beyond the library's own, is
                                 * AMDAT_INVALID_ARGUMENT (a struct that did not come from amdAprilTagsDefaultConfig). */
   uint32_t width, height;      /* input image size (fixed for the handle, as in the reference) */
   uint32_t tile_size;          /* 4 (src/apriltag_node.cpp:566) or 8; other values: AMDAT_UNSUPPORTED */
@@ -181,14 +181,21 @@ typedef struct {
                                 * stream 0) on the same device while this handle detects: on ROCm 7 such a call fails -- in the host's
                                 * thread -- whenever it meets a capture in progress, whatever the capture mode.  The
                                 * library itself survives the collision either way (the submission goes out uncaptured). */
+  uint32_t no_stream_priorities; /* != 0: a throughput-sized handle (max_batch > 8) creates its side streams without priorities (about
+                                * 2 % fewer frames per second on 256-frame submissions).  For processes that ALSO hold handles of up to
+                                * eight frames and create them AFTER the throughput-sized one: on ROCm 7 the launch graphs such a handle
+                                * replays find their branches on the prioritised handle's hardware queues and run 30 % slower
+                                * ("stream priorities").  Creating the small handles first, or one process per
+                                * handle -- a node's shape -- needs nothing. */
 } amdAprilTagsConfig_t;
 #define AMDAT_CORNERS_DEFAULT 0u
 #define AMDAT_CORNERS_ROTATED_180 1u
 
 void amdAprilTagsDefaultConfig(amdAprilTagsConfig_t* cfg, uint32_t width, uint32_t height);
 /* Layout generation of amdAprilTagsConfig_t this library was built with: 1 = the first versioned layout (struct_size at offset 0,
- * fields up to corner_convention), 2 = + no_graph_replay.  Layouts before 1 (no size field) are not accepted. */
-#define AMDAT_CONFIG_LAYOUT_VERSION 2
+ * fields up to corner_convention), 2 = + no_graph_replay, 3 = + no_stream_priorities.  Layouts before 1 (no size field) are not
+ * accepted. */
+#define AMDAT_CONFIG_LAYOUT_VERSION 3
 uint32_t amdAprilTagsConfigLayoutVersion(void);
 
 /* nvCreateAprilTagsDetector-shaped constructor (one family, batch 1, decimate 1). */

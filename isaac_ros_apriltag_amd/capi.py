@@ -51,7 +51,7 @@ class Config(C.Structure):
                 ("max_hamming", C.c_uint32), ("decode_sharpening", C.c_float), ("max_points", C.c_uint32),
                 ("hash_slots", C.c_uint32), ("max_clusters", C.c_uint32), ("max_quads", C.c_uint32),
                 ("max_detections", C.c_uint32), ("device", C.c_int32), ("skew", C.c_float), ("corner_convention", C.c_uint32),
-                ("no_graph_replay", C.c_uint32)]
+                ("no_graph_replay", C.c_uint32), ("no_stream_priorities", C.c_uint32)]
 
 
 # every symbol include/apriltag_amd.h declares

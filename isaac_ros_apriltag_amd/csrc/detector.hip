@@ -325,6 +325,7 @@ void amdAprilTagsDefaultConfig(amdAprilTagsConfig_t* cfg, uint32_t width, uint32
   cfg->decode_sharpening = 0.25f;
   cfg->device = -1;
   cfg->no_graph_replay = 0;
+  cfg->no_stream_priorities = 0;
 }
 
 uint32_t amdAprilTagsConfigLayoutVersion(void) { return AMDAT_CONFIG_LAYOUT_VERSION; }
@@ -670,6 +671,9 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
 #ifndef FS_B1
 #define FS_B1 FS_B0   // (= FS_B0: no K = 4 class)
 #endif
+#ifndef FS_K4_GROWS
+#define FS_K4_GROWS true   // the K = 4 class's moments: true -- global scratch slot; false -- LDS (14 KB per workgroup)
+#endif
     const int sb0 = P.split_moments ? FS_B0 : 0, sb1 = P.split_moments ? FS_B1 : 0;
     c[0] = {64, 0, 0, sb0, minu((unsigned)FS_GRID_K2 * cus, 4096u * (unsigned)B), sb0, FQ_POP0, 2};
     c[1] = {64, 0, sb0, sb1, minu((unsigned)FS_GRID_K4 * cus, 4096u * (unsigned)B), sb1 > 256 ? sb1 : 256, FQ_POP0, 4};   // (slot: 256 rows of moments)
@@ -766,24 +770,37 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
 #ifndef AMDAT_AUX_PRIO
 #define AMDAT_AUX_PRIO 1
 #endif
-  D->aux_prioritised = AMDAT_AUX_PRIO && cfg.max_batch > 8;
+  D->aux_prioritised = AMDAT_AUX_PRIO && cfg.max_batch > 8 && !cfg.no_stream_priorities;
   {
     int lo = 0, hi = 0;   // (numerically hi <= lo: hi is the greatest priority)
     if (D->aux_prioritised && hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { D->aux_prioritised = false; (void)hipGetLastError(); }
-    if (D->aux_prioritised) {
-      // On this runtime the hardware queues of plain streams have to exist BEFORE the first prioritised stream of the process is
-      // created: a handle of up to eight frames created after a prioritised one otherwise runs its fit classes 30 % slower for
-      // the life of the process (one 1080p frame 0.51 against 0.39 ms, eight 1.38 against 1.06; tools/stream_order.py -- four
-      // plain streams created and destroyed first are enough, whatever runs on them or not).
+    // (What the runtime does with the streams' hardware queues is sensitive to the ORDER in which plain and prioritised streams
+    // come into being in a process -- measured on ROCm 7.0 / 7.2, bench.py's step and one- / eight-frame calls of a small handle,
+    // tools/stream_order.py, tools/bench_variant.py:
+    //   throughput-sized handle first, small handle after it      17.30 ms per 256 frames | 0.49 ms one frame, 1.32 ms eight
+    //   small handle first (its four plain streams alive)         17.5                    | 0.38, 1.05
+    //   four plain streams created and destroyed first            18.0 (every stage)      | 0.38, 1.05
+    //   ... created and destroyed after the prioritised ones      17.5                    | 0.47, 1.34
+    //   no priorities at all (cfg.no_stream_priorities)           17.7                    | 0.38, 1.05
+    // rocprofv3's kernel trace shows the graph branches of a small handle created after a prioritised one on that handle's
+    // hardware queues.  The library does not try to steer this: the first row is what a process with one throughput-sized handle
+    // gets, a node's process -- one small handle -- never meets a prioritised stream, and a process that mixes both creates the
+    // small handles first or sets no_stream_priorities: include/apriltag_amd.h, INTEGRATION.md.)
+    auto prime_plain_queues = [&]() {
       hipStream_t plain[4] = {};
       for (auto& q : plain) if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) { q = nullptr; (void)hipGetLastError(); }
       for (auto& q : plain) if (q) hipStreamDestroy(q);
-    }
+    };
+#ifndef AMDAT_PRIME_PLAIN_QUEUES
+#define AMDAT_PRIME_PLAIN_QUEUES 0   // 0: never, 1: before the prioritised streams are created, 2: after (measurement builds)
+#endif
+    if (D->aux_prioritised && AMDAT_PRIME_PLAIN_QUEUES == 1) prime_plain_queues();
     for (int k = 0; k < FQ_NAUX; k++) {
       const int pr = k == 0 ? hi : (k == 1 ? (lo + hi) / 2 : lo);
       if (ok && (D->aux_prioritised ? hipStreamCreateWithPriority(&D->aux_stream[k], hipStreamNonBlocking, pr)
                                     : hipStreamCreateWithFlags(&D->aux_stream[k], hipStreamNonBlocking)) != hipSuccess) ok = false;
     }
+    if (D->aux_prioritised && AMDAT_PRIME_PLAIN_QUEUES == 2) prime_plain_queues();
     if (D->aux_prioritised) D->graph_max_frames = 0;
   }
   if (ok && hipEventCreateWithFlags(&D->ev_fork, hipEventDisableTiming) != hipSuccess) ok = false;
@@ -832,7 +849,12 @@ int amdAprilTagsDestroy(amdAprilTagsHandle handle) {
   for (auto& a : handle->aux_stream) if (a) (void)hipStreamSynchronize(a);
   (void)hipDeviceSynchronize();   // (a caller's stream may have carried the last submission; fails harmlessly under another thread's capture)
   (void)hipGetLastError();
+  const bool had_graphs = !handle->retired_graphs.empty() || [&]() { for (auto& g : handle->graphs) if (g.exec) return true; return false; }();
   free_all(handle);
+  // (hipGraphExecDestroy followed, with no device-wide wait in between, by the capture, instantiation and launch of another graph
+  // is the sequence that crashes inside PyTorch's bundled HIP 7.0 runtime -- retire_graph below -- and the next graph may be
+  // another handle's: one run of the regrowth stress loop in the GPU suite died that way, handle after handle in one process)
+  if (had_graphs) { (void)hipDeviceSynchronize(); (void)hipGetLastError(); }
   delete handle;
   return AMDAT_SUCCESS;
 }
@@ -1025,8 +1047,8 @@ __global__ __launch_bounds__(64) void k_prologue(const uint32_t* __restrict__ ho
 #ifndef AMDAT_SMALL_PX
 #define AMDAT_SMALL_PX (16ull << 20)
 #endif
-#ifndef AMDAT_SMALL_PX_CC      // k_cc_local<16> below this many working pixels per submission
-#define AMDAT_SMALL_PX_CC AMDAT_SMALL_PX
+#ifndef AMDAT_SMALL_PX_CC      // k_cc_local<16> below this many working pixels per submission (eight 1080p frames: 0.089 ms with
+#define AMDAT_SMALL_PX_CC (8ull << 20)   // four waves per tile against 0.123 with sixteen -- the chip is full by then; four frames: 0.068 either way)
 #endif
 #ifndef AMDAT_SMALL_PX_PF      // CU-wide prefilter workgroups below this
 #define AMDAT_SMALL_PX_PF AMDAT_SMALL_PX
@@ -1154,7 +1176,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
 #define FS_ARGS D->d_frames, D->d_gray, D->d_pts, D->d_clusters, D->d_work + D->work_layout.off[c], D->d_workctl + c,               \
                 D->work_layout.cap[c], D->d_workctl + 8 + c, cl.d_lf, D->d_cands, D->d_counters, pop, P
         if (cl.small_k == 2) hipLaunchKernelGGL((k_fit_small<2, false>), grid, dim3(64), FS_LDS_BYTES(2, false), sc, FS_ARGS);
-        else hipLaunchKernelGGL((k_fit_small<4, true>), grid, dim3(64), FS_LDS_BYTES(4, true), sc, FS_ARGS);
+        else hipLaunchKernelGGL((k_fit_small<4, FS_K4_GROWS>), grid, dim3(64), FS_LDS_BYTES(4, FS_K4_GROWS), sc, FS_ARGS);
 #undef FS_ARGS
         return true;
       }
@@ -1213,8 +1235,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
       // 0.395 ms for one frame, 1.055 vs 1.065 for eight.  Priorities act on every slot that frees up, not on the first placement.)
       int a = 0;
       for (int c = pf_first - 1; c >= 0; c--)
-        if (launch_class(c, aux[a % FQ_NAUX])) a++;
-
+        if (launch_class(c, aux[a < FQ_NAUX ? a : FQ_NAUX - 1])) a++;   // (a fourth class queues behind the third: the two k_fit_small classes)
     } else {
     if (large_first) {
       launch_class(FQ_C0 + 3, s);

@@ -127,7 +127,53 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   const int X0 = bx_ * PT_TW, Y0 = by_ * PT_TH;
   const int tid = threadIdx.x;
 
-  {
+  // An INTERIOR tile -- all of its 17 x 66 entries inside the image, every pixel of it a valid emission source whose left
+  // neighbour is one too (nine tiles in ten at 1080p) -- takes the straight-line forms of the tile load and of the emission tests
+  // below: no per-entry bounds tests, row addresses as a uniform base plus the lane's offset (the general form pays two 64-bit
+  // multiply-adds per entry), the halo column with wave 1 and row 16 with wave 0 (five entries per thread instead of six in the
+  // wave the barrier waits for).
+#ifndef PT_INTERIOR
+#define PT_INTERIOR 1
+#endif
+  const bool interior = PT_INTERIOR && bx_ >= 1 && by_ >= 1 && X0 + PT_TW + 1 <= W && Y0 + PT_TH + 1 <= H;
+  if (interior) {
+    const int lane_ = tid & 63;
+    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint8_t* const t0 = thr + ((uint32_t)Y0 * (uint32_t)P.WS + (uint32_t)X0);                       // (uniform)
+    const char* const l0 = reinterpret_cast<const char*>(label + ((uint32_t)Y0 * (uint32_t)W + (uint32_t)X0));
+    const char* const lab0 = reinterpret_cast<const char*>(label);
+    const uint32_t WS_ = (uint32_t)P.WS, W4 = (uint32_t)W * 4u;
+    uint32_t v[5], l[5], r[5];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const uint32_t row = (uint32_t)(wvu + 4 * e);
+      v[e] = (t0 + row * WS_)[lane_];
+      l[e] = *reinterpret_cast<const uint32_t*>(l0 + row * W4 + (uint32_t)lane_ * 4u);
+    }
+    int si4 = -1;
+    v[4] = 127; l[4] = AT_NO_LABEL;
+    if (wvu == 0) {
+      v[4] = (t0 + (uint32_t)PT_TH * WS_)[lane_];
+      l[4] = *reinterpret_cast<const uint32_t*>(l0 + (uint32_t)PT_TH * W4 + (uint32_t)lane_ * 4u);
+      si4 = PT_TH * PT_LW + lane_ + 1;
+    } else if (wvu == 1 && lane_ < 2 * PT_LH) {
+      const uint32_t ly = (uint32_t)lane_ >> 1;
+      const int col = (lane_ & 1) ? PT_TW : -1;
+      v[4] = t0[(int)(ly * WS_) + col];
+      l[4] = *reinterpret_cast<const uint32_t*>(l0 + (int)(ly * W4) + col * 4);
+      si4 = (int)ly * PT_LW + ((lane_ & 1) ? PT_LW - 1 : 0);
+    }
+    // (inside the image a pixel has no label exactly when its value is 127; (l << 2) drops the flag bit of a root's own entry)
+#pragma unroll
+    for (int e = 0; e < 5; e++) {
+      r[e] = 0;
+      if (l[e] != AT_NO_LABEL) r[e] = *reinterpret_cast<const uint32_t*>(lab0 + (l[e] << 2));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      slab[(wvu + 4 * e) * PT_LW + lane_ + 1] = (r[e] >> 31) ? ((r[e] & PT_REP_MASK) | (v[e] == 255u ? PT_WHITE : PT_BLACK)) : 0u;
+    if (si4 >= 0) slab[si4] = (r[4] >> 31) ? ((r[4] & PT_REP_MASK) | (v[4] == 255u ? PT_WHITE : PT_BLACK)) : 0u;
+  } else {
     // tile + halo: 17 rows x 66 columns.  A wave takes rows wv, wv + 4, ... with lane = column (64 coalesced entries per
     // row, no division to find an entry's place), the 2 x 17 halo entries go to the first 34 threads.  Two dependent loads
     // per entry (pixel -> tile-local root l, then label[l] = representative | size bit, kernels_cc.h), issued level by level
@@ -175,9 +221,22 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   // key -- was measured slower, 9.6 vs 6.1 ms: a 64-pixel row step meets too many distinct component pairs.  Taking
   // the rank from the counting atomic's return value INSIDE this sparse loop was slower too, 7.8 ms.)
   // (straight-line: every lane reads its pixel's six words and forms the four tests; validity of the source pixel is two masks)
+  // (bit d * 4 + k of the mask = direction d of the thread's k-th pixel, tile pixel tid + 256 k: the list record of an emission --
+  // pixel | direction << 10 -- is tid + (bit << 8))
   uint32_t emask = 0;
   {
     auto opposite = [](uint32_t a, uint32_t b) { return (a ^ b) > 0xBFFFFFFFu; };   // one white, one black, both counted
+    if (interior) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int c = ((tid >> 6) + 4 * k) * PT_LW + lx + 1;
+        const uint32_t s0 = slab[c], s_l = slab[c - 1], s_r = slab[c + 1];
+        const uint32_t s_dl = slab[c + PT_LW - 1], s_d = slab[c + PT_LW], s_dr = slab[c + PT_LW + 1];
+        const uint32_t e0 = opposite(s0, s_r) ? 1u : 0u, e1 = opposite(s0, s_d) ? 16u : 0u;
+        const uint32_t e2 = (!opposite(s_l, s_d) && opposite(s0, s_dl)) ? 256u : 0u, e3 = opposite(s0, s_dr) ? 4096u : 0u;
+        emask |= (e0 | e1 | e2 | e3) << k;
+      }
+    } else {
     const bool gx_ok = gx >= 1 && gx <= W - 2;
     const bool left_is_source = gx - 1 >= 1;
 #pragma unroll
@@ -191,9 +250,10 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
       // upstream's connected_last: the left neighbour (a valid source itself) emitted its (1,1) point,
       // which is this pixel's (-1,1) half-pixel location
       const bool left_emits = left_is_source && opposite(s_l, s_d);
-      const uint32_t e0 = (ok && opposite(s0, s_r)) ? 1u : 0u, e1 = (ok && opposite(s0, s_d)) ? 2u : 0u;
-      const uint32_t e2 = (ok && !left_emits && opposite(s0, s_dl)) ? 4u : 0u, e3 = (ok && opposite(s0, s_dr)) ? 8u : 0u;
-      emask |= (e0 | e1 | e2 | e3) << (4 * k);
+      const uint32_t e0 = (ok && opposite(s0, s_r)) ? 1u : 0u, e1 = (ok && opposite(s0, s_d)) ? 16u : 0u;
+      const uint32_t e2 = (ok && !left_emits && opposite(s0, s_dl)) ? 256u : 0u, e3 = (ok && opposite(s0, s_dr)) ? 4096u : 0u;
+      emask |= (e0 | e1 | e2 | e3) << k;
+    }
     }
   }
   const uint32_t cnt = (uint32_t)__popc(emask);
@@ -216,7 +276,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     while (m && q < PT_ELIST) {
       const int sidx = __ffs((int)m) - 1;
       m &= m - 1;
-      elist[q++] = (uint32_t)(((tid >> 6) + 4 * (sidx >> 2)) * 64 + lx) | ((uint32_t)(sidx & 3) << 10);
+      elist[q++] = (uint32_t)tid + ((uint32_t)sidx << 8);
     }
   }
   __syncthreads();
@@ -263,12 +323,14 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   const uint32_t nlist = total < PT_ELIST ? total : PT_ELIST;
   for (uint32_t q = tid; q < nlist; q += 256) {
     const uint32_t rec = elist[q];
-    const int ly = (int)(rec & 1023u) >> 6, plx = (int)(rec & 63u), d = (int)((rec >> 10) & 3u);
-    const int c = ly * PT_LW + plx + 1;
-    const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
+    // slab index of the pixel: row * 66 + column + 1 = pixel + 2 * row + 1; of its neighbour: + 1, 66, 65, 67 by direction
+    const uint32_t pix = rec & 1023u;
+    const uint32_t c = pix + 2u * (pix >> 6) + 1u;
+    static_assert(PT_LW == 66, "neighbour offsets of pass 2");
+    const uint32_t dn = (0x43414201u >> ((rec >> 7) & 24u)) & 0xFFu;
     const uint32_t s0 = slab[c];
-    const uint32_t r0 = s0 & PT_REP_MASK, r1 = slab[c + ddy * PT_LW + ddx] & PT_REP_MASK;
-    const uint64_t key = r0 < r1 ? ((uint64_t)r0 << 32) | r1 : ((uint64_t)r1 << 32) | r0;
+    const uint32_t r0 = s0 & PT_REP_MASK, r1 = slab[c + dn] & PT_REP_MASK;
+    const uint64_t key = ((uint64_t)min(r0, r1) << 32) | max(r0, r1);
     const int e = ltab_insert(tkey, key);
     uint32_t ee = 255u, rk = 0u;
 #ifndef PT_NO_LEADER_ADD
@@ -304,7 +366,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     while (m) {
       const int sidx = __ffs((int)m) - 1;
       m &= m - 1;
-      if (q >= PT_ELIST) emit_long((uint32_t)(((tid >> 6) + 4 * (sidx >> 2)) * 64 + lx) | ((uint32_t)(sidx & 3) << 10), base + q);
+      if (q >= PT_ELIST) emit_long((uint32_t)tid + ((uint32_t)sidx << 8), base + q);
       q++;
     }
   }

@@ -125,7 +125,7 @@ def test_config_struct_size():
     assert L.amdCreateAprilTagsDetectorEx(C.byref(h), C.byref(cfg)) == 2
     assert not h
     L.amdAprilTagsConfigLayoutVersion.restype = C.c_uint32
-    assert L.amdAprilTagsConfigLayoutVersion() == 2
+    assert L.amdAprilTagsConfigLayoutVersion() == 3
 
 
 def test_register_custom_family():
