@@ -191,7 +191,7 @@ def threshold_roofline(frames_dev, decimate, reps=20):
     # (tools/thr_only.py; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), committed under
     # profiles/; bench.py cannot collect PMC counters itself.
     traffic, traffic_src = None, None
-    for name in ("r05_threshold_pmc.json", "r04_threshold_pmc.json", "r03_threshold_pmc.json", "r02_threshold_pmc.json", "r01_threshold_pmc.json"):
+    for name in ("r06_threshold_pmc.json", "r05_threshold_pmc.json", "r04_threshold_pmc.json", "r03_threshold_pmc.json", "r02_threshold_pmc.json", "r01_threshold_pmc.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if decimate == 1 and os.path.exists(pmc):
             rec = json.load(open(pmc))
@@ -225,7 +225,7 @@ def stage_rooflines(stage_ms, nframes, counts, decimate):
     P, Pk = counts["npoints_raw"], counts["npoints_kept"]
     alg = {"threshold": 2 * N, "cc_local": 5 * N, "points": 5 * N + 4 * P, "scatter": 4 * P + 4 * Pk, "fit_quads": 8 * Pk}
     pmc, pmc_src = None, None
-    for name in ("r05_pipeline_pmc.json", "r04_pipeline_pmc.json", "r03_pipeline_pmc.json"):
+    for name in ("r06_pipeline_pmc.json", "r05_pipeline_pmc.json", "r04_pipeline_pmc.json", "r03_pipeline_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if decimate == 1 and os.path.exists(path):
             pmc, pmc_src = json.load(open(path)), "profiles/" + name

@@ -1091,7 +1091,10 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
   {
     unsigned gr = (unsigned)(((size_t)P.W * P.H / 16 + 255) / 256);
     if (gr < 1) gr = 1;
-    if (gr > 1024) gr = 1024;
+#ifndef AMDAT_CC_ROOT_GRID
+#define AMDAT_CC_ROOT_GRID 1024
+#endif
+    if (gr > AMDAT_CC_ROOT_GRID) gr = AMDAT_CC_ROOT_GRID;
     hipLaunchKernelGGL(k_cc_sizes, dim3(gr, 1, n), dim3(256), 0, s, D->d_label, D->d_csize, D->d_roots, D->d_counters, P);
     hipLaunchKernelGGL(k_cc_resolve, dim3(gr, 1, n), dim3(256), 0, s, D->d_label, D->d_csize, D->d_roots, D->d_counters, P);
   }
@@ -1165,7 +1168,23 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
       if (P.max_cluster_points <= lo_eff || cl.hi <= cl.lo || (!cl.small_k && !cl.d_lf)) return false;
       if (small && cl.small_k) return false;   // (their clusters are in the one-wave class's list: work_layout_small)
       if (FQ_SKIP_CLASS(c)) return false;   // (tools_hooks.h: always 0 in the product build)
-      const dim3 grid(cl.grid);   // (a submission of n < max_batch frames still gets the handle's persistent grid)
+#ifndef AMDAT_SMALL_GRID64
+#define AMDAT_SMALL_GRID64 8   // workgroups per CU of the one-wave class on the latency set (0: the handle's grid)
+#endif
+#ifndef AMDAT_SMALL_GRID128
+#define AMDAT_SMALL_GRID128 2
+#endif
+      // (latency set: the one-wave class's sixteen workgroups per CU -- the throughput grid -- leave the 128- and 256-thread classes'
+      // workgroups waiting for slots; eight per CU: one 1080p frame 0.395 -> 0.383 ms, four 0.682 -> 0.650, eight 1.028 -> 1.00;
+      // six: the same; four: 0.397 / 0.723 / 1.12)
+      unsigned gsz = cl.grid;
+      if (AMDAT_SMALL_GRID64 && small && c == FQ_C0 && gsz > (unsigned)AMDAT_SMALL_GRID64 * (unsigned)D->num_cus) gsz = (unsigned)AMDAT_SMALL_GRID64 * (unsigned)D->num_cus;
+#ifndef AMDAT_SMALL_GRID256
+#define AMDAT_SMALL_GRID256 1
+#endif
+      if (AMDAT_SMALL_GRID256 && small && c == FQ_C0 + 2 && gsz > (unsigned)AMDAT_SMALL_GRID256 * (unsigned)D->num_cus) gsz = (unsigned)AMDAT_SMALL_GRID256 * (unsigned)D->num_cus;
+      if (AMDAT_SMALL_GRID128 && small && c == FQ_C0 + 1 && gsz > (unsigned)AMDAT_SMALL_GRID128 * (unsigned)D->num_cus) gsz = (unsigned)AMDAT_SMALL_GRID128 * (unsigned)D->num_cus;
+      const dim3 grid(gsz);   // (a submission of n < max_batch frames still gets the handle's persistent grid)
       const size_t lds = lds_bytes(cl);
       const bool big = c == FQ_NCLS - 1;
       // a small submission spreads its clusters over the workgroups one by one (latency); large ones pop in chunks

@@ -107,7 +107,7 @@ def test_config_struct_size():
     (size 0), one larger than the library's, or one shorter than the FIRST versioned layout (round 5's, which ends behind
     corner_convention: nothing shorter was ever published with a size field -- ADVICE round 5) is refused before anything else is
     looked at; a caller built against that first layout -- before `no_graph_replay` was appended -- is accepted and the field it
-    does not know takes its default (checked up to the first validation that fails without a device: a bad decimate still reports
+    does not know takes its default, and so is one built against layout 2, before `no_stream_priorities` (checked up to the first validation that fails without a device: a bad decimate still reports
     AMDAT_UNSUPPORTED, i.e. the shorter struct was read, not rejected)."""
     _need_lib()
     L = capi.lib()
@@ -124,6 +124,9 @@ def test_config_struct_size():
     cfg.no_graph_replay = 77                               # garbage beyond the caller's struct: never read
     assert L.amdCreateAprilTagsDetectorEx(C.byref(h), C.byref(cfg)) == 2
     assert not h
+    cfg.struct_size = capi.Config.no_stream_priorities.offset   # layout 2: + no_graph_replay
+    cfg.no_stream_priorities = 99
+    assert L.amdCreateAprilTagsDetectorEx(C.byref(h), C.byref(cfg)) == 2 and not h
     L.amdAprilTagsConfigLayoutVersion.restype = C.c_uint32
     assert L.amdAprilTagsConfigLayoutVersion() == 3
 

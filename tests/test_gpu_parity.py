@@ -1244,6 +1244,38 @@ def test_small_submissions_alternating_shapes_and_streams(built):
     det.close()
 
 
+def test_throughput_handle_without_stream_priorities_and_small_handles_beside_it(built):
+    """A throughput-sized handle (more than eight frames per submission) runs the fit's size classes on prioritised side streams;
+    `no_stream_priorities` (config layout 3) gives it plain ones -- for processes that also hold small handles, whose replayed launch
+    graphs this runtime otherwise places on the prioritised handle's hardware queues ("stream priorities").  Both
+    kinds of handle, and a one-frame handle created AFTER each of them (graph replay live), return the same records; the sixteen
+    frames are compared with the oracle."""
+    frames = np.stack([synth.scene_c2(seed=2300 + i, sigma=2.0)[0] for i in range(16)])
+    K = synth.scene_c2(seed=2300)[1]
+    t = torch.from_numpy(frames).cuda()
+
+    def same(x, y):
+        return len(x) == len(y) and all(a["id"] == b["id"] and np.array_equal(a["p"], b["p"]) and np.array_equal(a["R"], b["R"]) and
+                                        np.array_equal(a["t"], b["t"]) for a, b in zip(x, y))
+    results = []
+    for opt in ({}, {"no_stream_priorities": 1}):
+        big = AprilTagDetector(1920, 1080, intrinsics=_k4(K), max_batch=16, **opt)
+        r = big.detect_batch_ex(t, max_dets=64)
+        assert big.last_submission_path() == "throughput" and big.frame_flags(16) == [0] * 16
+        small = AprilTagDetector(1920, 1080, intrinsics=_k4(K), max_batch=1)
+        for _ in range(3):
+            r1 = small.detect_batch_ex(t[3], max_dets=64)[0]
+        assert small.graph_replay()[1] >= 1 and same(r1, r[3])
+        r_again = big.detect_batch_ex(t, max_dets=64)
+        assert all(same(a, b) for a, b in zip(r, r_again))
+        small.close(); big.close()
+        results.append(r)
+    assert all(same(a, b) for a, b in zip(results[0], results[1]))
+    for f in (0, 7, 15):
+        o, _ = po.detect(frames[f], params=pu.oracle_params(K, 1, 0.22))
+        assert len(o) == 10 and not pu.compare_detections(results[0][f], o)
+
+
 def test_point_capacity_grows_with_the_content(built):
     """Default handles start at one boundary point per working pixel and grow (doubling, up to two per pixel) when a frame
     overflows; the submission is repeated, so results never depend on the capacity.  One-pixel horizontal stripes
