@@ -521,6 +521,52 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ st
   const uint2* btab = btab_all + ((size_t)frame * bpf + blk) * PT_TB;
   const uint32_t* stage = stage_all + (size_t)frame * P.pcap + hdr.x;
   const int X0 = (int)(blk % gx_tiles) * PT_TW, Y0 = (int)(blk / gx_tiles) * PT_TH;
+#ifndef SC_LDS_TABLE
+#define SC_LDS_TABLE 1
+#endif
+#if SC_LDS_TABLE
+  // The tile's pair table is resolved ONCE per wave into LDS -- entry -> first position of the tile's points of that pair in the
+  // cluster's range, hoff[slot] + base rank -- so a record is one load (its staging word), one LDS read and one store; with the
+  // table entry and the range start fetched per record it was three dependent loads.  All 256 entries are resolved: which of them
+  // the tile used is known only to its records, and an unused one holds whatever an earlier submission left (a slot of the pair
+  // table, or -- first use of the buffer -- anything: slots beyond the table read as "none"), never looked at.
+  __shared__ uint32_t s_abs[4][PT_TB];
+  {
+    uint32_t* const mine = s_abs[threadIdx.x >> 6];
+    uint2 te[PT_TB / 64];
+    uint32_t ho[PT_TB / 64];
+#pragma unroll
+    for (int j = 0; j < PT_TB / 64; j++) te[j] = hdr.y ? btab[lane + 64u * (uint32_t)j] : make_uint2(AT_INVALID_SLOT, 0u);
+#pragma unroll
+    for (int j = 0; j < PT_TB / 64; j++) ho[j] = te[j].x < P.hcap ? hoff[te[j].x] : AT_INVALID_SLOT;
+#pragma unroll
+    for (int j = 0; j < PT_TB / 64; j++) mine[lane + 64u * (uint32_t)j] = ho[j] != AT_INVALID_SLOT ? ho[j] + te[j].y : AT_INVALID_SLOT;
+  }
+  __syncthreads();
+  const uint32_t* const tabs = s_abs[threadIdx.x >> 6];
+  for (uint32_t i0 = lane; i0 < hdr.y; i0 += SC_U * 64) {
+    uint32_t w[SC_U];
+#pragma unroll
+    for (int u = 0; u < SC_U; u++) {
+      const uint32_t i = i0 + (uint32_t)u * 64u;
+      w[u] = i < hdr.y ? __builtin_nontemporal_load(stage + i) : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < SC_U; u++) {
+      if ((w[u] & 255u) == 255u) continue;   // (a long record's place holder, or beyond the tile's records)
+      const uint32_t base = tabs[w[u] & 255u];
+      if (base == AT_INVALID_SLOT) continue;
+      const uint32_t pix = (w[u] >> 19) & 1023u;
+      const int ly = (int)(pix >> 6), plx = (int)(pix & 63u), d = (int)((w[u] >> 29) & 3u);
+      const int ddx = (d == 2) ? -1 : (d == 1 ? 0 : 1), ddy = (d == 0) ? 0 : 1;
+      // packed point = x << 18 | y << 4 | (sign of gx + 1) << 2 | (sign of gy + 1), the gradient (dx, dy) * (+-255): pack_point
+      // without its divisions by 255
+      const int sgn = (w[u] >> 31) ? -1 : 1;
+      pts[base + ((w[u] >> 8) & 2047u)] = ((uint32_t)(2 * (X0 + plx) + ddx) << 18) | ((uint32_t)(2 * (Y0 + ly) + ddy) << 4) |
+                                          ((uint32_t)(ddx * sgn + 1) << 2) | (uint32_t)(ddy * sgn + 1);
+    }
+  }
+#else
   // Three dependent loads per record (staging word -> table entry -> range start).  A tile has a few records per thread:
   // they are taken SC_U at a time, level by level, so that the latencies of a thread's records overlap instead of adding up.
   for (uint32_t i0 = lane; i0 < hdr.y; i0 += SC_U * 64) {
@@ -548,6 +594,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ st
                                                        ((uint32_t)(ddx * sgn + 1) << 2) | (uint32_t)(ddy * sgn + 1);
     }
   }
+#endif
   uint32_t nl = counters[frame].nlong;
   if (nl > P.lcap) nl = P.lcap;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nl; i += gridDim.x * 256) {
