@@ -272,11 +272,15 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   // the emitters go to a block-wide list in LDS at the thread's scan offset: record = pixel (10 bits) | direction (2);
   // emissions beyond the list capacity (more than two per pixel of the tile on average) are kept by their thread
   {
-    uint32_t q = off, m = emask;
-    while (m && q < PT_ELIST) {
-      const int sidx = __ffs((int)m) - 1;
+    // (the number of records this thread writes is known up front -- its emissions, cut where the list ends --, so a trip of the
+    // loop is find-first-set, record, clear, store: no test of the mask or of the list's end per trip)
+    const uint32_t room = off < PT_ELIST ? PT_ELIST - off : 0u;
+    uint32_t m = emask;
+    uint32_t* dst = elist + off;
+    for (uint32_t n = cnt < room ? cnt : room; n; n--) {
+      const uint32_t sidx = (uint32_t)__builtin_ctz(m);   // (m != 0: n counts its set bits)
       m &= m - 1;
-      elist[q++] = (uint32_t)tid + ((uint32_t)sidx << 8);
+      *dst++ = (uint32_t)tid | (sidx << 8);
     }
   }
   __syncthreads();
