@@ -103,7 +103,7 @@ typedef struct {
   uint32_t width;
   uint32_t height;
   const uint8_t* dev_ptr; /* mono8 (or, in the *Color calls, interleaved colour), device memory */
-  size_t pitch;           /* bytes per row; pitch * height must stay below 2^31 (AMDAT_INVALID_ARGUMENT otherwise) */
+  size_t pitch;           /* bytes per row; below 2^24, and pitch * height below 2^31 (AMDAT_INVALID_ARGUMENT otherwise) */
 } amdAprilTagsImageInput_t;
 
 typedef struct {

@@ -915,6 +915,7 @@ static int check_images(amdAprilTagsDetector_st* D, uint32_t n, const amdAprilTa
     if (images[i].width != D->cfg.width || images[i].height != D->cfg.height) return AMDAT_SIZE_MISMATCH;
     if (images[i].pitch < (size_t)images[i].width * enc_channels(fmt)) return AMDAT_INVALID_ARGUMENT;
     if ((uint64_t)images[i].pitch * images[i].height > 0x7FFFFFFFull) return AMDAT_INVALID_ARGUMENT;   // 32-bit pixel offsets on the device
+    if (images[i].pitch >= (1u << 24)) return AMDAT_INVALID_ARGUMENT;   // (row offsets are formed with 24-bit multiplies: a 16 MB row is no image)
   }
   return AMDAT_SUCCESS;
 }

@@ -1065,7 +1065,7 @@ __device__ __forceinline__ void fit_quads_body(const FrameDesc* __restrict__ fra
           const int ix = (int)((px + 1) >> 1), iy = (int)((py + 1) >> 1);
           uint32_t G = 0;
           if (((unsigned)(ix - 1) < (unsigned)(W - 2)) & ((unsigned)(iy - 1) < (unsigned)(H - 2))) {
-            const uint32_t o = (uint32_t)iy * (uint32_t)gpitch + (uint32_t)ix;
+            const uint32_t o = __umul24((uint32_t)iy, (uint32_t)gpitch) + (uint32_t)ix;   // (rows below 2^14, pitches below 2^24: check_images)
             const int g_r = ggray[o + 1], g_l = ggray[o - 1], g_d = ggray[o + (uint32_t)gpitch], g_u = ggray[o - (uint32_t)gpitch];
             const int grad_x = g_r - g_l, grad_y = g_d - g_u;
             G = (uint32_t)(grad_x * grad_x + grad_y * grad_y);
@@ -1152,7 +1152,7 @@ __device__ __forceinline__ void fit_quads_body(const FrameDesc* __restrict__ fra
           const double x = (int)(px + 1) * .5, y = (int)(py + 1) * .5;
           const int ix = (int)((px + 1) >> 1), iy = (int)((py + 1) >> 1);
           if (((unsigned)(ix - 1) < (unsigned)(W - 2)) & ((unsigned)(iy - 1) < (unsigned)(H - 2))) {
-            const uint32_t o = (uint32_t)iy * (uint32_t)gpitch + (uint32_t)ix;
+            const uint32_t o = __umul24((uint32_t)iy, (uint32_t)gpitch) + (uint32_t)ix;   // (rows below 2^14, pitches below 2^24: check_images)
             const int g_r = ggray[o + 1], g_l = ggray[o - 1], g_d = ggray[o + (uint32_t)gpitch], g_u = ggray[o - (uint32_t)gpitch];
             const int grad_x = g_r - g_l, grad_y = g_d - g_u;
             G = (uint32_t)(grad_x * grad_x + grad_y * grad_y);
@@ -1234,20 +1234,21 @@ __device__ __forceinline__ void fit_quads_body(const FrameDesc* __restrict__ fra
         szd = __builtin_amdgcn_readlane(kincl, 63);
       }
       // walk 2: replay the lane's points from its exclusive offset
+      // (the row pointer advances with the kept points: formed from the position per point it was a 64-bit multiply-add a trip)
+      double* o = lf + (size_t)pos * 6;
       for (int i = i0; i < i1; i++) {
         const unsigned long long st = in_lds ? skeys[FQ_KP(i)] : gkeys[i];
         if (st >> 63) {
           const double x = (int)(((uint32_t)st & 0x3FFFu) + 1u) * .5, y = (int)(((uint32_t)(st >> 14) & 0x3FFFu) + 1u) * .5;
           const double Wt = sqrt_u18((uint32_t)(st >> 28) & 0x3FFFFu) + 1;
           const double tt[6] = {Wt * x, Wt * y, Wt * x * x, Wt * x * y, Wt * y * y, Wt};
-          double* o = lf + (size_t)pos * 6;
 #pragma unroll
           for (int j = 0; j < 6; j++) {
             const D2 t = split_term(tt[j]);
             off[j].hi += t.hi; off[j].lo += t.lo;
             o[j] = off[j].hi + off[j].lo;
           }
-          pos++;
+          o += 6;
         }
       }
     } else {
@@ -1837,7 +1838,7 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
           const int ix = (int)((px + 1) >> 1), iy = (int)((py + 1) >> 1);
           GG[e] = 0;
           if ((base + tid * 8 + e < sz) & ((unsigned)(ix - 1) < (unsigned)(W - 2)) & ((unsigned)(iy - 1) < (unsigned)(H - 2))) {
-            const uint32_t o = (uint32_t)iy * (uint32_t)gpitch + (uint32_t)ix;
+            const uint32_t o = __umul24((uint32_t)iy, (uint32_t)gpitch) + (uint32_t)ix;   // (rows below 2^14, pitches below 2^24: check_images)
             const int g_r = ggray[o + 1], g_l = ggray[o - 1], g_d = ggray[o + (uint32_t)gpitch], g_u = ggray[o - (uint32_t)gpitch];
             const int grad_x = g_r - g_l, grad_y = g_d - g_u;
             GG[e] = (uint32_t)(grad_x * grad_x + grad_y * grad_y);

@@ -216,7 +216,7 @@ __device__ __forceinline__ void fit_small_body(const FrameDesc* __restrict__ fra
         const double x = (int)(px + 1) * .5, y = (int)(py + 1) * .5;
         const int ix = (int)((px + 1) >> 1), iy = (int)((py + 1) >> 1);
         if (((unsigned)(ix - 1) < (unsigned)(W - 2)) & ((unsigned)(iy - 1) < (unsigned)(H - 2))) {
-          const uint32_t o = (uint32_t)iy * (uint32_t)gpitch + (uint32_t)ix;
+          const uint32_t o = __umul24((uint32_t)iy, (uint32_t)gpitch) + (uint32_t)ix;   // (rows below 2^14, pitches below 2^24: check_images)
           const int g_r = ggray[o + 1], g_l = ggray[o - 1], g_d = ggray[o + (uint32_t)gpitch], g_u = ggray[o - (uint32_t)gpitch];
           const int grad_x = g_r - g_l, grad_y = g_d - g_u;
           G = (uint32_t)(grad_x * grad_x + grad_y * grad_y);
