@@ -152,7 +152,7 @@ __device__ __forceinline__ void fit_small_body(const FrameDesc* __restrict__ fra
       const int x = (int)(p >> 18), y = (int)((p >> 4) & 0x3FFF);
       const int gx = (int)((p >> 2) & 3) - 1, gy = (int)(p & 3) - 1;
       xmin = min(xmin, x); xmax = max(xmax, x); ymin = min(ymin, y); ymax = max(ymax, y);
-      sxg += x * gx + y * gy;
+      sxg += __mul24(x, gx) + __mul24(y, gy);
       sg += gx * 65536 + gy;
     }
     xmin = wave_min_i(xmin); xmax = wave_max_i(xmax); ymin = wave_min_i(ymin); ymax = wave_max_i(ymax);
