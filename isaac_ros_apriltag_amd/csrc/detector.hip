@@ -209,6 +209,7 @@ struct amdAprilTagsDetector_st {
   bool grow_points = false;          // point capacity follows the content (no explicit max_points)
   bool grow_hash = false;            // the same for the component-pair table (no explicit hash_slots)
   bool pending_hash_grow = false;
+  uint32_t lcap_div = 0;             // long-record capacity = point capacity / lcap_div (alloc_point_buffers; halves when the long records overflow)
   bool unusable = false;             // a capacity change failed twice (grown and original size): buffers are gone, every later call reports it
   size_t cands_bytes = 0;
   uint32_t hcap_hard = 0;
@@ -501,12 +502,16 @@ static int alloc_point_buffers(amdAprilTagsDetector_st* D) {
   for (int k = 0; k < FQ_C0; k++) { D->work_layout_small.lo[k] = 23; D->work_layout_small.hi[k] = 0; }
   D->work_layout_small.lo[FQ_C0] = 23;
   // Long staging records (kernels_cluster.h) only occur where a 64 x 16 tile has more than 2048 emissions -- above two per pixel --
-  // or more than 255 component pairs; an eighth of the point capacity is room for them (an overflow reports like a point
-  // overflow and grows with the point buffers).  Tools builds that shrink the tile's list take the whole capacity.
+  // or more than 255 component pairs; an eighth of the point capacity is room for them on ordinary content.  An overflow reports
+  // like a point overflow (0x1); the host tells the two apart by the counters and grows the list by itself -- a quarter, half, all
+  // of the point capacity (end_batch): two-level noise near the percolation threshold puts more than a quarter of its points there
+  // (a fuzz case of round 6: such a frame used to keep its overflow flag at the largest point capacity).  Tools builds that shrink
+  // the tile's list start with the whole capacity.
 #ifndef AMDAT_LCAP_DIV
 #define AMDAT_LCAP_DIV 8
 #endif
-  P.lcap = P.pcap / AMDAT_LCAP_DIV > 4096u ? P.pcap / AMDAT_LCAP_DIV : 4096u;
+  if (D->lcap_div == 0) D->lcap_div = AMDAT_LCAP_DIV;
+  P.lcap = P.pcap / D->lcap_div > 4096u ? P.pcap / D->lcap_div : 4096u;
   void** bufs[5] = {(void**)&D->d_stage, (void**)&D->d_long, (void**)&D->d_pts, (void**)&D->d_work, (void**)&D->d_work2};
   const size_t bytes[5] = {B * (size_t)P.pcap * 4, B * (size_t)P.lcap * 16, B * (size_t)P.pcap * 4, (size_t)off * 4,
                            ((size_t)off - D->work_layout.off[D->prefilter_class]) * 4};
@@ -1547,9 +1552,14 @@ static int end_batch(amdAprilTagsDetector_st* D) {
     // A frame whose boundary points did not fit yields no clusters at all (flag 0x1), one whose component pairs did not fit
     // loses clusters (0x2).  Unless the host fixed the capacities, the buffers grow -- doubling, up to what no content
     // exceeds -- and the submission runs again; a pair table filled beyond a quarter grows for the next submission.
-    bool pts_over = false, hash_over = false, hash_crowded = false;
+    bool pts_over = false, hash_over = false, hash_crowded = false, long_over = false;
+    uint32_t nlong_max = 0;
     for (uint32_t f = 0; f < n; f++) {
-      pts_over |= (D->h_counters[f].flags & 0x1u) != 0;
+      // (0x1 covers both the staging words and the long records: the counters say which list it was -- both count every attempt)
+      if (D->h_counters[f].flags & 0x1u) {
+        if (D->h_counters[f].nlong > D->P.lcap) { long_over = true; if (D->h_counters[f].nlong > nlong_max) nlong_max = D->h_counters[f].nlong; }
+        if (D->h_counters[f].npoints_raw > D->P.pcap || D->h_counters[f].nlong <= D->P.lcap) pts_over = true;
+      }
       hash_over |= (D->h_counters[f].flags & 0x2u) != 0;
       hash_crowded |= D->h_counters[f].nclusters > D->P.hcap / 4;
     }
@@ -1580,20 +1590,24 @@ static int end_batch(amdAprilTagsDetector_st* D) {
     }
     if (!again) {
       const bool can_pts = D->grow_points && D->P.pcap < D->pcap_hard;
+      const bool can_long = D->grow_points && D->lcap_div > 1;
       const bool can_hash = D->grow_hash && D->P.hcap < D->hcap_hard;
-      const bool redo = (pts_over && can_pts) || (hash_over && can_hash);
+      const bool redo = (pts_over && can_pts) || (long_over && can_long) || (hash_over && can_hash);
       if (!redo) {   // (a crowded table grows before the next submission: this one's buffers may still be inspected)
         if (hash_crowded && can_hash) D->pending_hash_grow = true;
         return AMDAT_SUCCESS;
       }
       drop_graphs_for_regrowth(D);   // captured launches carry the old pointers and capacities
-      const uint32_t pcap_before = D->P.pcap, hcap_before = D->P.hcap;
+      const uint32_t pcap_before = D->P.pcap, hcap_before = D->P.hcap, ldiv_before = D->lcap_div;
       if (pts_over && can_pts) { const uint64_t want = (uint64_t)D->P.pcap * 2; D->P.pcap = want > D->pcap_hard ? D->pcap_hard : (uint32_t)want; }
+      if (long_over && can_long) {   // the smallest share of the (new) point capacity that holds what this submission asked for
+        do D->lcap_div >>= 1; while (D->lcap_div > 1 && D->P.pcap / D->lcap_div < nlong_max);
+      }
       if (hash_over && can_hash) D->P.hcap = D->P.hcap * 2 > D->hcap_hard ? D->hcap_hard : D->P.hcap * 2;
       int grc = alloc_hash_buffers(D);
       if (grc == AMDAT_SUCCESS) grc = alloc_point_buffers(D);   // (also when only the staging format changed)
       if (grc != AMDAT_SUCCESS) {   // not enough memory to grow: keep reporting the overflow with the old capacities
-        D->P.pcap = pcap_before; D->P.hcap = hcap_before;
+        D->P.pcap = pcap_before; D->P.hcap = hcap_before; D->lcap_div = ldiv_before;
         D->grow_points = false; D->grow_hash = false;
         if (alloc_hash_buffers(D) != AMDAT_SUCCESS || alloc_point_buffers(D) != AMDAT_SUCCESS) { D->unusable = true; return AMDAT_OUT_OF_MEMORY; }
         return AMDAT_SUCCESS;

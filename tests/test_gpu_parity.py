@@ -1306,6 +1306,49 @@ def test_point_capacity_grows_with_the_content(built):
     fixed.close()
 
 
+def test_long_record_capacity_grows_with_the_content(built):
+    """Two-level noise near the percolation threshold -- every pixel 0 or 255, two fifths white -- gives a 64 x 16 tile more than 255
+    component pairs, so most of its boundary points travel as long staging records (kernels_cluster.h).  Their list starts at an
+    eighth of the point capacity and used to grow only WITH the point buffers (to a quarter of the largest point capacity at
+    most): a fuzz case of round 6 (two-level noise, 430 x 492) kept its overflow flag and lost every cluster.  The list now grows
+    by itself -- a quarter, half, all of the point capacity -- and the submission is repeated: every stage equals the oracle's,
+    alone and as one frame of a three-frame submission on both launch sets; an explicit max_points still reports the overflow."""
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_r06_two_level_noise_430x492.npz"))
+    w, h = int(fx["w"]), int(fx["h"])
+    img = (np.unpackbits(fx["bits"])[:w * h].reshape(h, w) * 255).astype(np.uint8)   # (the fuzzer's frame: 40 % white)
+    rng = np.random.default_rng(879)
+    other = ((rng.random((h, w)) < 0.3) * 255).astype(np.uint8)
+    K = synth.default_K(w, h)
+    t = torch.from_numpy(img).cuda()
+    det = AprilTagDetector(w, h, intrinsics=_k4(K), families=("tag25h9",), max_batch=1)
+    before = det.device_bytes()
+    g = det.detect_batch_ex(t, max_dets=64)[0]
+    assert det.frame_flags(1) == [0]
+    # (the point buffers double once -- 10 bytes per point and 2 more per long-record slot at an eighth -- and the long records' list
+    # grows beyond that doubling)
+    assert det.device_bytes() - before > (10 + 16 // 4) * w * h
+    errs, odets = pu.compare_stages(det, 0, img, ("tag25h9",), K, 1)
+    errs += pu.compare_detections(g, odets)
+    assert not errs, errs[:4]
+    det.close()
+    for path in PATHS:
+        det = AprilTagDetector(w, h, intrinsics=_k4(K), families=("tag25h9",), max_batch=3)
+        det.set_submission_path(path)
+        frames = [other, img, other]
+        ts = [torch.from_numpy(f).cuda() for f in frames]
+        gs = det.detect_batch_ex([(x.data_ptr(), w) for x in ts], max_dets=64)
+        assert det.frame_flags(3) == [0, 0, 0]
+        for f in range(3):
+            errs, odets = pu.compare_stages(det, f, frames[f], ("tag25h9",), K, 1)
+            errs += pu.compare_detections(gs[f], odets)
+            assert not errs, (path, f, errs[:4])
+        det.close()
+    fixed = AprilTagDetector(w, h, intrinsics=_k4(K), families=("tag25h9",), max_batch=1, max_points=2 * w * h)
+    fixed.detect_batch_ex(t, max_dets=64)
+    assert fixed.frame_flags(1)[0] & 1                             # reported, not grown
+    fixed.close()
+
+
 def test_multi_camera_node(built):
     """AprilTagMultiCameraNode: eight camera streams with their own intrinsics, frame ids and
     stamps go through ONE node that stages the latest frame of each and submits them as one batch.  Every stream's message
