@@ -88,7 +88,25 @@ def tag_scene(rng, h, w, fams):
     return img
 
 
-def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None, batch=1, only=None, dump=None):
+def colour_frame(rng, gray_like, encoding, pitch_pad):
+    """A colour frame with random chroma around the content (so that a swapped channel order cannot pass) and garbage behind every
+    row; returns (host buffer [h, pitch bytes], pitch, the numpy-converted gray frame -- the fixed-point BT.601 statement)."""
+    h, w = gray_like.shape
+    nch = capi.ENC_CHANNELS[encoding]
+    order = (0, 1, 2) if encoding in ("rgb8", "rgba8") else (2, 1, 0)
+    base = gray_like.astype(np.int32)
+    amp = int(rng.integers(0, 60))
+    rgb = np.stack([np.clip(base + rng.integers(-amp, amp + 1, size=(h, w)), 0, 255) for _ in range(3)], axis=2).astype(np.uint8)
+    pitch = w * nch + pitch_pad
+    buf = rng.integers(0, 256, size=(h, pitch), dtype=np.uint8)
+    px = buf[:, :w * nch].reshape(h, w, nch)
+    for c in range(3):
+        px[..., order[c]] = rgb[..., c]
+    r, g, b = (rgb[..., i].astype(np.uint32) for i in range(3))
+    return buf, pitch, ((4899 * r + 9617 * g + 1868 * b + 8192) >> 14).astype(np.uint8)
+
+
+def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None, batch=1, only=None, dump=None, colour=False):
     """Returns (cases run, list of failure strings).  path: None (the library picks the launch set by size: the latency set at these
     sizes), "latency", "throughput", or "alternate" (even cases latency, odd cases throughput).  batch > 1: every case submits `batch` frames
     of the case's size, each with content of its own, in ONE call, and every frame is compared (frame indexing of every stage)."""
@@ -136,8 +154,14 @@ def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None, batch=1
             continue
         if path is not None:
             det.set_submission_path(("latency", "throughput")[case & 1] if path == "alternate" else path)
+        enc = "mono8"
+        if colour:   # the same content as interleaved colour frames (one encoding per submission), read by the threshold pass's loader
+            enc = ("rgb8", "bgr8", "rgba8", "bgra8")[int(rng.integers(0, 4))]
+            pad = int(rng.choice([0, 0, 1, 3, 16, 37]))
+            cf = [colour_frame(rng, im, enc, pad) for im in imgs]
+            bufs = [c[0] for c in cf]; pitch = cf[0][1]; imgs = [c[2] for c in cf]
         ts = [torch.from_numpy(b).cuda() for b in bufs]
-        gs = det.detect_batch_ex([(t.data_ptr(), pitch) for t in ts], max_dets=256)
+        gs = det.detect_batch_ex([(t.data_ptr(), pitch) for t in ts], max_dets=256, encoding=enc)
         errs = []
         for f in range(batch):
             e, odets = pu.compare_stages(det, f, np.ascontiguousarray(imgs[f]), fams, K, dec)
@@ -146,8 +170,8 @@ def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None, batch=1
         det.close()
         done += 1
         if errs:
-            fails.append("case %d FAIL kind %s %dx%d pitch %d dec %d fams %s: %s" % (case, kind, w, h, pitch, dec, fams,
-                                                                                  errs[:3]))
+            fails.append("case %d FAIL kind %s %dx%d pitch %d dec %d fams %s enc %s: %s" % (case, kind, w, h, pitch, dec, fams, enc,
+                                                                                         errs[:3]))
             out(fails[-1])
     return done, fails
 
@@ -161,11 +185,12 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="frames per case (one submission)")
     ap.add_argument("--only", type=int, default=None, help="run this case only (the cases before it are generated and skipped)")
     ap.add_argument("--dump", default=None, help="with --only: write the case's frames to this .npz")
+    ap.add_argument("--colour", action="store_true", help="submit the content as rgb8 / bgr8 / rgba8 / bgra8 frames with random chroma")
     ap.add_argument("--path", default="alternate", help="launch set: latency | throughput | alternate | auto")
     a = ap.parse_args()
     t0 = time.time()
     done, fails = run_cases(a.cases, a.seed, a.maxdim, a.budget, out=lambda m: print(m, flush=True), path=None if a.path == "auto" else a.path, batch=a.batch,
-                            only=a.only, dump=a.dump)
+                            only=a.only, dump=a.dump, colour=a.colour)
     print("fuzz: %d cases, %d failed, %.1f s" % (done, len(fails), time.time() - t0))
     sys.exit(1 if fails else 0)
 
