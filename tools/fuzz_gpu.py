@@ -106,7 +106,7 @@ def colour_frame(rng, gray_like, encoding, pitch_pad):
     return buf, pitch, ((4899 * r + 9617 * g + 1868 * b + 8192) >> 14).astype(np.uint8)
 
 
-def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None, batch=1, only=None, dump=None, colour=False):
+def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None, batch=1, only=None, dump=None, colour=False, tile=4):
     """Returns (cases run, list of failure strings).  path: None (the library picks the launch set by size: the latency set at these
     sizes), "latency", "throughput", or "alternate" (even cases latency, odd cases throughput).  batch > 1: every case submits `batch` frames
     of the case's size, each with content of its own, in ONE call, and every frame is compared (frame indexing of every stage)."""
@@ -147,8 +147,10 @@ def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None, batch=1
         K = synth.default_K(w, h)
         try:
             det = AprilTagDetector(w, h, intrinsics=(K[0, 0], K[1, 1], K[0, 2], K[1, 2]), families=fams, decimate=dec,
-                                   max_batch=batch)
+                                   max_batch=batch, tile_size=tile)
         except Exception as e:  # noqa: BLE001
+            if tile > 4 and min(1 + (w - 1) // dec, 1 + (h - 1) // dec) < tile:
+                continue   # (a working image below one tile a side is refused at creation: AMDAT_UNSUPPORTED, by design)
             fails.append("case %d: create failed for %dx%d dec %d: %s" % (case, w, h, dec, e))
             out(fails[-1])
             continue
@@ -164,7 +166,7 @@ def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None, batch=1
         gs = det.detect_batch_ex([(t.data_ptr(), pitch) for t in ts], max_dets=256, encoding=enc)
         errs = []
         for f in range(batch):
-            e, odets = pu.compare_stages(det, f, np.ascontiguousarray(imgs[f]), fams, K, dec)
+            e, odets = pu.compare_stages(det, f, np.ascontiguousarray(imgs[f]), fams, K, dec, tile_size=tile)
             e += pu.compare_detections(gs[f], odets)
             errs += ["frame %d: %s" % (f, x) for x in e] if batch > 1 else e
         det.close()
@@ -185,12 +187,13 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="frames per case (one submission)")
     ap.add_argument("--only", type=int, default=None, help="run this case only (the cases before it are generated and skipped)")
     ap.add_argument("--dump", default=None, help="with --only: write the case's frames to this .npz")
+    ap.add_argument("--tile", type=int, default=4, help="tile_size of the handle (4 or 8)")
     ap.add_argument("--colour", action="store_true", help="submit the content as rgb8 / bgr8 / rgba8 / bgra8 frames with random chroma")
     ap.add_argument("--path", default="alternate", help="launch set: latency | throughput | alternate | auto")
     a = ap.parse_args()
     t0 = time.time()
     done, fails = run_cases(a.cases, a.seed, a.maxdim, a.budget, out=lambda m: print(m, flush=True), path=None if a.path == "auto" else a.path, batch=a.batch,
-                            only=a.only, dump=a.dump, colour=a.colour)
+                            only=a.only, dump=a.dump, colour=a.colour, tile=a.tile)
     print("fuzz: %d cases, %d failed, %.1f s" % (done, len(fails), time.time() - t0))
     sys.exit(1 if fails else 0)
 
