@@ -165,7 +165,8 @@ typedef struct {
   uint32_t max_points;         /* boundary points; default 2 per working pixel */
   uint32_t hash_slots;         /* power of two */
   uint32_t max_clusters;
-  uint32_t max_quads;
+  uint32_t max_quads;          /* 0: starts at min(cluster capacity, 16 384) and doubles when a frame fills it; an explicit value is
+                                * never grown and reports AMDAT_FLAG_QUADS_OVERFLOW */
   uint32_t max_detections;
   int32_t device;              /* HIP device ordinal, -1 = current */
   float skew;                  /* K[0][1] of the pinhole matrix; 0 on the cuAprilTags-shaped path, the VPI path of

@@ -208,6 +208,8 @@ struct amdAprilTagsDetector_st {
   int prefilter_class = FQ_C0 + 2;           // first size class whose clusters go through k_fit_prefilter (those above 2048 points)
   bool grow_points = false;          // point capacity follows the content (no explicit max_points)
   bool grow_hash = false;            // the same for the component-pair table (no explicit hash_slots)
+  bool grow_quads = false;           // the same for the quad list (no explicit max_quads): doubles up to the cluster capacity
+  size_t quads_bytes = 0;
   bool pending_hash_grow = false;
   uint32_t lcap_div = 0;             // long-record capacity = point capacity / lcap_div (alloc_point_buffers; halves when the long records overflow)
   bool unusable = false;             // a capacity change failed twice (grown and original size): buffers are gone, every later call reports it
@@ -635,6 +637,8 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   P.ccap = cfg.max_clusters ? cfg.max_clusters : (D->hcap_hard < 65536 ? D->hcap_hard : 65536);
   if (P.ccap > 65536) P.ccap = 65536;                 // a work item carries the cluster index in 16 bits
   P.qcap = cfg.max_quads ? cfg.max_quads : (P.ccap < 16384 ? P.ccap : 16384);
+  D->grow_quads = cfg.max_quads == 0;   // (a two-megapixel checkerboard of two-pixel cells has 29 000 quads: the list doubles and the
+                                        // submission is repeated, end_batch; an explicit max_quads reports AMDAT_FLAG_QUADS_OVERFLOW)
   P.dcap = cfg.max_detections ? cfg.max_detections : 1024;
   if (P.dcap > 65535) P.dcap = 65535;
 
@@ -736,6 +740,7 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
     alloc((void**)&D->d_keys_scr, (size_t)c.grid * c.slot_cap * 8);
   }
   alloc((void**)&D->d_quads, B * (size_t)P.qcap * sizeof(QuadRec));
+  D->quads_bytes = B * (size_t)P.qcap * sizeof(QuadRec);
   // every kept cluster can become a candidate (ccap); the list starts at the quad capacity and grows when a frame fills it
   P.cand_cap = P.qcap;
   alloc((void**)&D->d_cands, B * (size_t)P.cand_cap * sizeof(FitCand));
@@ -1566,7 +1571,30 @@ static int end_batch(amdAprilTagsDetector_st* D) {
     bool cands_over = false;
     for (uint32_t f = 0; f < n; f++) cands_over |= (D->h_counters[f].flags & AT_FLAG_CANDS) != 0;
     bool again = false;
-    if (cands_over) {
+    {   // the quad list of a handle without an explicit max_quads follows the content like the candidate list
+      bool quads_over = false;
+      for (uint32_t f = 0; f < n; f++) quads_over |= (D->h_counters[f].flags & 0x8u) != 0 && D->h_counters[f].nquads > D->P.qcap;
+      if (quads_over && D->grow_quads && D->P.qcap < D->P.ccap) {
+        const uint64_t want = (uint64_t)D->P.qcap * 2;
+        const uint32_t ncap = want > D->P.ccap ? D->P.ccap : (uint32_t)want;
+        QuadRec* nb = nullptr;
+        const size_t nbytes = (size_t)D->cfg.max_batch * ncap * sizeof(QuadRec);
+        if (hipMalloc((void**)&nb, nbytes) == hipSuccess) {
+          drop_graphs_for_regrowth(D);
+          hipFree(D->d_quads);
+          D->d_quads = nb;
+          D->device_bytes += nbytes - D->quads_bytes;
+          D->quads_bytes = nbytes;
+          D->P.qcap = ncap;
+          D->grown++;
+          again = true;
+        } else {
+          (void)hipGetLastError();
+          D->grow_quads = false;   // (not enough memory: the overflow is reported from here on)
+        }
+      }
+    }
+    if (!again && cands_over) {
       if (D->P.cand_cap < D->P.ccap) {   // grow the candidate list and repeat
         drop_graphs_for_regrowth(D);
         const uint64_t want = (uint64_t)D->P.cand_cap * 2;

@@ -900,6 +900,32 @@ def test_checkerboard_more_quads_than_the_old_fixed_capacity(built):
     assert nq > 8192
 
 
+def test_quad_list_grows_with_the_content(built):
+    """The default quad capacity starts at min(cluster capacity, 16 384) and doubles when a frame fills it (the submission is
+    repeated): a 1600 x 1500 checkerboard of 8-pixel cells has 18 340 quads -- a fuzz case of round 6, a larger board, came back
+    with AMDAT_FLAG_QUADS_OVERFLOW and 16 384 of 29 092 quads.  Every stage equals the oracle's, no flag is left; an explicit
+    max_quads is never grown and reports the overflow."""
+    w, h = 1600, 1500
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = ((((yy // 8) + (xx // 8)) & 1) * 200).astype(np.uint8)
+    K = synth.default_K(w, h)
+    t = torch.from_numpy(img).cuda()
+    det = AprilTagDetector(w, h, intrinsics=_k4(K), families=("tag16h5",), max_batch=1)
+    before = det.device_bytes()
+    g = det.detect_batch_ex(t, max_dets=64)[0]
+    assert det.frame_flags(1) == [0] and det.device_bytes() > before
+    errs, odets = pu.compare_stages(det, 0, img, ("tag16h5",), K, 1)
+    errs += pu.compare_detections(g, odets)
+    nq = len(det.debug(0, capi.DBG_QUADS))
+    det.close()
+    assert not errs, errs[:3]
+    assert nq > 16384
+    fixed = AprilTagDetector(w, h, intrinsics=_k4(K), families=("tag16h5",), max_batch=1, max_quads=16384)
+    fixed.detect_batch_ex(t, max_dets=64)
+    assert fixed.frame_flags(1)[0] & 8
+    fixed.close()
+
+
 def test_cpp_multi_stream_host(built, tmp_path):
     """examples/multi_stream_host.cpp with BASELINE config 4's EIGHT streams: one handle per GPU (and per distinct tag
     size), ncclBroadcast of the per-stream parameter block, streams sharded s % G.  On this 1-GPU box G = 1; every
