@@ -522,6 +522,33 @@ def test_skew_in_pose(built):
         assert np.array_equal(a["p"], b["p"]) and not np.array_equal(a["t"], b["t"])
 
 
+@pytest.mark.parametrize("more", [
+    {"refine_edges": 0},
+    {"max_hamming": 0},
+    {"max_hamming": 1, "decode_sharpening": 0.0},
+    {"max_hamming": 3, "decode_sharpening": 1.0, "skew": 1.5},
+    {"refine_edges": 0, "max_hamming": 3, "decode_sharpening": 0.5},
+], ids=lambda m: ",".join("%s=%s" % kv for kv in m.items()))
+def test_decode_parameters_beside_their_defaults(built, more):
+    """refine_edges, max_hamming, decode_sharpening (cuAprilTags fixes them; the VPI-shaped path and AprilRobotics expose them) at other
+    values than the defaults every other test runs: a noisy 1080p frame under tag36h11 + tag16h5 -- the second family turns noise
+    blobs into dozens of hamming-1 .. 3 records, so the hamming bound and the sharpened decision margins are exercised on real
+    candidates -- every stage and every record bit-identical to the oracle with the same parameters, tag size 5 cm."""
+    img, K, _ = synth.scene_c2(sigma=2.0)
+    fams = ("tag36h11", "tag16h5")
+    det = AprilTagDetector(1920, 1080, families=fams, intrinsics=_k4(K), max_batch=1, tag_size=0.05, **more)
+    got = det.detect_batch_ex(torch.from_numpy(img).cuda(), max_dets=512)[0]
+    errs, odets = pu.compare_stages(det, 0, img, fams, K, 1, tag_size=0.05, **more)
+    det.close()
+    errs += pu.compare_detections(got, odets)
+    assert not errs, errs[:3]
+    assert len(odets) >= 10 and sum(1 for d in odets if d["family"] == "tag36h11" and d["hamming"] == 0) == 10
+    hs = {d["hamming"] for d in odets}
+    assert max(hs) <= more.get("max_hamming", 2)
+    if more.get("max_hamming", 2) == 3:
+        assert 3 in hs   # (the bound is reached: the case is not vacuous)
+
+
 def test_4k_decimate1_batch(built):
     """3840x2160 at decimate 1 in a batch: clusters may exceed the LDS key array (3(2W+2H) = 36000 points), so the
     last size class sorts in its global scratch slot; the handle's memory stays bounded (no per-point moment

@@ -106,7 +106,10 @@ def colour_frame(rng, gray_like, encoding, pitch_pad):
     return buf, pitch, ((4899 * r + 9617 * g + 1868 * b + 8192) >> 14).astype(np.uint8)
 
 
-def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None, batch=1, only=None, dump=None, colour=False, tile=4):
+MAX_DETS = 256   # records a call asks for: a frame with more (noise fields under tag16h5) comes back as the first MAX_DETS of the canonical order
+
+
+def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None, batch=1, only=None, dump=None, colour=False, tile=4, params=False):
     """Returns (cases run, list of failure strings).  path: None (the library picks the launch set by size: the latency set at these
     sizes), "latency", "throughput", or "alternate" (even cases latency, odd cases throughput).  batch > 1: every case submits `batch` frames
     of the case's size, each with content of its own, in ONE call, and every frame is compared (frame indexing of every stage)."""
@@ -145,9 +148,16 @@ def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None, batch=1
         if dump:
             np.savez(dump, imgs=np.stack(imgs), pitch=pitch, dec=dec, fams=np.array(fams), w=w, h=h)
         K = synth.default_K(w, h)
+        more, tag_size = {}, 0.22
+        if params:   # the decode parameters beside their defaults (refine_edges off, every max_hamming, sharpening, skew, tag size)
+            prng = np.random.default_rng(seed * 1000003 + case)   # (a generator of its own: the content stream stays the plain run's)
+            more = {"refine_edges": int(prng.random() < 0.5), "max_hamming": int(prng.integers(0, 4)),
+                    "decode_sharpening": float(np.float32(prng.choice([0.0, 0.1, 0.25, 0.5, 1.0]))),
+                    "skew": float(np.float32(prng.choice([0.0, 0.0, 1.5, -3.25])))}
+            tag_size = float(np.float32(prng.choice([0.22, 0.05, 1.0])))
         try:
             det = AprilTagDetector(w, h, intrinsics=(K[0, 0], K[1, 1], K[0, 2], K[1, 2]), families=fams, decimate=dec,
-                                   max_batch=batch, tile_size=tile)
+                                   max_batch=batch, tile_size=tile, tag_size=tag_size, **more)
         except Exception as e:  # noqa: BLE001
             if tile > 4 and min(1 + (w - 1) // dec, 1 + (h - 1) // dec) < tile:
                 continue   # (a working image below one tile a side is refused at creation: AMDAT_UNSUPPORTED, by design)
@@ -163,17 +173,17 @@ def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None, batch=1
             cf = [colour_frame(rng, im, enc, pad) for im in imgs]
             bufs = [c[0] for c in cf]; pitch = cf[0][1]; imgs = [c[2] for c in cf]
         ts = [torch.from_numpy(b).cuda() for b in bufs]
-        gs = det.detect_batch_ex([(t.data_ptr(), pitch) for t in ts], max_dets=256, encoding=enc)
+        gs = det.detect_batch_ex([(t.data_ptr(), pitch) for t in ts], max_dets=MAX_DETS, encoding=enc)
         errs = []
         for f in range(batch):
-            e, odets = pu.compare_stages(det, f, np.ascontiguousarray(imgs[f]), fams, K, dec, tile_size=tile)
-            e += pu.compare_detections(gs[f], odets)
+            e, odets = pu.compare_stages(det, f, np.ascontiguousarray(imgs[f]), fams, K, dec, tag_size=tag_size, tile_size=tile, **more)
+            e += pu.compare_detections(gs[f], odets[:MAX_DETS])
             errs += ["frame %d: %s" % (f, x) for x in e] if batch > 1 else e
         det.close()
         done += 1
         if errs:
-            fails.append("case %d FAIL kind %s %dx%d pitch %d dec %d fams %s enc %s: %s" % (case, kind, w, h, pitch, dec, fams, enc,
-                                                                                         errs[:3]))
+            fails.append("case %d FAIL kind %s %dx%d pitch %d dec %d fams %s enc %s %s: %s" % (case, kind, w, h, pitch, dec, fams, enc,
+                                                                                            more, errs[:3]))
             out(fails[-1])
     return done, fails
 
@@ -189,11 +199,12 @@ def main():
     ap.add_argument("--dump", default=None, help="with --only: write the case's frames to this .npz")
     ap.add_argument("--tile", type=int, default=4, help="tile_size of the handle (4 or 8)")
     ap.add_argument("--colour", action="store_true", help="submit the content as rgb8 / bgr8 / rgba8 / bgra8 frames with random chroma")
+    ap.add_argument("--params", action="store_true", help="random decode parameters (refine_edges, max_hamming 0..3, decode_sharpening, skew, tag_size)")
     ap.add_argument("--path", default="alternate", help="launch set: latency | throughput | alternate | auto")
     a = ap.parse_args()
     t0 = time.time()
     done, fails = run_cases(a.cases, a.seed, a.maxdim, a.budget, out=lambda m: print(m, flush=True), path=None if a.path == "auto" else a.path, batch=a.batch,
-                            only=a.only, dump=a.dump, colour=a.colour, tile=a.tile)
+                            only=a.only, dump=a.dump, colour=a.colour, tile=a.tile, params=a.params)
     print("fuzz: %d cases, %d failed, %.1f s" % (done, len(fails), time.time() - t0))
     sys.exit(1 if fails else 0)
 
