@@ -549,6 +549,41 @@ def test_decode_parameters_beside_their_defaults(built, more):
         assert 3 in hs   # (the bound is reached: the case is not vacuous)
 
 
+@pytest.mark.parametrize("encoding", ["mono8", "bgr8", "rgba8"])
+@pytest.mark.parametrize("path", PATHS)
+def test_frames_at_any_address_with_pitches_of_their_own(built, encoding, path):
+    """The frames of one submission as regions of larger device buffers: base addresses at any byte (1, 7, 13 past an aligned
+    block, one aligned) and a pitch of its own per frame (cuAprilTagsImageInput_t carries both per image, apriltag_node.cpp:481-486).
+    Every stage and every record of every frame equals the oracle on the frame's gray content."""
+    nch = capi.ENC_CHANNELS[encoding]
+    rng = np.random.default_rng(77)
+    frames, ptrs, keep = [], [], []
+    for i, (off, pad) in enumerate([(1, 0), (7, 3), (0, 64), (13, 29)]):
+        gray = synth.scene_c2(seed=1300 + i)[0]
+        if nch == 1:
+            px = gray[..., None]
+        else:   # equal channels convert back to the gray value exactly: (4899 + 9617 + 1868) v + 8192 >> 14 = v
+            px = np.repeat(gray[..., None], nch, axis=2)
+            if nch == 4:
+                px[..., 3] = rng.integers(0, 256, size=gray.shape, dtype=np.uint8)
+        h, w = gray.shape
+        pitch = w * nch + pad
+        fb = rng.integers(0, 256, size=off + h * pitch + 16, dtype=np.uint8)
+        fb[off:off + h * pitch].reshape(h, pitch)[:, :w * nch] = px.reshape(h, w * nch)
+        t = torch.from_numpy(fb).cuda()
+        keep.append(t); frames.append(gray); ptrs.append((t.data_ptr() + off, pitch))
+    K = synth.default_K(1920, 1080)
+    det = AprilTagDetector(1920, 1080, intrinsics=_k4(K), max_batch=4)
+    det.set_submission_path(path)
+    got = det.detect_batch_ex(ptrs, max_dets=64, encoding=encoding)
+    for i, gray in enumerate(frames):
+        errs, odets = pu.compare_stages(det, i, gray, ("tag36h11",), K, 1)
+        errs += pu.compare_detections(got[i], odets)
+        assert not errs, (i, errs[:3])
+        assert len(odets) == 10
+    det.close()
+
+
 def test_4k_decimate1_batch(built):
     """3840x2160 at decimate 1 in a batch: clusters may exceed the LDS key array (3(2W+2H) = 36000 points), so the
     last size class sorts in its global scratch slot; the handle's memory stays bounded (no per-point moment

@@ -109,7 +109,7 @@ def colour_frame(rng, gray_like, encoding, pitch_pad):
 MAX_DETS = 256   # records a call asks for: a frame with more (noise fields under tag16h5) comes back as the first MAX_DETS of the canonical order
 
 
-def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None, batch=1, only=None, dump=None, colour=False, tile=4, params=False):
+def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None, batch=1, only=None, dump=None, colour=False, tile=4, params=False, layout=False):
     """Returns (cases run, list of failure strings).  path: None (the library picks the launch set by size: the latency set at these
     sizes), "latency", "throughput", or "alternate" (even cases latency, odd cases throughput).  batch > 1: every case submits `batch` frames
     of the case's size, each with content of its own, in ONE call, and every frame is compared (frame indexing of every stage)."""
@@ -172,8 +172,22 @@ def run_cases(cases, seed, maxdim=420, budget=1e9, out=print, path=None, batch=1
             pad = int(rng.choice([0, 0, 1, 3, 16, 37]))
             cf = [colour_frame(rng, im, enc, pad) for im in imgs]
             bufs = [c[0] for c in cf]; pitch = cf[0][1]; imgs = [c[2] for c in cf]
-        ts = [torch.from_numpy(b).cuda() for b in bufs]
-        gs = det.detect_batch_ex([(t.data_ptr(), pitch) for t in ts], max_dets=MAX_DETS, encoding=enc)
+        ptrs = None
+        if layout:   # every frame of the submission at a base address and a pitch of its own (a region of a larger device buffer)
+            lrng = np.random.default_rng(seed * 7919 + case)
+            nch = capi.ENC_CHANNELS[enc]
+            flat, ptrs = [], []
+            for b in bufs:
+                off = int(lrng.integers(1, 16)) if lrng.random() < 0.6 else 0
+                pf = w * nch + int(lrng.choice([0, 1, 2, 3, 5, 16, 29, 64]))
+                fb = lrng.integers(0, 256, size=off + h * pf + 16, dtype=np.uint8)
+                fb[off:off + h * pf].reshape(h, pf)[:, :w * nch] = b[:, :w * nch]
+                flat.append(fb); ptrs.append((off, pf))
+            ts = [torch.from_numpy(fb).cuda() for fb in flat]
+            ptrs = [(t.data_ptr() + off, pf) for t, (off, pf) in zip(ts, ptrs)]
+        else:
+            ts = [torch.from_numpy(b).cuda() for b in bufs]
+        gs = det.detect_batch_ex(ptrs if ptrs else [(t.data_ptr(), pitch) for t in ts], max_dets=MAX_DETS, encoding=enc)
         errs = []
         for f in range(batch):
             e, odets = pu.compare_stages(det, f, np.ascontiguousarray(imgs[f]), fams, K, dec, tag_size=tag_size, tile_size=tile, **more)
@@ -200,11 +214,12 @@ def main():
     ap.add_argument("--tile", type=int, default=4, help="tile_size of the handle (4 or 8)")
     ap.add_argument("--colour", action="store_true", help="submit the content as rgb8 / bgr8 / rgba8 / bgra8 frames with random chroma")
     ap.add_argument("--params", action="store_true", help="random decode parameters (refine_edges, max_hamming 0..3, decode_sharpening, skew, tag_size)")
+    ap.add_argument("--layout", action="store_true", help="every frame at a base address (any byte) and a pitch of its own")
     ap.add_argument("--path", default="alternate", help="launch set: latency | throughput | alternate | auto")
     a = ap.parse_args()
     t0 = time.time()
     done, fails = run_cases(a.cases, a.seed, a.maxdim, a.budget, out=lambda m: print(m, flush=True), path=None if a.path == "auto" else a.path, batch=a.batch,
-                            only=a.only, dump=a.dump, colour=a.colour, tile=a.tile, params=a.params)
+                            only=a.only, dump=a.dump, colour=a.colour, tile=a.tile, params=a.params, layout=a.layout)
     print("fuzz: %d cases, %d failed, %.1f s" % (done, len(fails), time.time() - t0))
     sys.exit(1 if fails else 0)
 
