@@ -164,7 +164,8 @@ typedef struct {
   /* capacities per frame; 0 = defaults derived from the image size */
   uint32_t max_points;         /* boundary points; default 2 per working pixel */
   uint32_t hash_slots;         /* power of two */
-  uint32_t max_clusters;
+  uint32_t max_clusters;       /* 0: starts at 65 536 and grows to the fullest frame's count when a frame fills it (up to one cluster per slot
+                                * of the largest pair table); an explicit value is never grown and reports AMDAT_FLAG_CLUSTERS_OVERFLOW */
   uint32_t max_quads;          /* 0: starts at min(cluster capacity, 16 384) and doubles when a frame fills it; an explicit value is
                                 * never grown and reports AMDAT_FLAG_QUADS_OVERFLOW */
   uint32_t max_detections;

@@ -100,9 +100,10 @@ LIB_STRESS = os.path.join(_HERE, "libapriltag_amd_stress.so")
 def build_stress(force=False):
     """Stress build for the GPU suite (tests/test_gpu_parity.py::test_long_staging_records...): a 64 x 16 tile's emission list
     is cut to 768 entries, so that on ordinary frames a good share of the boundary points takes the long-record path that the
-    product build only enters above two emissions per pixel of a tile.  Never loaded by the product path."""
+    product build only enters above two emissions per pixel of a tile; and the cluster list starts at 1024 entries instead of
+    65 536, so that the noisy 1080p frames (4 000 clusters) make it grow twice.  Never loaded by the product path."""
     if force or _newer(LIB_STRESS, [os.path.join(_CSRC, "detector.hip")] + _sources(".h")):
-        build_amd_variant("stress", ["PT_ELIST=768", "AMDAT_LCAP_DIV=1"])
+        build_amd_variant("stress", ["PT_ELIST=768", "AMDAT_LCAP_DIV=1", "AMDAT_CCAP0=1024u"])
     return LIB_STRESS
 
 

@@ -118,6 +118,7 @@ struct DetParams {
   uint32_t rcap;     // tile-local roots per frame (CC root list)
   uint32_t cand_cap; // quad candidates per frame (k_fit_quads -> k_quad_finish); grows on demand up to ccap
   uint32_t lcap;     // long staging records per frame (emissions without a block-table entry, kernels_cluster.h): pcap / 8
+  uint32_t wshift;   // a work item of the quad fit is (frame << wshift) | cluster index: 32 - bits of the handle's frame count, at most 24
   FamilyDev fam[AT_MAX_FAMILIES];
 };
 

@@ -209,6 +209,9 @@ struct amdAprilTagsDetector_st {
   bool grow_points = false;          // point capacity follows the content (no explicit max_points)
   bool grow_hash = false;            // the same for the component-pair table (no explicit hash_slots)
   bool grow_quads = false;           // the same for the quad list (no explicit max_quads): doubles up to the cluster capacity
+  bool grow_clusters = false;        // and for the cluster list (no explicit max_clusters): up to ccap_hard
+  uint32_t ccap_hard = 0;            // what the pair table and a work item's index bits admit
+  size_t clusters_bytes = 0;
   size_t quads_bytes = 0;
   bool pending_hash_grow = false;
   uint32_t lcap_div = 0;             // long-record capacity = point capacity / lcap_div (alloc_point_buffers; halves when the long records overflow)
@@ -543,7 +546,7 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   memcpy(&cfg, cfg_in, cfg_in->struct_size);
   cfg.struct_size = (uint32_t)sizeof(cfg);
   if (cfg.width == 0 || cfg.height == 0 || cfg.max_batch == 0 || cfg.decimate == 0) return AMDAT_INVALID_ARGUMENT;
-  if (cfg.max_batch > 65535) return AMDAT_BATCH_TOO_LARGE;   // a work item carries the batch slot in 16 bits
+  if (cfg.max_batch > 65535) return AMDAT_BATCH_TOO_LARGE;   // a work item carries the batch slot in at most 16 bits
   if (cfg.tile_size != 4 && cfg.tile_size != 8) return AMDAT_UNSUPPORTED;   // (the reference's default and twice it)
   if (cfg.decimate > 4) return AMDAT_UNSUPPORTED;     // the threshold loader is instantiated for 1..4
   if (cfg.max_hamming > 3) return AMDAT_INVALID_ARGUMENT;  // AprilRobotics' own limit for the code search
@@ -634,8 +637,25 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
   if (D->hcap_hard < 256) D->hcap_hard = 256;
   P.hcap = cfg.hash_slots ? D->hcap_hard : next_pow2(npx / 32 > 4096 ? npx / 32 : 4096);
   if (P.hcap > D->hcap_hard) P.hcap = D->hcap_hard;
-  P.ccap = cfg.max_clusters ? cfg.max_clusters : (D->hcap_hard < 65536 ? D->hcap_hard : 65536);
-  if (P.ccap > 65536) P.ccap = 65536;                 // a work item carries the cluster index in 16 bits
+  // A work item of the quad fit is one word: (frame << wshift) | cluster index.  The frame takes the bits the handle's frame count
+  // needs, the index the rest (at most 24): 256 frames per submission leave room for 2^24 clusters per frame, 65 536 frames for
+  // 65 536.  A frame has at most one cluster per used slot of the pair table, so min(2^wshift, hcap_hard) bounds the list; it starts
+  // at 65 536 (a sigma-2 1080p frame has 4 000 clusters) and, like the point buffers, GROWS when a frame reports
+  // AMDAT_FLAG_CLUSTERS_OVERFLOW -- an eight-megapixel checkerboard of six-pixel cells has 116 000 (end_batch).  An explicit
+  // max_clusters is taken as given (clamped to the bound) and never grown.
+  {
+    uint32_t fbits = 0;
+    while ((1ull << fbits) < (uint64_t)cfg.max_batch) fbits++;
+    // (max_batch <= 65 535 was checked above: fbits <= 16)
+    P.wshift = 32u - fbits > 24u ? 24u : 32u - fbits;
+  }
+#ifndef AMDAT_CCAP0
+#define AMDAT_CCAP0 65536u   // (tools builds start lower, so that ordinary content exercises the growth)
+#endif
+  D->ccap_hard = D->hcap_hard < (1u << P.wshift) ? D->hcap_hard : (1u << P.wshift);
+  D->grow_clusters = cfg.max_clusters == 0;
+  P.ccap = cfg.max_clusters ? cfg.max_clusters : (D->ccap_hard < AMDAT_CCAP0 ? D->ccap_hard : AMDAT_CCAP0);
+  if (P.ccap > D->ccap_hard) P.ccap = D->ccap_hard;
   P.qcap = cfg.max_quads ? cfg.max_quads : (P.ccap < 16384 ? P.ccap : 16384);
   D->grow_quads = cfg.max_quads == 0;   // (a two-megapixel checkerboard of two-pixel cells has 29 000 quads: the list doubles and the
                                         // submission is repeated, end_batch; an explicit max_quads reports AMDAT_FLAG_QUADS_OVERFLOW)
@@ -724,6 +744,7 @@ int amdCreateAprilTagsDetectorEx(amdAprilTagsHandle* handle, const amdAprilTagsC
     alloc((void**)&D->d_btab, B * tiles * PT_TB * sizeof(uint2));
   }
   alloc((void**)&D->d_clusters, B * (size_t)P.ccap * sizeof(ClusterRec));
+  D->clusters_bytes = B * (size_t)P.ccap * sizeof(ClusterRec);
   if (ok) { const int rc = alloc_point_buffers(D); if (rc == AMDAT_BATCH_TOO_LARGE) { free_all(D); delete D; return rc; } ok = rc == AMDAT_SUCCESS; }
   for (int k = 0; k < FQ_NCLS; k++) {
     FqClass& c = D->cls[k];
@@ -1571,7 +1592,41 @@ static int end_batch(amdAprilTagsDetector_st* D) {
     bool cands_over = false;
     for (uint32_t f = 0; f < n; f++) cands_over |= (D->h_counters[f].flags & AT_FLAG_CANDS) != 0;
     bool again = false;
-    {   // the quad list of a handle without an explicit max_quads follows the content like the candidate list
+    {   // the cluster list of a handle without an explicit max_clusters follows the content: to the next power of two that holds the
+        // fullest frame (the counter counts every kept cluster, listed or not); the work lists of the quad fit follow it
+      uint32_t ncl_max = 0;
+      for (uint32_t f = 0; f < n; f++)
+        if ((D->h_counters[f].flags & 0x4u) && D->h_counters[f].nclusters > D->P.ccap && D->h_counters[f].nclusters > ncl_max) ncl_max = D->h_counters[f].nclusters;
+      if (ncl_max && D->grow_clusters && D->P.ccap < D->ccap_hard) {
+        uint32_t ncap = D->P.ccap;
+        while (ncap < ncl_max && ncap < D->ccap_hard) ncap *= 2;
+        if (ncap > D->ccap_hard) ncap = D->ccap_hard;
+        ClusterRec* nb = nullptr;
+        const size_t nbytes = (size_t)D->cfg.max_batch * ncap * sizeof(ClusterRec);
+        const uint32_t before = D->P.ccap;
+        if (hipMalloc((void**)&nb, nbytes) == hipSuccess) {
+          drop_graphs_for_regrowth(D);
+          D->P.ccap = ncap;
+          if (alloc_point_buffers(D) == AMDAT_SUCCESS) {
+            hipFree(D->d_clusters);
+            D->d_clusters = nb;
+            D->device_bytes += nbytes - D->clusters_bytes;
+            D->clusters_bytes = nbytes;
+            D->grown++;
+            again = true;
+          } else {   // not enough memory for the longer work lists: the old capacities stay and the overflow is reported
+            (void)hipGetLastError();
+            hipFree(nb);
+            D->P.ccap = before; D->grow_clusters = false;
+            if (alloc_point_buffers(D) != AMDAT_SUCCESS) { D->unusable = true; return AMDAT_OUT_OF_MEMORY; }
+          }
+        } else {
+          (void)hipGetLastError();
+          D->grow_clusters = false;
+        }
+      }
+    }
+    if (!again) {   // the quad list of a handle without an explicit max_quads follows the content like the candidate list
       bool quads_over = false;
       for (uint32_t f = 0; f < n; f++) quads_over |= (D->h_counters[f].flags & 0x8u) != 0 && D->h_counters[f].nquads > D->P.qcap;
       if (quads_over && D->grow_quads && D->P.qcap < D->P.ccap) {

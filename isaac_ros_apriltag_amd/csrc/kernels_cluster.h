@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
 }
 
 // Work lists of the quad fit: the kept clusters of all frames of the submission, bucketed by size class
-// (class c holds lo[c] < count <= hi[c]).  An item is (frame << 16) | cluster index.  k_cluster_select appends them as it
+// (class c holds lo[c] < count <= hi[c]).  An item is (frame << P.wshift) | cluster index (wshift >= 16: DetParams).  k_cluster_select appends them as it
 // creates the cluster records; appends are aggregated per block in LDS, so every class counter sees one global atomic per
 // block.  (A separate k_worklist pass over the records cost a launch and a round trip through them.)
 #define FQ_NCLS 7
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void k_cluster_select(unsigned long long* __re
     for (int j = 0; j < 4; j++) {
       if (wcls[ch][j] < 0) continue;
       const uint32_t pos = s_wbase[wcls[ch][j]] + wrank[ch][j];
-      if (pos < L.cap[wcls[ch][j]]) work[L.off[wcls[ch][j]] + pos] = ((uint32_t)frame << 16) | wci[ch][j];
+      if (pos < L.cap[wcls[ch][j]]) work[L.off[wcls[ch][j]] + pos] = ((uint32_t)frame << P.wshift) | wci[ch][j];
       else atomicOr(&counters[frame].flags, 0x4u);
     }
   }

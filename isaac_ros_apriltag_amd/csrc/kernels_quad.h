@@ -938,12 +938,12 @@ __device__ __forceinline__ void fit_quads_body(const FrameDesc* __restrict__ fra
     FQ_TL_NEXT_CLUSTER()
     if (item >= nwork) break;
     const uint32_t wi = (uint32_t)__builtin_amdgcn_readfirstlane((int)work[item]);
-    const int frame = (int)(wi >> 16);
+    const int frame = (int)(wi >> P.wshift);
     const FrameDesc fd = frames[frame];
     const uint8_t* gray = (P.decimate > 1) ? gray_all + (size_t)frame * P.H * P.WS : fd.img;
     const int gpitch = (P.decimate > 1) ? P.WS : (int)fd.pitch;
     const __attribute__((address_space(1))) uint8_t* const ggray = (const __attribute__((address_space(1))) uint8_t*)gray;   // global, not generic
-    const ClusterRec cl = clusters_all[(size_t)frame * P.ccap + (wi & 0xFFFFu)];
+    const ClusterRec cl = clusters_all[(size_t)frame * P.ccap + (wi & ((1u << P.wshift) - 1u))];
     const int sz = (int)cl.count;
     FQ_TL_SIZE(sz)
     if (sz < 24 || sz > slot_cap) continue;   // (the work list only holds clusters of this class)
@@ -1758,12 +1758,12 @@ __global__ __launch_bounds__(FQ_PF_NT) void k_fit_prefilter(const FrameDesc* __r
       }
     }
     const uint32_t wi = (uint32_t)__builtin_amdgcn_readfirstlane((int)work[widx]);
-    const int frame = (int)(wi >> 16);
+    const int frame = (int)(wi >> P.wshift);
     const FrameDesc fd = frames[frame];
     const uint8_t* gray = (P.decimate > 1) ? gray_all + (size_t)frame * P.H * P.WS : fd.img;
     const int gpitch = (P.decimate > 1) ? P.WS : (int)fd.pitch;
     const __attribute__((address_space(1))) uint8_t* const ggray = (const __attribute__((address_space(1))) uint8_t*)gray;
-    const ClusterRec cl = clusters_all[(size_t)frame * P.ccap + (wi & 0xFFFFu)];
+    const ClusterRec cl = clusters_all[(size_t)frame * P.ccap + (wi & ((1u << P.wshift) - 1u))];
     const int sz = (int)cl.count;
     const uint32_t* pts = pts_all + (size_t)frame * P.pcap + cl.start;
 

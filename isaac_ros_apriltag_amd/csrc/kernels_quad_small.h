@@ -101,8 +101,8 @@ __device__ __forceinline__ void fit_small_body(const FrameDesc* __restrict__ fra
   auto stage2 = [&](Pending& n) {
     if (n.item >= nwork) return;
     const uint32_t wi = (uint32_t)__builtin_amdgcn_readfirstlane((int)n.wi_v);
-    const int frame = (int)(wi >> 16);
-    const gptr32 rec = (gptr32)(clusters_all + (size_t)frame * P.ccap + (wi & 0xFFFFu));
+    const int frame = (int)(wi >> P.wshift);
+    const gptr32 rec = (gptr32)(clusters_all + (size_t)frame * P.ccap + (wi & ((1u << P.wshift) - 1u)));
     const gptr32 fdp = (gptr32)(frames + frame);
 #pragma unroll
     for (int j = 0; j < 4; j++) n.rec_v[j] = rec[j];
@@ -111,7 +111,7 @@ __device__ __forceinline__ void fit_small_body(const FrameDesc* __restrict__ fra
   auto stage3 = [&](Pending& n) {
     if (n.item >= nwork) return;
     const uint32_t wi = (uint32_t)__builtin_amdgcn_readfirstlane((int)n.wi_v);
-    const int frame = (int)(wi >> 16);
+    const int frame = (int)(wi >> P.wshift);
     const uint32_t start = (uint32_t)__builtin_amdgcn_readfirstlane((int)n.rec_v[2]);
     const int sz = __builtin_amdgcn_readfirstlane((int)n.rec_v[3]);
     const gptr32 pts = (gptr32)(pts_all + (size_t)frame * P.pcap + start);
@@ -126,7 +126,7 @@ __device__ __forceinline__ void fit_small_body(const FrameDesc* __restrict__ fra
     int pf = 0;        // prefetch stages of the next cluster issued so far
     do {
     const uint32_t wi = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.wi_v);
-    const int frame = (int)(wi >> 16);
+    const int frame = (int)(wi >> P.wshift);
     const uint8_t* gray = (P.decimate > 1) ? gray_all + (size_t)frame * P.H * P.WS
                                            : reinterpret_cast<const uint8_t*>(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)cur.img_v[1]) << 32) |
                                                                               (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)cur.img_v[0]));

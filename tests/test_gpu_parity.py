@@ -988,6 +988,59 @@ def test_quad_list_grows_with_the_content(built):
     fixed.close()
 
 
+def test_cluster_list_grows_with_the_content(built):
+    """The default cluster list holds 65 536 clusters per frame -- once the limit of the format (a work item of the quad fit carried
+    the cluster index in 16 bits) -- and now grows like the other lists: a 3000 x 2800 checkerboard of six-pixel cells has 116 499
+    clusters, each of them a quad candidate, so the cluster list, the quad list and the candidate list all grow and the submission
+    is repeated.  Every stage equals the oracle's, no flag is left; an explicit max_clusters is never grown and reports
+    AMDAT_FLAG_CLUSTERS_OVERFLOW."""
+    w, h = 3000, 2800
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = ((((yy // 6) + (xx // 6)) & 1) * 200).astype(np.uint8)
+    K = synth.default_K(w, h)
+    t = torch.from_numpy(img).cuda()
+    det = AprilTagDetector(w, h, intrinsics=_k4(K), families=("tag16h5",), max_batch=1)
+    before = det.device_bytes()
+    g = det.detect_batch_ex(t, max_dets=64)[0]
+    assert det.frame_flags(1) == [0] and det.device_bytes() > before
+    errs, odets = pu.compare_stages(det, 0, img, ("tag16h5",), K, 1)
+    errs += pu.compare_detections(g, odets)
+    ncl = len(det.debug(0, capi.DBG_CLUSTERS))
+    nq = len(det.debug(0, capi.DBG_QUADS))
+    g2 = det.detect_batch_ex(t, max_dets=64)[0]   # (the grown handle, first try)
+    assert det.frame_flags(1) == [0] and not pu.compare_detections(g2, odets)
+    det.close()
+    assert not errs, errs[:3]
+    assert ncl > 100000 and nq > 100000
+    fixed = AprilTagDetector(w, h, intrinsics=_k4(K), families=("tag16h5",), max_batch=1, max_clusters=65536)
+    fixed.detect_batch_ex(t, max_dets=64)
+    assert fixed.frame_flags(1)[0] & 4
+    fixed.close()
+
+
+def test_work_items_of_a_handle_with_many_frames(built):
+    """A work item of the quad fit is (frame << wshift) | cluster index, the split following the handle's frame count: 600 frames
+    take ten bits, the index 22.  600 small frames (a tag on a noisy ground, content of its own per frame) in one submission on the
+    throughput set: one record per frame, and frames 0, 255, 256, 511, 512 and 599 -- either side of every carry of the frame bits --
+    equal the oracle on every stage."""
+    n, w, h = 600, 160, 120
+    s = 22.0
+    Hm = np.array([[s, 0, 80.0], [0, s, 60.0], [0, 0, 1.0]])
+    base = synth.render(w, h, [{"family": "tag36h11", "id": 7, "H": Hm}], background=150, sigma=0.0, seed=3).astype(np.int16)
+    rng = np.random.default_rng(99)
+    frames = np.clip(base[None] + rng.integers(-6, 7, size=(n, h, w)), 0, 255).astype(np.uint8)
+    K = synth.default_K(w, h)
+    det = AprilTagDetector(w, h, intrinsics=_k4(K), max_batch=n)
+    got = det.detect_batch_ex(torch.from_numpy(frames).cuda(), max_dets=8)
+    assert det.frame_flags(n) == [0] * n
+    assert [len(g) for g in got] == [1] * n and {g[0]["id"] for g in got} == {7}
+    for f in (0, 255, 256, 511, 512, 599):
+        errs, odets = pu.compare_stages(det, f, frames[f], ("tag36h11",), K, 1)
+        errs += pu.compare_detections(got[f], odets)
+        assert not errs, (f, errs[:3])
+    det.close()
+
+
 def test_cpp_multi_stream_host(built, tmp_path):
     """examples/multi_stream_host.cpp with BASELINE config 4's EIGHT streams: one handle per GPU (and per distinct tag
     size), ncclBroadcast of the per-stream parameter block, streams sharded s % G.  On this 1-GPU box G = 1; every
