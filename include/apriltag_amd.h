@@ -168,7 +168,8 @@ typedef struct {
                                 * of the largest pair table); an explicit value is never grown and reports AMDAT_FLAG_CLUSTERS_OVERFLOW */
   uint32_t max_quads;          /* 0: starts at min(cluster capacity, 16 384) and doubles when a frame fills it; an explicit value is
                                 * never grown and reports AMDAT_FLAG_QUADS_OVERFLOW */
-  uint32_t max_detections;
+  uint32_t max_detections;     /* 0: 1024 decoded candidates per frame (before the same-id overlap test), at most 65 535; not grown: a frame
+                                * with more reports AMDAT_FLAG_DETS_OVERFLOW */
   int32_t device;              /* HIP device ordinal, -1 = current */
   float skew;                  /* K[0][1] of the pinhole matrix; 0 on the cuAprilTags-shaped path, the VPI path of
                                 * the reference passes it with its 2x3 intrinsics (src/apriltag_node.cpp:215-225) */
