@@ -1116,8 +1116,8 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
     const int nrows = (P.H - 1) / CC_T, ncols = (P.W - 1) / CC_T;
     const long total = (long)nrows * P.W + (long)ncols * P.H;
     if (total > 0)
-      hipLaunchKernelGGL(k_cc_border, dim3((unsigned)((total + 255) / 256) * n), dim3(256), 0, s, D->d_perim, D->d_label,
-                         (uint32_t)((total + 255) / 256), n, P);
+      hipLaunchKernelGGL(k_cc_border, dim3((unsigned)((total + 255) / 256) * n), dim3(256), 0, s, D->d_perim, D->d_label, D->d_roots,
+                         D->d_counters, (uint32_t)((total + 255) / 256), n, P);
   }
   mark();
   {

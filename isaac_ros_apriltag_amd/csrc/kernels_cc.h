@@ -8,20 +8,23 @@
 //   k_cc_local   one 64x64 tile per 256-thread block, entirely in LDS: wave-ballot run labelling
 //                of each 64-pixel row (no atomics), lock-free atomicMin union of rows, flatten,
 //                per-run size counting; writes global labels (index of the tile-local root), the
-//                local size at root pixels, and appends the roots of components that touch the tile's
-//                perimeter (the only ones that can merge with another tile) to a per-frame root list.
+//                local size at root pixels -- with the size bit (AT_LABEL_BIG) on every root that has min_component_size
+//                pixels inside the tile alone -- and the tile's perimeter arrays.
 //   k_cc_border  unions across tile borders with global atomicMin (only first-overlap pixels).  It reads neither the threshold
 //                image nor the label array: k_cc_local leaves, per frame, the PERIMETER of every tile -- class and tile-local
 //                root of the pixels of its first / last row and first / last column -- in four compact arrays laid out along the
 //                borders (CcPerim below), so a border pixel's whole neighbourhood is a handful of coalesced words (the column
 //                borders used to gather bytes and labels at a stride of one image row: a cache line per lane and load).
-//   k_cc_sizes   over the root list only: every tile-local root is pointed at its final representative
+//                ★ round 6: it LISTS the roots its unions turn into non-roots (each exactly once, by the thread whose atomicMin
+//                did it).  That list -- a third to a half of the perimeter roots k_cc_local used to list: a speck that touches
+//                a tile border without a partner across it is final where it stands -- is all the two passes below visit.
+//   k_cc_sizes   over the list: every listed root is pointed at its final representative
 //                and its pixel count is added there.  Pixels keep the index of their tile-local root, so
 //                a consumer reaches the representative with two loads (label[label[p]]) and the image-wide
 //                flatten pass (12 B/pixel of traffic) is not needed.
-//   k_cc_resolve second pass over the root list: every listed root's entry becomes representative | AT_LABEL_BIG (bit 31 set
-//                when the component has at least min_component_size pixels).  Roots of components that lie inside one tile
-//                got the bit from k_cc_local already.  A consumer then needs ONE dependent load per pixel --
+//   k_cc_resolve second pass over the list: where the component has reached min_component_size pixels, the listed root's entry
+//                becomes representative | AT_LABEL_BIG and the representative's own entry gets the bit (plain stores).  Roots
+//                that were large enough inside their tile carry it from k_cc_local.  A consumer then needs ONE dependent load per pixel --
 //                e = label[label[p] & AT_LABEL_MASK]: representative e & AT_LABEL_MASK, "large enough" e >> 31 -- and no
 //                size gather at all (k_points used to fetch label[l] and csize[l]: two cache lines per root, a quarter of
 //                its HBM traffic).
@@ -70,31 +73,34 @@ __device__ __forceinline__ void lds_union(uint32_t* L, uint32_t a, uint32_t b) {
   }
 }
 
-// (entries that take part in the global unions never carry AT_LABEL_BIG: only roots of components inside one tile get it
-// before k_cc_resolve, and those touch no tile border)
+// (a ROOT's own entry may carry AT_LABEL_BIG -- k_cc_local sets it on every root with enough pixels inside its tile --, a
+// non-root's entry never does: the finds mask the bit)
 __device__ __forceinline__ uint32_t glb_load(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Lock-free union (the larger root is pointed at the smaller one; entries only ever decrease towards the root, which is
-// what keeps concurrent unions correct).  Trees are never rebalanced, so a giant component's chain of tile-local roots
+// what keeps concurrent unions correct -- a root's entry with the size bit is larger than every index, so the atomicMin that
+// makes it a non-root drops the bit with it).  Returns the root this call turned into a non-root (every root is turned exactly
+// once: the border pass lists it for k_cc_sizes / k_cc_resolve), or AT_NO_LABEL when the two were joined already.
+// Trees are never rebalanced, so a giant component's chain of tile-local roots
 // grows with the number of tiles it has crossed.  Two shortcuts were measured and dropped: path halving inside the find
 // (grandparent links at every hop: 1.27-1.36 vs 1.35-1.39 ms, noise; round 4 again: 0.71 vs 0.68 ms, one frame 0.41 vs 0.41 ms) and pointing both START entries at the final root
 // with an atomicMin after the union (1.54 ms: two more atomics on entries that are already contended).  What does help
 // is launching the frames of a submission interleaved (at_frame_block): the unions of one frame then contend with the
 // unions of other frames for the atomic units instead of with each other for the same few roots.
-__device__ __forceinline__ void glb_union(uint32_t* L, uint32_t a, uint32_t b) {
+__device__ __forceinline__ uint32_t glb_union(uint32_t* L, uint32_t a, uint32_t b) {
   for (;;) {
     // (the two chases advance together: two independent L2 round trips in flight per step, not one after the other)
     for (;;) {
-      const uint32_t pa = glb_load(&L[a]), pb = glb_load(&L[b]);
+      const uint32_t pa = glb_load(&L[a]) & AT_LABEL_MASK, pb = glb_load(&L[b]) & AT_LABEL_MASK;
       if (pa == a && pb == b) break;
       a = pa; b = pb;
     }
-    if (a == b) return;
+    if (a == b) return AT_NO_LABEL;
     if (a < b) { uint32_t t = a; a = b; b = t; }
-    uint32_t old = atomicMin(&L[a], b);
-    if (old == a) return;
-    a = old;
+    const uint32_t old = atomicMin(&L[a], b);
+    if ((old & AT_LABEL_MASK) == a) return a;
+    a = old;   // (a non-root's entry: an index without the bit)
   }
 }
 
@@ -137,10 +143,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CC_LOCA
   uint8_t* const st = s_tile_or_requests;
   uint16_t* const s_ureq = reinterpret_cast<uint16_t*>(s_tile_or_requests);
   __shared__ uint32_t sl[CC_T * CC_T];
-  // (the two words of the root-list pass live in the request area, dead by then: with 4 waves the block is 20 KB of LDS to the
-  // byte -- eight blocks per CU, and at 57 registers eight waves per SIMD)
-  uint32_t& s_nroots = reinterpret_cast<uint32_t*>(s_tile_or_requests)[0];
-  uint32_t& s_rbase = reinterpret_cast<uint32_t*>(s_tile_or_requests)[1];
+  // (with 4 waves the block is 20 KB of LDS to the byte -- eight blocks per CU, and eight waves per SIMD)
   const int frame = (int)blockIdx.z + P.frame0;
   const int X0 = blockIdx.x * CC_T, Y0 = blockIdx.y * CC_T;
   const int W = P.W, H = P.H;
@@ -326,13 +329,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CC_LOCA
 #pragma unroll
   for (int k = 0; k < ROWS; k++) {
     const uint32_t len = (runlen[k >> 2] >> (8 * (k & 3))) & 0xFFu;   // (nonzero on the last pixel of a black or white run)
-    if (len) {
-      atomicAdd(lds_at(sl, root[k]), len);
-      // a component can only ever merge with another tile's through a pixel on the tile's perimeter: flag it (bit 31).
-      // (first or last row of the tile, a run from column 0 -- its length is then the lane + 1 -- or one up to column 63)
-      const bool edge_row = (k == 0 && wv == 0) || (k == ROWS - CC_LAST_ROW_OFFSET(NW) && wv == NW - 1);   // (tools_hooks.h: 1)
-      if (edge_row || len == (uint32_t)(lane + 1) || lane == 63) atomicOr(lds_at(sl, root[k]), 0x80000000u);
-    }
+    if (len) atomicAdd(lds_at(sl, root[k]), len);
   }
   __syncthreads();
 
@@ -340,25 +337,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CC_LOCA
   // ---- 4. write global labels (index of the local root), local sizes at the roots, root list -------
   uint32_t* label = label_all + (size_t)frame * W * H;
   uint32_t* csize = csize_all + (size_t)frame * W * H;
-  uint32_t* roots = roots_all + (size_t)frame * P.rcap;
-  if (tid == 0) s_nroots = 0;
-  __syncthreads();
-  // Only roots of components that touch the perimeter go to the root list: every other component is complete inside
-  // this tile (its label and size are final here), so the passes over the list (k_cc_sizes, k_cc_resolve) skip the
-  // interior specks that make up most components of a noisy frame.
-  uint32_t myroots = 0;
-  {
-    const uint32_t me4 = fresh(me4w);
-    const uint32_t* const sl4 = lds_at(sl, me4);
-#pragma unroll
-    for (int k = 0; k < ROWS; k++)
-      if (root[k] == (me4 | (uint32_t)(k * CC_T * 4)) && (sl4[k * CC_T] >> 31)) myroots++;   // (AT_NO_LABEL is no pixel's byte offset)
-  }
-  uint32_t rpos = myroots ? atomicAdd(&s_nroots, myroots) : 0;
-  __syncthreads();
-  if (tid == 0) s_rbase = s_nroots ? atomicAdd(&counters[frame].nroots, s_nroots) : 0;
-  __syncthreads();
-  rpos += s_rbase;
+  // No root list any more (round 6): a root keeps the size bit of its LOCAL pixel count whether or not its component touches the
+  // tile's perimeter -- the count only grows when the border pass joins it to another tile's component, so the bit is final when
+  // set -- and the passes behind the border pass (k_cc_sizes, k_cc_resolve) run over the roots that LOST a union there, which
+  // k_cc_border lists as it makes them: the specks that touch a tile border without crossing it, half of a noisy frame's
+  // perimeter roots, are final here and are never visited again.
   // (straight-line per row: every lane forms its label -- the select of "no label" included -- and the row goes out as one
   // predicated store; only the size and the list entry of a root, one lane per component, sit under a branch.  An early exit
   // from the unrolled row loop had the compiler build a state machine around every row.)
@@ -382,21 +365,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CC_LOCA
       // (24-bit multiply: one full-rate instruction; rows and the width are far below 2^24)
       uint32_t lab = __umul24((uint32_t)Y0 + (rt >> 8), (uint32_t)W) + (uint32_t)X0 + ((rt >> 2) & (CC_T - 1));
       {
-        // (a perimeter pixel's root carries the perimeter flag, never the size bit: bit 31 of the entry is free for the class)
+        // (formed before the size bit goes into `lab`: bit 31 of a perimeter entry is the pixel's class)
         const uint32_t pe = rt == AT_NO_LABEL ? AT_NO_LABEL : (lab | (px(k) == CLS_WHITE ? 0x80000000u : 0u));
         if (k == 0 && wv == 0) perim[PL.top + blockIdx.y * (uint32_t)PL.WP + (uint32_t)gx] = pe;
-        if (k == ROWS - 1 && wv == NW - 1) perim[PL.bot + blockIdx.y * (uint32_t)PL.WP + (uint32_t)gx] = pe;
+        if (k == ROWS - CC_LAST_ROW_OFFSET(NW) && wv == NW - 1) perim[PL.bot + blockIdx.y * (uint32_t)PL.WP + (uint32_t)gx] = pe;   // (tools_hooks.h: 1)
         if (col_lane) pcol[k] = pe;
       }
-      // complete inside this tile (no perimeter flag): size and representative are final
-      if (isroot && !(cs >> 31) && (int)cs >= P.min_component_size) lab |= AT_LABEL_BIG;
+      // (enough pixels inside this tile alone: the size bit is final whatever the border pass adds)
+      if (isroot && (int)cs >= P.min_component_size) lab |= AT_LABEL_BIG;
       if (rt == AT_NO_LABEL) lab = AT_NO_LABEL;
       if (col_ok && gyw < H - k) {
         label[gi] = lab;
-        if (isroot) {
-          csize[gi] = cs & 0x7FFFFFFFu;
-          if (cs >> 31) roots[rpos++] = gi;
-        }
+        if (isroot) csize[gi] = cs;
       }
     }
   }
@@ -446,6 +426,7 @@ __device__ __forceinline__ void cc_column_requests(int W, int gx, bool upward, u
 #define CC_ILEAVE 256
 #endif
 __global__ __launch_bounds__(256) void k_cc_border(const uint32_t* __restrict__ perim_all, uint32_t* __restrict__ label_all,
+                                                   uint32_t* __restrict__ roots_all, FrameCounters* __restrict__ counters,
                                                    uint32_t bpf, uint32_t nframes, DetParams P) {
   uint32_t fr_, blk_;
   at_frame_block(blockIdx.x, bpf, nframes, CC_ILEAVE, &fr_, &blk_);
@@ -457,6 +438,10 @@ __global__ __launch_bounds__(256) void k_cc_border(const uint32_t* __restrict__ 
   const int nrows = (H - 1) / CC_T;  // tile-top rows at y = 64, 128, ...
   const int ncols = (W - 1) / CC_T;  // tile-left columns at x = 64, 128, ...
   int i = (int)blk_ * 256 + threadIdx.x;
+  __shared__ uint32_t s_lost, s_base;
+  if (threadIdx.x == 0) s_lost = 0;
+  __syncthreads();
+  uint32_t lost[3];
   uint32_t ra[3] = {AT_NO_LABEL, AT_NO_LABEL, AT_NO_LABEL}, rb[3] = {AT_NO_LABEL, AT_NO_LABEL, AT_NO_LABEL};
   if (i < nrows * W) {
     const int gx = i % W, ty = i / W + 1;
@@ -497,11 +482,28 @@ __global__ __launch_bounds__(256) void k_cc_border(const uint32_t* __restrict__ 
       if (same && (int)lane_id() != leader) mine = false;
       todo &= ~__ballot(same);
     }
-    if (mine) glb_union(label, a, b2);
+    lost[k] = mine ? glb_union(label, a, b2) : AT_NO_LABEL;
+  }
+  // The roots this block's unions turned into non-roots go to the frame's list -- these, and only these, are the tile-local roots
+  // whose entry, size and size bit k_cc_sizes / k_cc_resolve still have to settle.  One append per BLOCK: the list's counter is one
+  // word per frame, and a one-frame submission has a thousand waves here (one add per wave and request slot cost such a call 15 us).
+  const uint32_t mycnt = (lost[0] != AT_NO_LABEL ? 1u : 0u) + (lost[1] != AT_NO_LABEL ? 1u : 0u) + (lost[2] != AT_NO_LABEL ? 1u : 0u);
+  uint32_t pos = mycnt ? atomicAdd(&s_lost, mycnt) : 0u;
+  __syncthreads();
+  if (threadIdx.x == 0 && s_lost) s_base = atomicAdd(&counters[frame].nroots, s_lost);
+  __syncthreads();
+  if (mycnt) {
+    pos += s_base;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      if (lost[k] != AT_NO_LABEL) {
+        if (pos < P.rcap) roots_all[(size_t)frame * P.rcap + pos] = lost[k];   // (at most one loser per perimeter root: rcap is their bound)
+        pos++;
+      }
   }
 }
 
-// one thread per tile-local root of the frame
+// one thread per listed root of the frame (the roots that lost a union in k_cc_border)
 __global__ __launch_bounds__(256) void k_cc_sizes(uint32_t* __restrict__ label_all, uint32_t* __restrict__ csize_all,
                                                   const uint32_t* __restrict__ roots_all, const FrameCounters* __restrict__ counters,
                                                   DetParams P) {
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(256) void k_cc_sizes(uint32_t* __restrict__ label_a
   uint32_t* label = label_all + (size_t)frame * n;
   uint32_t* csize = csize_all + (size_t)frame * n;
   const uint32_t* roots = roots_all + (size_t)frame * P.rcap;
-  const uint32_t nroots = counters[frame].nroots;
+  const uint32_t nroots = min(counters[frame].nroots, P.rcap);
   // A frame with textured background has a few giant components with tens of thousands of tile-local roots each: one
   // atomicAdd per root on the representative's size serialised on a single address (most of this kernel's time, 80 us
   // of a single frame's latency).  The adds of a wave are combined per representative first: leader rounds over the
@@ -520,16 +522,12 @@ __global__ __launch_bounds__(256) void k_cc_sizes(uint32_t* __restrict__ label_a
     const uint32_t i = i0 + threadIdx.x;
     uint32_t r = AT_NO_LABEL, add = 0;
     if (i < nroots) {
-      const uint32_t p = roots[i];
+      const uint32_t p = roots[i];   // (a root that lost a union: never its component's representative)
       uint32_t q;
       r = p;
-      while ((q = glb_load(&label[r])) != r) r = q;
-      if (r != p) {
-        label[p] = r;  // every chain through p now ends in one more hop
-        add = csize[p];
-      } else {
-        r = AT_NO_LABEL;
-      }
+      while ((q = glb_load(&label[r]) & AT_LABEL_MASK) != r) r = q;
+      label[p] = r;  // every chain through p now ends in one more hop
+      add = csize[p];
     }
     unsigned long long todo = __ballot(r != AT_NO_LABEL);
     for (int round = 0; round < 4 && todo; round++) {
@@ -550,8 +548,11 @@ __global__ __launch_bounds__(256) void k_cc_sizes(uint32_t* __restrict__ label_a
   }
 }
 
-// Second pass over the root list, after every k_cc_sizes thread has finished: the entry of every listed root -- the
-// representative included -- becomes representative | AT_LABEL_BIG-if-large-enough (see the header of this file).
+// Second pass over the list, after every k_cc_sizes thread has finished: where the representative's count has reached
+// min_component_size, the listed root's entry becomes representative | AT_LABEL_BIG and the representative's own entry gets the
+// bit (see the header of this file).  Plain stores: a listed root is visited by one thread, a representative's entry is only ever
+// written with the one value r | AT_LABEL_BIG, and no thread of this kernel reads an entry another one writes (the listed roots
+// and the representatives are disjoint sets).  Entries that need no bit stay as k_cc_sizes and k_cc_local left them.
 __global__ __launch_bounds__(256) void k_cc_resolve(uint32_t* __restrict__ label_all, const uint32_t* __restrict__ csize_all,
                                                     const uint32_t* __restrict__ roots_all,
                                                     const FrameCounters* __restrict__ counters, DetParams P) {
@@ -560,12 +561,14 @@ __global__ __launch_bounds__(256) void k_cc_resolve(uint32_t* __restrict__ label
   uint32_t* label = label_all + (size_t)frame * n;
   const uint32_t* csize = csize_all + (size_t)frame * n;
   const uint32_t* roots = roots_all + (size_t)frame * P.rcap;
-  const uint32_t nroots = counters[frame].nroots;
+  const uint32_t nroots = min(counters[frame].nroots, P.rcap);
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nroots; i += gridDim.x * 256) {
     const uint32_t p = roots[i];
-    // (k_cc_sizes left label[p] = representative; another thread may already have flagged a representative's own entry)
-    const uint32_t r = __hip_atomic_load(&label[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & AT_LABEL_MASK;
-    if ((int)csize[r] >= P.min_component_size) atomicOr(&label[p], AT_LABEL_BIG);
+    const uint32_t r = label[p];   // (k_cc_sizes left the representative there, without the bit)
+    if ((int)csize[r] >= P.min_component_size) {
+      label[p] = r | AT_LABEL_BIG;
+      label[r] = r | AT_LABEL_BIG;
+    }
   }
 }
 

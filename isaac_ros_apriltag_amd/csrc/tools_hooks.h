@@ -10,7 +10,7 @@
 //   -DAMDAT_FQ_NO_*         one of the quad fit's sound early exits compiled out (see below)
 //   -DAMDAT_MUTATE=n        a deliberately WRONG build for tools/mutation_check.sh, which shows that the GPU suite fails on it:
 //                           1 = the launch sequence leaves out k_fit_small (the throughput set's small-cluster fit);
-//                           2 = k_cc_local<4> flags the perimeter on the wrong last row (one row constant off in the 4-wave instance only)
+//                           2 = k_cc_local<4> writes the wrong row as its tile's last perimeter row (one row constant off in the 4-wave instance only)
 //                           3 = k_fit_prefilter<64>'s 64-sector test counts one sector too many at either end of every forward arc
 //                               (the cut sectors themselves, which hold the corners): it then "proves" real quads above 2048 points
 //                               impossible and drops them
