@@ -425,6 +425,7 @@ __device__ __forceinline__ void cc_column_requests(int W, int gx, bool upward, u
 #ifndef CC_ILEAVE
 #define CC_ILEAVE 256
 #endif
+template <bool PER_WAVE>
 __global__ __launch_bounds__(256) void k_cc_border(const uint32_t* __restrict__ perim_all, uint32_t* __restrict__ label_all,
                                                    uint32_t* __restrict__ roots_all, FrameCounters* __restrict__ counters,
                                                    uint32_t bpf, uint32_t nframes, DetParams P) {
@@ -439,8 +440,10 @@ __global__ __launch_bounds__(256) void k_cc_border(const uint32_t* __restrict__ 
   const int ncols = (W - 1) / CC_T;  // tile-left columns at x = 64, 128, ...
   int i = (int)blk_ * 256 + threadIdx.x;
   __shared__ uint32_t s_lost, s_base;
-  if (threadIdx.x == 0) s_lost = 0;
-  __syncthreads();
+  if (!PER_WAVE) {
+    if (threadIdx.x == 0) s_lost = 0;
+    __syncthreads();
+  }
   uint32_t lost[3];
   uint32_t ra[3] = {AT_NO_LABEL, AT_NO_LABEL, AT_NO_LABEL}, rb[3] = {AT_NO_LABEL, AT_NO_LABEL, AT_NO_LABEL};
   if (i < nrows * W) {
@@ -485,15 +488,27 @@ __global__ __launch_bounds__(256) void k_cc_border(const uint32_t* __restrict__ 
     lost[k] = mine ? glb_union(label, a, b2) : AT_NO_LABEL;
   }
   // The roots this block's unions turned into non-roots go to the frame's list -- these, and only these, are the tile-local roots
-  // whose entry, size and size bit k_cc_sizes / k_cc_resolve still have to settle.  One append per BLOCK: the list's counter is one
-  // word per frame, and a one-frame submission has a thousand waves here (one add per wave and request slot cost such a call 15 us).
+  // whose entry, size and size bit k_cc_sizes / k_cc_resolve still have to settle.  Small submissions append once per BLOCK: the
+  // list's counter is one word per frame, and a one-frame submission has a thousand waves here (one add per wave and request slot
+  // cost such a call 15 us).  Large ones -- their blocks in flight belong to different frames -- append once per WAVE and spare the
+  // two barriers, behind which a block's waves wait for its slowest chase.
   const uint32_t mycnt = (lost[0] != AT_NO_LABEL ? 1u : 0u) + (lost[1] != AT_NO_LABEL ? 1u : 0u) + (lost[2] != AT_NO_LABEL ? 1u : 0u);
-  uint32_t pos = mycnt ? atomicAdd(&s_lost, mycnt) : 0u;
-  __syncthreads();
-  if (threadIdx.x == 0 && s_lost) s_base = atomicAdd(&counters[frame].nroots, s_lost);
-  __syncthreads();
-  if (mycnt) {
+  uint32_t pos;
+  if (PER_WAVE) {
+    const uint32_t incl = wave_incl_scan(mycnt);
+    const uint32_t wtotal = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (wtotal == 0) return;   // (uniform)
+    uint32_t base = 0;
+    if (lane_id() == 63) base = atomicAdd(&counters[frame].nroots, wtotal);
+    pos = (uint32_t)__builtin_amdgcn_readlane((int)base, 63) + incl - mycnt;
+  } else {
+    pos = mycnt ? atomicAdd(&s_lost, mycnt) : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_lost) s_base = atomicAdd(&counters[frame].nroots, s_lost);
+    __syncthreads();
     pos += s_base;
+  }
+  if (mycnt) {
 #pragma unroll
     for (int k = 0; k < 3; k++)
       if (lost[k] != AT_NO_LABEL) {
