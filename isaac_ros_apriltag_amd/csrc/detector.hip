@@ -1115,7 +1115,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
   {
     const int nrows = (P.H - 1) / CC_T, ncols = (P.W - 1) / CC_T;
     const long total = (long)nrows * P.W + (long)ncols * P.H;
-    if (total > 0)
+    if (total > 0) {
 #define BORDER_ARGS dim3((unsigned)((total + 255) / 256) * n), dim3(256), 0, s, D->d_perim, D->d_label, D->d_roots, D->d_counters,   \
                     (uint32_t)((total + 255) / 256), n, P
 #ifndef AMDAT_BORDER_PER_WAVE
@@ -1124,6 +1124,7 @@ static int issue_pipeline(amdAprilTagsDetector_st* D, uint32_t n, uint32_t ostri
       if (!AMDAT_BORDER_PER_WAVE || small_submission(D, P, n)) hipLaunchKernelGGL((k_cc_border<false>), BORDER_ARGS);   // (one list append per block)
       else hipLaunchKernelGGL((k_cc_border<true>), BORDER_ARGS);                               // (per wave, no barriers)
 #undef BORDER_ARGS
+    }
   }
   mark();
   {
