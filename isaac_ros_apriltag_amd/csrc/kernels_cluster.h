@@ -40,6 +40,28 @@ __device__ __forceinline__ uint32_t hash_insert(unsigned long long* hkeys, uint3
   return AT_INVALID_SLOT;
 }
 
+// the same, with the load of the home slot already made (`cur0`: what it held then -- the table only ever turns empty slots into
+// keys, so a key seen there is final and an empty slot is settled by the CAS)
+__device__ __forceinline__ uint32_t hash_insert_probed(unsigned long long* hkeys, uint32_t hcap, uint32_t hshift, uint64_t key, unsigned long long cur0) {
+  uint32_t h = hash_slot(key, hshift);
+  if (cur0 == key) return h;
+  if (cur0 == AT_EMPTY_KEY) {
+    unsigned long long old = atomicCAS(&hkeys[h], AT_EMPTY_KEY, (unsigned long long)key);
+    if (old == AT_EMPTY_KEY || old == key) return h;
+  }
+  h = (h + 1) & (hcap - 1);
+  for (uint32_t probe = 1; probe < hcap; probe++) {
+    unsigned long long cur = __hip_atomic_load(&hkeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == key) return h;
+    if (cur == AT_EMPTY_KEY) {
+      unsigned long long old = atomicCAS(&hkeys[h], AT_EMPTY_KEY, (unsigned long long)key);
+      if (old == AT_EMPTY_KEY || old == key) return h;
+    }
+    h = (h + 1) & (hcap - 1);
+  }
+  return AT_INVALID_SLOT;
+}
+
 #define PT_WHITE 0x80000000u   // slab word of k_points: class bits (white / black; neither: not in a counted component) ...
 #define PT_BLACK 0x40000000u
 #define PT_REP_MASK 0x3FFFFFFFu   // ... above the component's representative (a pixel index: images below 2^30 pixels)
@@ -365,6 +387,18 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
   }
   PT_TICK(3)
   PT_STOP_AT(3, stage_all[(size_t)frame * P.pcap + (blk_ % 64u) * 256 + tid] = emask ^ off ^ elist[tid] ^ sbase)
+#ifndef PT_EARLY_PROBE
+#define PT_EARLY_PROBE 1
+#endif
+  // The frame-table phase at the end of the block is a chain of two or three dependent round trips to the memory side per table
+  // entry (0.37 ms of the kernel: a build that stops before it).  Its first one -- the load of the key's home slot -- is issued
+  // HERE, as soon as this wave is through its share of the list, for the entry the thread will own (other waves may still add
+  // entries: those are probed at the end as before), and is in flight while the wave waits at the barrier below.
+  unsigned long long pf_key = AT_EMPTY_KEY, pf_cur = 0;
+  if (PT_EARLY_PROBE) {
+    pf_key = __hip_atomic_load(&tkey[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (pf_key != AT_EMPTY_KEY) pf_cur = __hip_atomic_load(&hkeys[hash_slot(pf_key, P.hshift)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (off + cnt > PT_ELIST) {   // this thread's emissions beyond the list
     uint32_t q = off, m = emask;
     while (m) {
@@ -374,7 +408,16 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
       q++;
     }
   }
-  __syncthreads();   // the block table's counts are complete
+  // the block table's counts are complete.  (An LDS-only barrier: nothing global is handed from thread to thread across it, and
+  // __syncthreads' fence would wait for the probe above -- every outstanding global access -- in front of the barrier, in the
+  // wave that arrives last as in the others.)
+  if (PT_EARLY_PROBE) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  } else {
+    __syncthreads();
+  }
   PT_TICK(4)
   PT_STOP_AT(5, (void)0)
   {
@@ -385,7 +428,8 @@ __global__ __launch_bounds__(256) void k_points(const uint8_t* __restrict__ thr_
     // behind a barrier: 0.8 ms of the kernel).
     const unsigned long long key = tkey[tid];
     if (key != AT_EMPTY_KEY) {
-      const uint32_t slot = hash_insert(hkeys, P.hcap, P.hshift, key);
+      const uint32_t slot = (PT_EARLY_PROBE && key == pf_key) ? hash_insert_probed(hkeys, P.hcap, P.hshift, key, pf_cur)
+                                                              : hash_insert(hkeys, P.hcap, P.hshift, key);
       uint32_t kbase = 0;
       if (slot != AT_INVALID_SLOT) kbase = atomicAdd(&hcnt[slot], tcnt[tid]);
       else atomicOr(&counters[frame].flags, 0x2u);
